@@ -1,0 +1,111 @@
+"""ctypes binding of libarmenv.so (C ABI: include/armenv.h).  No fallback: if the library is missing or
+no HIP device is usable, calls raise ``ArmEnvError``."""
+import ctypes as C
+import os
+
+NJ = 7
+ABI_VERSION = 1
+TASK_REACH, TASK_PUSH = 0, 1
+ROBOT_KUKA, ROBOT_DIANA = 0, 1
+FK_AUTO, FK_GENERIC = 0, 1
+POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarmenv.so")
+
+
+class ArmEnvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"armenv error {code}: {msg}")
+        self.code = code
+
+
+class ArmEnvChain(C.Structure):
+    _fields_ = [("origin_xyz", C.c_double * 3 * NJ), ("origin_rpy", C.c_double * 3 * NJ),
+                ("limit_lo", C.c_double * NJ), ("limit_hi", C.c_double * NJ),
+                ("base_xyz", C.c_double * 3), ("base_rpy", C.c_double * 3)]
+
+
+class ArmEnvConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("num_envs", C.c_int64),
+        ("task", C.c_int32), ("precision", C.c_int32), ("fk_path", C.c_int32), ("auto_reset", C.c_int32),
+        ("seed", C.c_uint64), ("env_id_offset", C.c_uint64),
+        ("dv", C.c_double), ("reach_dis", C.c_double), ("max_steps", C.c_int32), ("clamp_joint_limits", C.c_int32),
+        ("box_lo", C.c_double * 3), ("box_hi", C.c_double * 3), ("goal_lo", C.c_double * 3), ("goal_hi", C.c_double * 3),
+        ("target_quat", C.c_double * 4), ("q_init", C.c_double * NJ),
+        ("ik_lambda", C.c_double), ("ik_residual", C.c_double), ("ik_max_dtheta", C.c_double),
+        ("ik_max_iters", C.c_int32), ("ik_exit_mode", C.c_int32), ("ik_angle_f32", C.c_int32), ("reserved0", C.c_int32),
+        ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
+        ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
+        ("chain", ArmEnvChain),
+    ]
+
+
+# every symbol include/armenv.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "armenv_default_config": (C.c_int, [C.c_int32, C.POINTER(ArmEnvConfig)]),
+    "armenv_builtin_chain": (C.c_int, [C.c_int32, C.POINTER(ArmEnvChain)]),
+    "armenv_create": (C.c_int, [C.POINTER(ArmEnvConfig), C.POINTER(_P)]),
+    "armenv_destroy": (None, [_P]),
+    "armenv_reset": (C.c_int, [_P, _P, _P, _P]),
+    "armenv_reset_with_goal": (C.c_int, [_P, _P, _P, _P, _P]),
+    "armenv_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "armenv_fk": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P]),
+    "armenv_ik": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "armenv_get_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "armenv_set_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "armenv_episode_stats": (C.c_int, [_P, _P, _P, _P, _P]),
+    "armenv_counters": (C.c_int, [_P, C.POINTER(C.c_uint64 * 4), _P]),
+    "armenv_set_policy": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "armenv_num_envs": (C.c_int64, [_P]),
+    "armenv_obs_dim": (C.c_int32, [_P]),
+    "armenv_action_dim": (C.c_int32, [_P]),
+    "armenv_kernel_name": (C.c_char_p, [_P]),
+    "armenv_last_error": (C.c_char_p, []),
+    "armenv_abi_version": (C.c_int32, []),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libarmenv.so (built by `make -C drl-on-robot-arm_amd` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ArmEnvError(-2, f"{LIB_PATH} not found: build it with `make -C drl-on-robot-arm_amd` "
+                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.armenv_abi_version() != ABI_VERSION:
+            raise ArmEnvError(-1, "libarmenv.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ArmEnvError(rc, load().armenv_last_error().decode())
+
+
+def default_config(task=TASK_REACH) -> ArmEnvConfig:
+    cfg = ArmEnvConfig()
+    check(load().armenv_default_config(task, C.byref(cfg)))
+    return cfg
+
+
+def chain_struct(chain) -> ArmEnvChain:
+    """armenv.urdf.Chain -> ArmEnvChain."""
+    s = ArmEnvChain()
+    for j in range(NJ):
+        s.origin_xyz[j][:] = chain.origin_xyz[j]
+        s.origin_rpy[j][:] = chain.origin_rpy[j]
+        s.limit_lo[j] = chain.limit_lo[j]
+        s.limit_hi[j] = chain.limit_hi[j]
+    s.base_xyz[:] = chain.base_xyz
+    s.base_rpy[:] = chain.base_rpy
+    return s

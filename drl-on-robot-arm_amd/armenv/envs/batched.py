@@ -1,0 +1,195 @@
+"""Batched, device-resident counterpart of the reference's gym-style envs.
+
+``BatchedReachEnv`` advances N independent RLReachEnv instances
+(/root/reference/envs/rl_reach_env.py:38-322) per call through libarmenv.so's fused HIP kernel.  Inputs
+and outputs are PyTorch-ROCm tensors on the env's device; PyTorch is used only for device memory and
+streams -- every number is produced by the HIP kernels behind the C ABI (include/armenv.h).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..spaces import Box
+from ..urdf import Chain, builtin_chain
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedArmEnv:
+    """Common plumbing: handle life-cycle, stream handling, state exchange."""
+
+    task = L.TASK_REACH
+    obs_dim = 6
+
+    def __init__(self, num_envs, device="cuda:0", seed=0, auto_reset=True, precision=64, robot="kuka",
+                 chain: Chain = None, env_id_offset=0, fk_path=L.FK_AUTO, **overrides):
+        self._h = None
+        lib = L.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.ArmEnvError(-2, f"device {device!r}: the engine runs on HIP devices only (no CPU fallback)")
+        self.num_envs = int(num_envs)
+        cfg = L.default_config(self.task)
+        cfg.device = self.device.index or 0
+        cfg.num_envs = self.num_envs
+        cfg.precision = precision
+        cfg.fk_path = fk_path
+        cfg.auto_reset = 1 if auto_reset else 0
+        cfg.seed = seed
+        cfg.env_id_offset = env_id_offset
+        self.chain = chain if chain is not None else builtin_chain(robot)
+        cfg.chain = L.chain_struct(self.chain)
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown config field {k!r}")
+            cur = getattr(cfg, k)
+            if hasattr(cur, "__len__"):
+                cur[:] = v
+            else:
+                setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        L.check(lib.armenv_create(C.byref(cfg), C.byref(h)))
+        self._h, self._lib = h, lib
+        n, dev = self.num_envs, self.device
+        self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=dev)
+        self._reward = torch.empty(n, dtype=torch.float32, device=dev)
+        self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._success = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._terminal = None
+        self.action_space = Box(low=[-0.4, -0.4, -0.6], high=[0.4, 0.4, 0.3])       # rl_reach_env.py:87-90
+        self.max_steps_one_episode = int(cfg.max_steps)
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def kernel_name(self):
+        return self._lib.armenv_kernel_name(self._h).decode()
+
+    def close(self):
+        if self._h is not None:
+            torch.cuda.synchronize(self.device)
+            self._lib.armenv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check_action(self, action):
+        if action.device != self.device or action.dtype != torch.float32 or tuple(action.shape) != (self.num_envs, 3) \
+                or not action.is_contiguous():
+            raise ValueError(f"action must be a contiguous float32 tensor [{self.num_envs}, 3] on {self.device}")
+
+    # ------------------------------------------------------------------ gym-style API, batched
+    def reset(self, mask=None, goal=None):
+        """Reset all envs (or those with mask != 0).  Returns obs [N, obs_dim] (rows of envs that were
+        not reset keep their previous contents)."""
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        if goal is None:
+            L.check(self._lib.armenv_reset(self._h, _ptr(m), _ptr(self._obs), self._stream()))
+        else:
+            g = goal.to(device=self.device, dtype=torch.float32).contiguous()
+            L.check(self._lib.armenv_reset_with_goal(self._h, _ptr(m), _ptr(g), _ptr(self._obs), self._stream()))
+        return self._obs
+
+    def step(self, action, want_terminal_obs=False):
+        """One env step for all N envs; no host synchronisation.  Returns (obs, reward, done, success)
+        -- the same preallocated tensors every call (clone them to keep a history).  With
+        want_terminal_obs the pre-reset observation is available as ``self.terminal_obs``."""
+        self._check_action(action)
+        if want_terminal_obs and self._terminal is None:
+            self._terminal = torch.empty_like(self._obs)
+        term = self._terminal if want_terminal_obs else None
+        L.check(self._lib.armenv_step(self._h, _ptr(action), _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
+                                      _ptr(self._success), _ptr(term), self._stream()))
+        return self._obs, self._reward, self._done.view(torch.bool), self._success.view(torch.bool)
+
+    @property
+    def terminal_obs(self):
+        return self._terminal
+
+    # ------------------------------------------------------------------ engine calls the reference makes
+    def fk(self, q):
+        """p.getLinkState(body, 6)[4], [5]: q [n,7] f64 -> (pos [n,3], quat xyzw [n,4]) f64."""
+        q = q.to(device=self.device, dtype=torch.float64).contiguous().reshape(-1, 7)
+        n = q.shape[0]
+        pos = torch.empty((n, 3), dtype=torch.float64, device=self.device)
+        quat = torch.empty((n, 4), dtype=torch.float64, device=self.device)
+        L.check(self._lib.armenv_fk(self._h, n, _ptr(q), _ptr(pos), _ptr(quat), self._stream()))
+        return pos, quat
+
+    def ik(self, q, target_pos):
+        """p.calculateInverseKinematics: q [n,7], target [n,3] f64 -> (q_out [n,7] f64, updates [n] i32)."""
+        q = q.to(device=self.device, dtype=torch.float64).contiguous().reshape(-1, 7)
+        t = target_pos.to(device=self.device, dtype=torch.float64).contiguous().reshape(-1, 3)
+        n = q.shape[0]
+        out = torch.empty_like(q)
+        iters = torch.empty(n, dtype=torch.int32, device=self.device)
+        L.check(self._lib.armenv_ik(self._h, n, _ptr(q), _ptr(t), _ptr(out), _ptr(iters), self._stream()))
+        return out, iters
+
+    # ------------------------------------------------------------------ state exchange / stats
+    def get_state(self):
+        n, dev = self.num_envs, self.device
+        st = dict(q=torch.empty((n, 7), dtype=torch.float64, device=dev),
+                  goal=torch.empty((n, 3), dtype=torch.float32, device=dev),
+                  step=torch.empty(n, dtype=torch.int32, device=dev),
+                  episode=torch.empty(n, dtype=torch.int32, device=dev),   # u32 bits
+                  ep_return=torch.empty(n, dtype=torch.float64, device=dev))
+        L.check(self._lib.armenv_get_state(self._h, _ptr(st["q"]), _ptr(st["goal"]), _ptr(st["step"]),
+                                           _ptr(st["episode"]), _ptr(st["ep_return"]), None, self._stream()))
+        return st
+
+    def set_state(self, q=None, goal=None, step=None, episode=None, ep_return=None):
+        dev = self.device
+
+        def prep(x, dt, shape):
+            if x is None:
+                return None
+            x = torch.as_tensor(x).to(device=dev, dtype=dt).contiguous()
+            assert tuple(x.shape) == shape, (tuple(x.shape), shape)
+            return x
+        n = self.num_envs
+        q_, g_, s_, e_, r_ = (prep(q, torch.float64, (n, 7)), prep(goal, torch.float32, (n, 3)),
+                              prep(step, torch.int32, (n,)), prep(episode, torch.int32, (n,)),
+                              prep(ep_return, torch.float64, (n,)))
+        L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), None,
+                                           self._stream()))
+        torch.cuda.current_stream(dev).synchronize()   # temporaries above must outlive the copy
+
+    def episode_stats(self):
+        """(return, length, success) of each env's most recently finished episode."""
+        n, dev = self.num_envs, self.device
+        ret = torch.empty(n, dtype=torch.float64, device=dev)
+        ln = torch.empty(n, dtype=torch.int32, device=dev)
+        su = torch.empty(n, dtype=torch.uint8, device=dev)
+        L.check(self._lib.armenv_episode_stats(self._h, _ptr(ret), _ptr(ln), _ptr(su), self._stream()))
+        return ret, ln, su
+
+    def counters(self):
+        out = (C.c_uint64 * 4)()
+        L.check(self._lib.armenv_counters(self._h, C.byref(out), self._stream()))
+        return dict(episodes=out[0], successes=out[1], env_steps=out[2], nonfinite=out[3])
+
+
+class BatchedReachEnv(BatchedArmEnv):
+    """N x RLReachEnv (/root/reference/envs/rl_reach_env.py)."""
+    task = L.TASK_REACH
+    obs_dim = 6
+
+    def __init__(self, num_envs, **kw):
+        super().__init__(num_envs, **kw)
+        lo = [0.2, -0.3, 0.0] * 2
+        hi = [0.7, 0.3, 0.55] * 2
+        self.observation_space = Box(low=lo, high=hi)                                 # rl_reach_env.py:93-96

@@ -1,0 +1,197 @@
+/*
+ * armenv.h -- C ABI of the MI355X-native batched robot-arm environment engine (libarmenv.so).
+ *
+ * Drop-in boundary for the env hot path of Shimly-2/DRL-on-robot-arm.  The reference has no FFI of
+ * its own (it is Python over the third-party pybullet C++ extension); the entry points below are
+ * what a binding for that path replaces, cited as /root/reference file:line on each function.
+ * A maintainer's ctypes stub is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / HIP types in any signature.
+ *   - `*_dev` pointers are DEVICE pointers owned by the caller (e.g. torch tensor.data_ptr()),
+ *     valid until the work enqueued on `stream` has completed.  `stream` is a hipStream_t passed
+ *     as void* (NULL = the default stream).  No call allocates, frees or synchronises unless it
+ *     says so; step/reset only enqueue kernels.
+ *   - Every function returns ARMENV_OK (0) or a negative error code; the message is available
+ *     from armenv_last_error() (thread-local).  Nothing aborts.
+ *   - A handle is not thread-safe; distinct handles (one per GPU / per stream) are independent.
+ *   - There is no CPU fallback: creating a handle without a usable HIP device fails with
+ *     ARMENV_ENODEV.
+ *
+ * Layouts (N = num_envs):
+ *   action  f32 [N][3]      obs  f32 [N][obs_dim]  (reach: 6 = [eef xyz, goal xyz];
+ *                                                    push: 9 = [eef, cube, target])
+ *   reward  f32 [N]         done / success  u8 [N]
+ *   state exchange (get/set_state): q f64 [N][7], goal f32 [N][3], step i32 [N],
+ *                                   episode u32 [N], ep_return f64 [N]
+ */
+#ifndef ARMENV_H
+#define ARMENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARMENV_NJ 7
+#define ARMENV_ABI_VERSION 1
+
+enum {
+  ARMENV_OK = 0,
+  ARMENV_EINVAL = -1,   /* bad argument / config */
+  ARMENV_ENODEV = -2,   /* no HIP device or wrong device index */
+  ARMENV_ENOMEM = -3,   /* device allocation failed */
+  ARMENV_EHIP = -4,     /* a HIP runtime call failed (message has the HIP error string) */
+  ARMENV_ESTATE = -5    /* call not valid in the handle's current state (e.g. actor not set) */
+};
+
+enum { ARMENV_TASK_REACH = 0, ARMENV_TASK_PUSH = 1 };
+enum { ARMENV_ROBOT_KUKA = 0, ARMENV_ROBOT_DIANA = 1 };
+enum { ARMENV_FK_AUTO = 0, ARMENV_FK_GENERIC = 1 };
+enum { ARMENV_POLICY_EXTERNAL = 0, ARMENV_POLICY_RANDOM = 1, ARMENV_POLICY_ACTOR = 2 };
+
+typedef struct ArmEnv ArmEnv;
+
+/* 7-revolute serial chain, every joint axis +z of its child frame (both robots the reference
+ * uses: /root/reference/envs/bmirobot_joints_info_pybullet.txt field 14).  URDF semantics:
+ * child frame = parent frame * Trans(origin_xyz) * Rz(yaw)Ry(pitch)Rx(roll) * Rz(q). */
+typedef struct ArmEnvChain {
+  double origin_xyz[ARMENV_NJ][3];
+  double origin_rpy[ARMENV_NJ][3];
+  double limit_lo[ARMENV_NJ];
+  double limit_hi[ARMENV_NJ];
+  double base_xyz[3];
+  double base_rpy[3];
+} ArmEnvChain;
+
+typedef struct ArmEnvConfig {
+  int32_t abi_version;     /* must be ARMENV_ABI_VERSION */
+  int32_t device;          /* HIP device ordinal */
+  int64_t num_envs;        /* N */
+  int32_t task;            /* ARMENV_TASK_* */
+  int32_t precision;       /* 64: state + arithmetic in f64 (the reference's number type); 32: f32 */
+  int32_t fk_path;         /* ARMENV_FK_AUTO picks the signed-permutation fast path for KUKA / Diana */
+  int32_t auto_reset;      /* 1: an env that finishes is reset inside the same step call */
+  uint64_t seed;           /* Philox key */
+  uint64_t env_id_offset;  /* global index of env 0 (rank * N when sharding across GPUs) */
+
+  /* task constants; armenv_default_config() fills the reference's values */
+  double dv;               /* /root/reference/config.py:41 (reach 0.02); envs/rl_push_env.py:322 (push 0.08) */
+  double reach_dis;        /* config.py:42 */
+  int32_t max_steps;       /* config.py:51 ; done when step_counter > max_steps (rl_reach_env.py:299) */
+  int32_t clamp_joint_limits; /* 0 = reference behaviour (limits are dead data, rl_reach_env.py:103-107) */
+  double box_lo[3];        /* Cartesian clip, rl_reach_env.py:221-223 */
+  double box_hi[3];
+  double goal_lo[3];       /* target sampling box, rl_reach_env.py:65-70,180-182 */
+  double goal_hi[3];
+  double target_quat[4];   /* xyzw, rl_reach_env.py:121-122 */
+  double q_init[ARMENV_NJ];/* rl_reach_env.py:116-119 */
+
+  /* IK: pybullet.calculateInverseKinematics defaults for the call at rl_reach_env.py:244-250 */
+  double ik_lambda;        /* jointDamping 1e-5, rl_reach_env.py:111-113 */
+  double ik_residual;      /* 1e-4 */
+  double ik_max_dtheta;    /* 45 deg */
+  int32_t ik_max_iters;    /* 20 */
+  int32_t ik_exit_mode;    /* 0 Bullet loop, 1 test-before-update */
+  int32_t ik_angle_f32;    /* 1: orientation-error angle rounded through f32 as Bullet does */
+  int32_t reserved0;
+
+  /* push task, /root/reference/envs/rl_push_env.py */
+  double push_success_dis; /* 0.05  :422 */
+  double push_cube_half;   /* 0.02  models/cube_small_push.urdf */
+  double push_eef_radius;  /* pusher radius of the simplified contact model */
+  double push_rest_z;      /* z at which the cube rests */
+  double push_place_min;   /* 0.22  :213 */
+  double push_place_max;   /* 0.25  :213 */
+
+  ArmEnvChain chain;
+} ArmEnvConfig;
+
+/* Fills `cfg` with the constants of RLReachEnv.__init__ / RLPushEnv.__init__
+ * (/root/reference/envs/rl_reach_env.py:44-125, envs/rl_push_env.py:49-143), Bullet's IK defaults and
+ * the KUKA iiwa chain.  num_envs is set to 1, precision to 64, auto_reset to 1. */
+int armenv_default_config(int32_t task, ArmEnvConfig *cfg);
+
+/* Built-in chains: KUKA iiwa (the robot reach/push/pick load, rl_reach_env.py:174) and Diana S1
+ * (/root/reference/models/diana/DianaS1_robot.urdf, loaded by envs/diana_cam_reach.py:201). */
+int armenv_builtin_chain(int32_t robot, ArmEnvChain *out);
+
+/* Replaces RLReachEnv.__init__ minus its implicit reset (rl_reach_env.py:44-125): allocates the
+ * per-env state on `cfg->device`.  State is undefined until the first armenv_reset. */
+int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out);
+void armenv_destroy(ArmEnv *env);
+
+/* Replaces RLReachEnv.reset / RLPushEnv.reset (rl_reach_env.py:132-217, rl_push_env.py:145-256) for
+ * the envs whose mask byte is non-zero (mask_dev == NULL: all).  Goals come from the engine's
+ * Philox stream.  obs_dev (nullable) receives the first observation of the reset envs only. */
+int armenv_reset(ArmEnv *env, const uint8_t *mask_dev, float *obs_dev, void *stream);
+
+/* Same, with caller-supplied goals f32 [N][3] (reach) -- the N=1 compatibility class uses this to
+ * keep the reference's Python `random` stream (rl_reach_env.py:180-183). Push: goal_dev is
+ * f32 [N][6] = [cube xyz, target xyz]. */
+int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *goal_dev, float *obs_dev,
+                           void *stream);
+
+/* Replaces RLReachEnv.step + _reward (rl_reach_env.py:219-319) / RLPushEnv.step + _reward
+ * (rl_push_env.py:310-440) for all N envs in one fused kernel:
+ *   FK -> add dv*action -> clip to the workspace box -> DLS IK -> FK -> distance/reward/done -> obs.
+ * action_dev may be NULL when a fused policy was installed with armenv_set_policy.
+ * terminal_obs_dev (nullable, f32 [N][obs_dim]) receives the observation of this step before any
+ * auto-reset; with auto_reset the obs of a finished env is its next episode's first observation. */
+int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+                uint8_t *success_dev, float *terminal_obs_dev, void *stream);
+
+/* Replaces p.getLinkState(body, 6)[4], [5] (call sites rl_reach_env.py:202,237,271): world position
+ * f64 [n][3] and orientation quaternion xyzw f64 [n][4] (nullable) of the link-7 frame for joint
+ * vectors q f64 [n][7].  Uses the handle's chain; n is independent of num_envs. */
+int armenv_fk(ArmEnv *env, int64_t n, const double *q_dev, double *pos_dev, double *quat_dev, void *stream);
+
+/* Replaces p.calculateInverseKinematics(body, 6, pos, orn, jointDamping) (rl_reach_env.py:244-250):
+ * q_out f64 [n][7] from start q f64 [n][7] and target position f64 [n][3]; orientation target is the
+ * handle's target_quat.  iters_dev (nullable) receives the number of DLS updates applied. */
+int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_pos_dev, double *q_out_dev,
+              int32_t *iters_dev, void *stream);
+
+/* State exchange for teacher-forced parity tests and checkpointing (the reference keeps this state
+ * inside the PyBullet client: joint angles via resetJointState rl_reach_env.py:252-257, target via
+ * loadURDF :186-189, step_counter :264).  Any pointer may be NULL to skip that field. Push adds
+ * aux f64 [N][8] = [cube xyz, target xyz, d_last, pad]. */
+int armenv_get_state(ArmEnv *env, double *q_dev, float *goal_dev, int32_t *step_dev, uint32_t *episode_dev,
+                     double *ep_return_dev, double *aux_dev, void *stream);
+int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, const int32_t *step_dev,
+                     const uint32_t *episode_dev, const double *ep_return_dev, const double *aux_dev,
+                     void *stream);
+
+/* Per-env statistics of the most recently finished episode (what main.py:125-130 accumulates on
+ * the host: episode_return, success).  Any pointer may be NULL. */
+int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len_dev, uint8_t *last_success_dev,
+                         void *stream);
+
+/* Totals since creation, copied to host (synchronises `stream`): out[0] episodes finished,
+ * out[1] successes, out[2] env-steps executed, out[3] non-finite joint states seen. */
+int armenv_counters(ArmEnv *env, uint64_t out[4], void *stream);
+
+/* Installs the TD3 actor (PolicyNet, /root/reference/algo/TD3/net_mlp.py:29-40; take_action
+ * algo/TD3/TD3_mlp.py:82-97) for fused stepping: a = action_bound * tanh(W3 relu(W2 relu(W1 s + b1) + b2) + b3),
+ * then the rollout loop's exploration a = clip(a + N(0, noise_sigma), +-noise_clip) (main.py:116-117).
+ * Weights are DEVICE pointers in torch Linear layout ([out][in], f32) and are copied.
+ * policy = ARMENV_POLICY_RANDOM ignores the weights (zero actor, noise only). */
+int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const float *b1_dev, const float *W2_dev,
+                      const float *b2_dev, const float *W3_dev, const float *b3_dev, int32_t hidden_dim,
+                      float action_bound, float noise_sigma, float noise_clip, void *stream);
+
+/* Shape / capability queries. */
+int64_t armenv_num_envs(const ArmEnv *env);
+int32_t armenv_obs_dim(const ArmEnv *env);
+int32_t armenv_action_dim(const ArmEnv *env);
+/* name of the step kernel variant in use, e.g. "reach_step<f64,kuka>" (for profiles) */
+const char *armenv_kernel_name(const ArmEnv *env);
+
+const char *armenv_last_error(void);
+int32_t armenv_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARMENV_H */

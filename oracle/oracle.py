@@ -1,0 +1,290 @@
+"""ctypes front-end of the CPU oracle (oracle/armenv_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- never from the product package.  Parity against real
+PyBullet is UNPINNED (pybullet is not installable here); see the header of armenv_oracle.c for
+what does pin it.
+
+The chain tables below are entered independently of the product's URDF assets so that the two
+can be cross-checked:
+  KUKA iiwa : SURVEY.md Appendix A (pybullet_data/kuka_iiwa/model.urdf is not vendored by the
+              reference; pinned by /root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7 and the
+              FK known answer at /root/reference/main.py:106)
+  Diana S1  : /root/reference/models/diana/DianaS1_robot.urdf:30,60,90,120,150,180,210
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "build", "liboracle.so")
+
+NJ = 7
+H = 1.57079632679      # the URDF text value, not math.pi/2
+PI = 3.14159265359
+
+KUKA = dict(
+    xyz=[(0, 0, 0.1575), (0, 0, 0.2025), (0, 0.2045, 0), (0, 0, 0.2155), (0, 0.1845, 0), (0, 0, 0.2155), (0, 0.081, 0)],
+    rpy=[(0, 0, 0), (H, 0, PI), (H, 0, PI), (H, 0, 0), (-H, PI, 0), (H, 0, 0), (-H, PI, 0)],
+    limit=[2.96705972839, 2.09439510239, 2.96705972839, 2.09439510239, 2.96705972839, 2.09439510239, 3.05432619099],
+    inertial=[(-0.1, 0, 0.07), (0, -0.03, 0.12), (0.0003, 0.059, 0.042), (0, 0.03, 0.13), (0, 0.067, 0.034),
+              (0.0001, 0.021, 0.076), (0, 0.0006, 0.0004), (0, 0, 0.02)],
+)
+DIANA = dict(
+    xyz=[(0, 0, 0.2723), (0, -0.156, 0), (0, 0.4577, 0), (0, 0.1371, 0), (0, -0.449, 0), (0, -0.1365, 0), (0, 0.0825, 0)],
+    rpy=[(PI, 0, 0), (-H, 0, 0), (H, 0, 0), (H, 0, 0), (-H, 0, 0), (-H, 0, 0), (H, 0, 0)],
+    limit=[3.12413936107, 2.79252680319, 3.12413936107, 2.79252680319, 3.12413936107, 3.12413936107, 3.12413936107],
+    inertial=[(-0.00025974, -0.00026507, 0.024973), (-0.000108043, -0.044600027, 0.068607373),
+              (0.00000875698, 0.047132796, 0.006996823), (0.0000183253, 0.03187396, 0.136688085),
+              (-0.0000171058, -0.048491536, 0.007150206), (-0.000027456, -0.002120073, 0.13041583),
+              (0.0000262506, 0.003206123, 0.027090603), (0.0, 0.0001, 0.03405)],
+)
+ROBOTS = {"kuka": KUKA, "diana": DIANA}
+
+# /root/reference/envs/rl_reach_env.py:116-119
+INIT_Q = [0.006418, 0.413184, -0.011401, -1.589317, 0.005379, 1.137684, -0.006539]
+
+
+class OrcChain(C.Structure):
+    _fields_ = [("xyz", C.c_double * 3 * NJ), ("R", C.c_double * 9 * NJ),
+                ("base_p", C.c_double * 3), ("base_R", C.c_double * 9)]
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("dv", C.c_double), ("reach_dis", C.c_double), ("max_steps", C.c_int32), ("task", C.c_int32),
+        ("box_lo", C.c_double * 3), ("box_hi", C.c_double * 3),
+        ("goal_lo", C.c_double * 3), ("goal_hi", C.c_double * 3),
+        ("target_quat", C.c_double * 4), ("q_init", C.c_double * NJ),
+        ("ik_lambda", C.c_double), ("ik_residual", C.c_double), ("ik_max_dtheta", C.c_double),
+        ("ik_max_iters", C.c_int32), ("ik_exit_mode", C.c_int32), ("ik_angle_f32", C.c_int32),
+        ("ik_form", C.c_int32),
+        ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
+        ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (no GPU, no reference sources involved)."""
+    src = os.path.join(_HERE, "armenv_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_ik.restype = C.c_int
+        _lib.orc_dls_delta.restype = C.c_int
+    return _lib
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def quat_from_euler(rpy):
+    out = (C.c_double * 4)()
+    lib().orc_quat_from_euler((C.c_double * 3)(*rpy), out)
+    return list(out)
+
+
+def make_chain(robot="kuka", base_xyz=(0, 0, 0), base_rpy=(0, 0, 0)):
+    r = ROBOTS[robot] if isinstance(robot, str) else robot
+    xyz = np.ascontiguousarray(r["xyz"], dtype=np.float64)
+    rpy = np.ascontiguousarray(r["rpy"], dtype=np.float64)
+    ch = OrcChain()
+    lib().orc_chain_from_rpy(_p(xyz), _p(rpy), (C.c_double * 3)(*base_xyz), (C.c_double * 3)(*base_rpy), C.byref(ch))
+    return ch
+
+
+def default_config(task="reach"):
+    """Constants of RLReachEnv.__init__ (/root/reference/envs/rl_reach_env.py:44-125),
+    config.py:41-42,51, and Bullet's IK defaults."""
+    c = OrcConfig()
+    c.task = 0 if task == "reach" else 1
+    c.dv = 0.02 if task == "reach" else 0.08
+    c.reach_dis = 0.01
+    c.max_steps = 500
+    c.box_lo[:] = [0.2, -0.3, 0.0]
+    c.box_hi[:] = [0.7, 0.3, 0.55 if task == "reach" else 0.1]
+    c.goal_lo[:] = [0.2, -0.3, 0.0]
+    c.goal_hi[:] = [0.7, 0.3, 0.55]
+    c.target_quat[:] = quat_from_euler([0.0, -math.pi, math.pi / 2.0])
+    c.q_init[:] = INIT_Q
+    c.ik_lambda = 1e-5
+    c.ik_residual = 1e-4
+    c.ik_max_dtheta = 45.0 * math.pi / 180.0
+    c.ik_max_iters = 20
+    c.ik_exit_mode = 0
+    c.ik_angle_f32 = 1
+    c.ik_form = 0
+    c.push_success_dis = 0.05
+    c.push_cube_half = 0.02
+    c.push_eef_radius = 0.03
+    c.push_rest_z = 0.01
+    c.push_place_min = 0.22
+    c.push_place_max = 0.25
+    return c
+
+
+# ------------------------------------------------------------------ thin numpy wrappers
+
+def fk(chain, q):
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, NJ)
+    n = q.shape[0]
+    pos = np.empty((n, 3)); quat = np.empty((n, 4))
+    lib().orc_fk_batch(C.byref(chain), C.c_int64(n), _p(q), _p(pos), _p(quat))
+    return pos, quat
+
+
+def fk_full(chain, q):
+    """Single-env FK returning (p, R, zs, ps)."""
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    p = np.empty(3); R = np.empty(9); zs = np.empty(21); ps = np.empty(21)
+    lib().orc_fk(C.byref(chain), _p(q), _p(p), _p(R), _p(zs), _p(ps))
+    return p, R.reshape(3, 3), zs.reshape(7, 3), ps.reshape(7, 3)
+
+
+def jacobian(chain, q):
+    p, _, zs, ps = fk_full(chain, q)
+    J = np.empty((6, 7))
+    lib().orc_jacobian(_p(np.ascontiguousarray(zs)), _p(np.ascontiguousarray(ps)), _p(p), _p(J))
+    return J
+
+
+def dls_delta(J, e, lam, max_dtheta, form):
+    J = np.ascontiguousarray(J, dtype=np.float64); e = np.ascontiguousarray(e, dtype=np.float64)
+    out = np.empty(7)
+    rc = lib().orc_dls_delta(_p(J), _p(e), C.c_double(lam), C.c_double(max_dtheta), C.c_int(form), _p(out))
+    assert rc == 0
+    return out
+
+
+def orientation_error(qt, qc, angle_f32=1):
+    e = np.empty(3)
+    lib().orc_orientation_error(_p(np.ascontiguousarray(qt, dtype=np.float64)),
+                                _p(np.ascontiguousarray(qc, dtype=np.float64)), C.c_int(angle_f32), _p(e))
+    return e
+
+
+def ik(chain, cfg, q, tgt):
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, NJ)
+    tgt = np.ascontiguousarray(tgt, dtype=np.float64).reshape(-1, 3)
+    n = q.shape[0]
+    out = np.empty_like(q); iters = np.empty(n, dtype=np.int32)
+    lib().orc_ik_batch(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(q), _p(tgt), _p(out), _p(iters))
+    return out, iters
+
+
+def philox(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    return list(out)
+
+
+def draw6(seed, env_id, episode, draw):
+    u = (C.c_double * 6)()
+    lib().orc_draw6(C.c_uint64(seed), C.c_uint64(env_id), C.c_uint32(episode), C.c_uint32(draw), u)
+    return list(u)
+
+
+class ReachState:
+    """Host mirror of the engine's per-env state (AoS, the get_state/set_state exchange layout)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.q = np.zeros((n, NJ)); self.goal = np.zeros((n, 3), dtype=np.float32)
+        self.step = np.zeros(n, dtype=np.int32); self.episode = np.zeros(n, dtype=np.uint32)
+        self.ep_return = np.zeros(n)
+        self.last_return = np.zeros(n); self.last_len = np.zeros(n, dtype=np.int32)
+        self.last_success = np.zeros(n, dtype=np.uint8)
+
+    def copy(self):
+        o = ReachState(self.n)
+        for k, v in self.__dict__.items():
+            if isinstance(v, np.ndarray):
+                setattr(o, k, v.copy())
+        return o
+
+
+def reach_reset(chain, cfg, st, seed=0, env_id0=0, mask=None):
+    obs = np.zeros((st.n, 6), dtype=np.float32)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_reach_reset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(st.n),
+                          _p(m), _p(st.q), _p(st.goal), _p(st.step), _p(st.episode), _p(obs))
+    if mask is None:
+        st.ep_return[:] = 0
+    else:
+        st.ep_return[np.asarray(mask, dtype=bool)] = 0
+    return obs
+
+
+def reach_reset_with_goal(chain, cfg, st, goal):
+    obs = np.zeros((st.n, 6), dtype=np.float32)
+    g = np.ascontiguousarray(goal, dtype=np.float32).reshape(st.n, 3)
+    lib().orc_reach_reset_with_goal(C.byref(chain), C.byref(cfg), C.c_int64(st.n), _p(g), _p(st.q), _p(st.goal),
+                                    _p(st.step), _p(obs))
+    st.ep_return[:] = 0
+    return obs
+
+
+def reach_step(chain, cfg, st, action):
+    """One step, no auto-reset.  Returns obs f32[N,6], reward f64[N], done, success, ik updates."""
+    n = st.n
+    a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
+    obs = np.zeros((n, 6), dtype=np.float32); rew = np.zeros(n)
+    done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); iters = np.zeros(n, dtype=np.int32)
+    lib().orc_reach_step(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(st.q), _p(st.goal), _p(st.step), _p(a),
+                         _p(obs), _p(rew), _p(done), _p(succ), _p(iters))
+    st.ep_return += rew
+    return obs, rew, done, succ, iters
+
+
+def reach_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, want_terminal=True):
+    n = st.n
+    a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
+    obs = np.zeros((n, 6), dtype=np.float32); rew = np.zeros(n)
+    done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8)
+    term = np.zeros((n, 6), dtype=np.float32) if want_terminal else None
+    lib().orc_reach_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
+                                   _p(st.q), _p(st.goal), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a),
+                                   _p(obs), _p(rew), _p(done), _p(succ), _p(term),
+                                   _p(st.last_return), _p(st.last_len), _p(st.last_success))
+    return obs, rew, done, succ, term
+
+
+def actor_forward(sd, states, action_bound):
+    """sd: dict fc1.weight ... fc3.bias as float32 numpy (torch Linear layout)."""
+    s = np.ascontiguousarray(states, dtype=np.float32)
+    n, in_dim = s.shape
+    W1, b1, W2, b2, W3, b3 = (np.ascontiguousarray(sd[k], dtype=np.float32) for k in
+                              ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias"))
+    hid, out_dim = W1.shape[0], W3.shape[0]
+    a = np.zeros((n, out_dim), dtype=np.float32)
+    lib().orc_actor_forward(C.c_int64(n), C.c_int(in_dim), C.c_int(hid), C.c_int(out_dim), _p(W1), _p(b1), _p(W2),
+                            _p(b2), _p(W3), _p(b3), C.c_float(action_bound), _p(s), _p(a))
+    return a
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def reach_outcome(cfg, dist, step_counter):
+    r = C.c_double(); d = C.c_uint8(); s = C.c_uint8()
+    lib().orc_reach_outcome(C.byref(cfg), C.c_double(dist), C.c_int32(step_counter), C.byref(r), C.byref(d), C.byref(s))
+    return r.value, bool(d.value), bool(s.value)

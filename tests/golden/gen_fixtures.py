@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the reference checkout.
+
+Runs ONLY in the build container (needs /root/reference); the fixtures it writes are committed and
+travel to the GPU box, this script's inputs do not.  Fixtures are data: numbers the reference holds
+(known answers, captured getJointInfo tuples) and input/output vectors produced by importing the
+reference's importable Python (config, algo.TD3) -- never reference source text.
+
+  G1 fk_kat.json               q = init_joint_positions (envs/rl_reach_env.py:116-119),
+                               p = initial_a (main.py:106) = f32(getLinkState(kuka,6)[4])
+  G2 joint_info.json           numeric fields of envs/bmirobot_joints_info_pybullet.txt:1-16
+  G3 td3_actor_seed0.npz       TD3_MLP(6,3,0.7) actor weights + 1024 states -> actions
+                               (algo/TD3/TD3_mlp.py:33-97, algo/TD3/net_mlp.py:29-40)
+  G4 py_random_targets_seed0.json   Python `random` stream in the reference's draw pattern
+                               (7 draws per reset envs/rl_reach_env.py:180-183,210-212; 3 per step :316-318)
+  G5 reward_truth.json         (distance, step_counter) -> (reward, done, success) of
+                               envs/rl_reach_env.py:299-309 (strict '>' and '<')
+"""
+import ast
+import json
+import os
+import random
+import re
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def g1_fk_kat():
+    src = open(os.path.join(REF, "envs/rl_reach_env.py")).read()
+    m = re.search(r"self\.init_joint_positions\s*=\s*\[(.*?)\]", src, re.S)
+    q = [float(x) for x in m.group(1).replace("\n", " ").split(",")]
+    msrc = open(os.path.join(REF, "main.py")).read()
+    m = re.search(r"initial_a\s*=\s*\[(.*?)\]", msrc)
+    p = [float(x) for x in m.group(1).split(",")]
+    assert len(q) == 7 and len(p) == 3
+    json.dump({"robot": "kuka", "q": q, "p_f32": p,
+               "source": "envs/rl_reach_env.py:116-119, main.py:106"},
+              open(os.path.join(OUT, "fk_kat.json"), "w"), indent=1)
+
+
+def g2_joint_info():
+    rows = {"kuka": [], "diana": []}
+    cur = "kuka"
+    for ln in open(os.path.join(REF, "envs/bmirobot_joints_info_pybullet.txt")):
+        ln = ln.strip()
+        if not ln:
+            cur = "diana"
+            continue
+        t = ast.literal_eval(ln)
+        rows[cur].append({
+            "index": t[0], "name": t[1].decode(), "type": t[2], "damping": t[6], "friction": t[7],
+            "lower": t[8], "upper": t[9], "max_force": t[10], "max_velocity": t[11],
+            "link": t[12].decode(), "axis": list(t[13]), "parent_frame_pos": list(t[14]),
+            "parent_frame_orn": list(t[15]), "parent_index": t[16]})
+    assert len(rows["kuka"]) == 7 and len(rows["diana"]) == 8
+    rows["source"] = "envs/bmirobot_joints_info_pybullet.txt:1-16 (p.getJointInfo tuples)"
+    json.dump(rows, open(os.path.join(OUT, "joint_info.json"), "w"), indent=1)
+
+
+def g3_td3_actor():
+    sys.path.insert(0, REF)
+    import torch
+    from algo.TD3.TD3_mlp import TD3_MLP  # the reference's own agent
+    torch.manual_seed(0)
+    agent = TD3_MLP(6, 3, 0.7, device=torch.device("cpu"))
+    sd = {k: v.detach().numpy().copy() for k, v in agent.actor.state_dict().items()}
+    rng = np.random.default_rng(0)
+    lo = np.array([0.2, -0.3, 0.0, 0.2, -0.3, 0.0]); hi = np.array([0.7, 0.3, 0.55, 0.7, 0.3, 0.55])
+    states = (lo + (hi - lo) * rng.random((1024, 6))).astype(np.float32)
+    states[0] = [0.53205401, -0.00112139, 0.49629840, 0.45, 0.1, 0.3]
+    with torch.no_grad():
+        actions = agent.actor(torch.from_numpy(states)).numpy()
+    # take_action path for row 0 (algo/TD3/TD3_mlp.py:82-97)
+    a0 = agent.take_action(states[0])
+    assert np.allclose(a0, actions[0], atol=1e-7)
+    np.savez(os.path.join(OUT, "td3_actor_seed0.npz"), states=states, actions=actions,
+             action_bound=np.float32(0.7), **{k.replace(".", "_"): v for k, v in sd.items()})
+
+
+def g4_py_random():
+    lo = [0.2, -0.3, 0.0]; hi = [0.7, 0.3, 0.55]
+    random.seed(0)
+    episodes = []
+    for ep in range(4):
+        goal = [random.uniform(lo[k], hi[k]) for k in range(3)]   # rl_reach_env.py:180-182
+        ang = random.random()                                       # :183
+        unused = [random.uniform(lo[k], hi[k]) for k in range(3)]  # :210-212
+        steps = []
+        for _ in range(5):
+            steps.append([random.uniform(lo[k], hi[k]) for k in range(3)])  # :316-318
+        episodes.append({"goal": goal, "ang_draw": ang, "unused_reset": unused, "unused_step": steps})
+    json.dump({"seed": 0, "steps_per_episode": 5, "episodes": episodes,
+               "source": "CPython random.seed(0) stream in the draw pattern of envs/rl_reach_env.py"},
+              open(os.path.join(OUT, "py_random_targets_seed0.json"), "w"), indent=1)
+
+
+def g5_reward_truth():
+    max_steps, reach_dis = 500, 0.01   # config.py:51, :42
+    rows = []
+    for step in (1, 250, 499, 500, 501, 502):
+        for d in (0.0, 0.005, 0.0099, 0.01, 0.0101, 0.05, 0.3):
+            # envs/rl_reach_env.py:299-309
+            if step > max_steps:
+                r, done, succ = -d * 10, True, False
+            elif d < reach_dis:
+                r, done, succ = 0.0, True, True
+            else:
+                r, done, succ = -d * 10, False, False
+            rows.append({"step_counter": step, "distance": d, "reward": r, "done": done, "success": succ})
+    json.dump({"max_steps": max_steps, "reach_dis": reach_dis, "rows": rows,
+               "source": "envs/rl_reach_env.py:299-309"},
+              open(os.path.join(OUT, "reward_truth.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth()
+    print("fixtures written to", OUT)

@@ -1,0 +1,447 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs; against the committed golden fixtures; and -- at BASELINE.json's full size -- through
+size-independent properties.
+
+Tolerances (north_star: joint positions and reward within 1e-4 of the reference):
+  f64 engine vs f64 oracle   FK 1e-12 m; one IK call / one env step 1e-6 rad (the orientation error's
+                             2*acos(w) has ~3e-8 rad of conditioning noise at convergence, in Bullet too),
+                             reward 1e-6, obs 1 f32 ulp
+  f32 engine vs f64 oracle   one env step 1e-4 rad / 1e-4 reward (the stated tolerance)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_json, golden_npz
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def envs():
+    from armenv import envs
+    return envs
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _actions(rng, n):
+    """the run() exploration distribution with a zero actor, main.py:116-117"""
+    return np.clip(rng.normal(0.0, 0.7 * 0.98, (n, 3)), -0.7, 0.7).astype(np.float32)
+
+
+def _mk(envs, n, **kw):
+    return envs.BatchedReachEnv(n, device=DEV, **kw)
+
+
+# ------------------------------------------------------------------------------ FK (R5)
+
+def test_library_is_the_hip_build(envs):
+    e = _mk(envs, 64)
+    assert e.kernel_name == "reach_step<f64,kuka>"
+    e.close()
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_fk_known_answer_on_gpu(envs, precision):
+    g = golden_json("fk_kat.json")
+    e = _mk(envs, 1, precision=precision)
+    pos, quat = e.fk(torch.tensor([g["q"]], dtype=torch.float64))
+    assert np.abs(_np(pos)[0] - np.array(g["p_f32"])).max() < (1e-7 if precision == 64 else 5e-7)
+    obs = _np(e.reset())
+    assert np.abs(obs[0, :3] - np.float32(g["p_f32"])).max() <= (6e-8 if precision == 64 else 5e-7)
+    e.close()
+
+
+@pytest.mark.parametrize("robot", ["kuka", "diana"])
+@pytest.mark.parametrize("fk_path", [0, 1])
+@pytest.mark.parametrize("precision", [64, 32])
+def test_fk_matches_oracle(envs, O, robot, fk_path, precision):
+    rng = np.random.default_rng(10)
+    q = rng.uniform(-3.0, 3.0, (4096 + 37, 7))       # ragged size: not a multiple of the block
+    e = _mk(envs, 8, robot=robot, fk_path=fk_path, precision=precision)
+    assert ("generic" in e.kernel_name) == (fk_path == 1)
+    pos, quat = e.fk(torch.from_numpy(q))
+    p_ref, q_ref = O.fk(O.make_chain(robot), q)
+    tol = 1e-12 if precision == 64 else 5e-6
+    assert np.abs(_np(pos) - p_ref).max() < tol
+    dq = np.minimum(np.abs(_np(quat) - q_ref).max(1), np.abs(_np(quat) + q_ref).max(1))
+    # getRotation switches branch on the trace / largest diagonal; both give the same rotation
+    assert np.median(dq) < (1e-12 if precision == 64 else 1e-5)
+    assert dq.max() < (1e-6 if precision == 64 else 2e-2)
+    e.close()
+
+
+def test_fk_generic_chain_with_base_transform(envs, O):
+    """Diana S1 as diana_cam_reach.py loads it: base yawed by pi (envs/diana_cam_reach.py:202-203)."""
+    from armenv.urdf import builtin_chain
+    ch = builtin_chain("diana").with_base(xyz=(0.1, -0.2, 0.3), rpy=(0.0, 0.0, math.pi))
+    e = _mk(envs, 8, chain=ch)
+    assert "generic" in e.kernel_name
+    rng = np.random.default_rng(11)
+    q = rng.uniform(-3, 3, (513, 7))
+    pos, _ = e.fk(torch.from_numpy(q))
+    p_ref, _ = O.fk(O.make_chain("diana", base_xyz=(0.1, -0.2, 0.3), base_rpy=(0, 0, math.pi)), q)
+    assert np.abs(_np(pos) - p_ref).max() < 1e-12
+    e.close()
+
+
+def test_fk_empty_batch(envs):
+    e = _mk(envs, 4)
+    pos, quat = e.fk(torch.empty((0, 7), dtype=torch.float64))
+    assert pos.shape == (0, 3)
+    e.close()
+
+
+# ------------------------------------------------------------------------------ IK (R6)
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("robot,fk_path", [("kuka", 0), ("kuka", 1), ("diana", 0)])
+def test_ik_matches_oracle_f64(envs, O, robot, fk_path, mode):
+    rng = np.random.default_rng(20)
+    n = 2048 + 5
+    ch = O.make_chain(robot)
+    cfg = O.default_config(); cfg.ik_exit_mode = mode
+    if robot == "diana":
+        cfg.target_quat[:] = [0.0, 0.0, 0.0, 1.0]
+    # start poses near the workspace: init pose plus noise; targets 0..3 cm away like an env step
+    q0 = np.array(O.INIT_Q) + rng.normal(0, 0.3, (n, 7))
+    p0, _ = O.fk(ch, q0)
+    tgt = p0 + rng.normal(0, 0.012, (n, 3))
+    e = _mk(envs, 8, robot=robot, fk_path=fk_path, ik_exit_mode=mode, target_quat=list(cfg.target_quat))
+    q_gpu, it_gpu = e.ik(torch.from_numpy(q0), torch.from_numpy(tgt))
+    q_ref, it_ref = O.ik(ch, cfg, q0, tgt)
+    same = _np(it_gpu) == it_ref
+    assert same.mean() > 0.999                       # a residual within ~1e-15 of 1e-4 may flip one trip
+    assert np.abs(_np(q_gpu) - q_ref)[same].max() < 1e-6
+    assert it_ref.max() <= 20 and it_ref.min() >= (1 if mode == 0 else 0)
+    e.close()
+
+
+def test_ik_iteration_cap_and_far_targets(envs, O):
+    """Unreachable targets run into the 20-iteration cap with 45-degree-clamped updates."""
+    rng = np.random.default_rng(21)
+    n = 256
+    q0 = np.tile(O.INIT_Q, (n, 1))
+    tgt = rng.uniform(-2.0, 2.0, (n, 3))
+    e = _mk(envs, 8)
+    q_gpu, it_gpu = e.ik(torch.from_numpy(q0), torch.from_numpy(tgt))
+    q_ref, it_ref = O.ik(O.make_chain("kuka"), O.default_config(), q0, tgt)
+    assert it_ref.max() == 20 and np.array_equal(_np(it_gpu), it_ref)
+    # long clamped trajectories amplify rounding; compare the well-conditioned majority tightly
+    err = np.abs(_np(q_gpu) - q_ref).max(1)
+    assert np.median(err) < 1e-8 and np.isfinite(_np(q_gpu)).all()
+    e.close()
+
+
+def test_ik_f32_within_stated_tolerance(envs, O):
+    rng = np.random.default_rng(22)
+    n = 4096
+    ch = O.make_chain("kuka"); cfg = O.default_config()
+    st = O.ReachState(n); O.reach_reset(ch, cfg, st, seed=5)
+    for _ in range(3):                                # leave the post-reset yaw transient
+        O.reach_step(ch, cfg, st, _actions(rng, n))
+    p0, _ = O.fk(ch, st.q)
+    tgt = np.clip(p0 + 0.02 * _actions(rng, n), cfg.box_lo[:], cfg.box_hi[:])
+    e = _mk(envs, 8, precision=32)
+    q_gpu, it_gpu = e.ik(torch.from_numpy(st.q), torch.from_numpy(tgt))
+    q_ref, it_ref = O.ik(ch, cfg, st.q, tgt)
+    same = _np(it_gpu) == it_ref
+    assert same.mean() > 0.98
+    assert np.abs(_np(q_gpu) - q_ref)[same].max() < 1e-4
+    p1, _ = O.fk(ch, _np(q_gpu))
+    assert np.linalg.norm(p1 - tgt, axis=1).max() < 2e-4
+    e.close()
+
+
+# ------------------------------------------------------------------------------ reset (R2)
+
+def test_reset_matches_oracle_and_golden(envs, O, kuka):
+    n = 4096 + 3
+    cfg = O.default_config()
+    e = _mk(envs, n, seed=99, env_id_offset=1234)
+    obs = _np(e.reset())
+    st = O.ReachState(n)
+    obs_ref = O.reach_reset(kuka, cfg, st, seed=99, env_id0=1234)
+    assert np.array_equal(obs[:, 3:], obs_ref[:, 3:])                      # goals: bit-exact (Philox + f64 affine)
+    assert np.abs(obs[:, :3] - obs_ref[:, :3]).max() <= 6e-8
+    s = e.get_state()
+    assert np.array_equal(_np(s["q"]), st.q) and np.array_equal(_np(s["goal"]), st.goal)
+    assert (_np(s["step"]) == 0).all() and (_np(s["episode"]) == 1).all()
+    # masked reset touches only the masked envs
+    mask = torch.zeros(n, dtype=torch.uint8); mask[::3] = 1
+    e.reset(mask=mask)
+    s2 = e.get_state()
+    ep = _np(s2["episode"])
+    assert (ep[::3] == 2).all() and (np.delete(ep, np.arange(0, n, 3)) == 1).all()
+    m = _np(mask).astype(bool)
+    O.reach_reset(kuka, cfg, st, seed=99, env_id0=1234, mask=_np(mask))
+    assert np.array_equal(_np(s2["goal"]), st.goal)
+    assert np.array_equal(_np(s2["goal"])[~m], _np(s["goal"])[~m])
+    e.close()
+
+
+def test_reset_with_goal_and_state_roundtrip(envs):
+    n = 130
+    e = _mk(envs, n)
+    goal = torch.rand(n, 3)
+    obs = _np(e.reset(goal=goal))
+    assert np.array_equal(obs[:, 3:], goal.numpy())
+    rng = np.random.default_rng(0)
+    q = rng.uniform(-1, 1, (n, 7)); step = rng.integers(0, 500, n).astype(np.int32)
+    ret = rng.normal(size=n); epi = rng.integers(0, 1000, n).astype(np.int32)
+    e.set_state(q=q, step=step, ep_return=ret, episode=epi)
+    s = e.get_state()
+    assert np.array_equal(_np(s["q"]), q) and np.array_equal(_np(s["step"]), step)
+    assert np.array_equal(_np(s["ep_return"]), ret) and np.array_equal(_np(s["episode"]), epi)
+    assert np.array_equal(_np(s["goal"]), goal.numpy())
+    e.close()
+
+
+# ------------------------------------------------------------------------------ step (R3, R4)
+
+@pytest.mark.parametrize("robot,fk_path,mode", [("kuka", 0, 0), ("kuka", 0, 1), ("kuka", 1, 0), ("diana", 0, 0)])
+def test_step_teacher_forced_f64(envs, O, robot, fk_path, mode):
+    """Every step starts from the oracle's state (set_state), so the comparison is per step."""
+    n = 1024 + 9
+    rng = np.random.default_rng(30)
+    ch = O.make_chain(robot)
+    cfg = O.default_config(); cfg.ik_exit_mode = mode
+    over = {}
+    if robot == "diana":      # a reachable set-up for the second chain (diana_cam_reach.py:102-104,156-157)
+        cfg.target_quat[:] = [1.0, 0.0, 0.0, 0.0]
+        cfg.q_init[:] = [0.0, 0.5, 0.0, 1.6, 0.0, -1.0, 0.0]
+        p_init, _ = O.fk(ch, cfg.q_init[:])
+        lo = (p_init[0] - 0.25).tolist(); hi = (p_init[0] + 0.25).tolist()
+        cfg.box_lo[:] = lo; cfg.box_hi[:] = hi; cfg.goal_lo[:] = lo; cfg.goal_hi[:] = hi
+        over = dict(target_quat=list(cfg.target_quat), q_init=list(cfg.q_init), box_lo=lo, box_hi=hi, goal_lo=lo, goal_hi=hi)
+    e = _mk(envs, n, robot=robot, fk_path=fk_path, auto_reset=False, seed=3, ik_exit_mode=mode, **over)
+    st = O.ReachState(n)
+    O.reach_reset(ch, cfg, st, seed=3)
+    e.reset()
+    worst_q = worst_r = 0.0
+    flips = 0
+    for t in range(25):
+        a = _actions(rng, n)
+        e.set_state(q=st.q, goal=st.goal, step=st.step, ep_return=st.ep_return)
+        obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV))
+        obs, rew, done, succ = _np(obs).copy(), _np(rew).copy(), _np(done).copy(), _np(succ).copy()
+        obs_r, rew_r, done_r, succ_r, iters = O.reach_step(ch, cfg, st, a)
+        s = e.get_state()
+        dq = np.abs(_np(s["q"]) - st.q).max(1)
+        ok = dq < 1e-6
+        flips += int((~ok).sum())
+        worst_q = max(worst_q, dq[ok].max())
+        worst_r = max(worst_r, np.abs(rew.astype(np.float64) - rew_r)[ok].max())
+        assert np.abs(obs - obs_r)[ok].max() <= 1.2e-7
+        assert np.array_equal(done[ok], done_r[ok].astype(bool)) and np.array_equal(succ[ok], succ_r[ok].astype(bool))
+        assert np.array_equal(_np(s["step"]), st.step)
+        assert np.abs(_np(s["ep_return"]) - st.ep_return)[ok].max() < 1e-5
+    assert flips <= 1, flips                   # an IK residual within rounding of 1e-4 may flip one trip
+    assert worst_q < 1e-6 and worst_r < 1e-5
+
+
+def test_step_teacher_forced_f32(envs, O, kuka):
+    n = 4096
+    rng = np.random.default_rng(31)
+    cfg = O.default_config()
+    e = _mk(envs, n, precision=32, auto_reset=False, seed=4)
+    st = O.ReachState(n)
+    O.reach_reset(kuka, cfg, st, seed=4)
+    e.reset()
+    bad = 0
+    for t in range(20):
+        a = _actions(rng, n)
+        e.set_state(q=st.q, goal=st.goal, step=st.step, ep_return=st.ep_return)
+        obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV))
+        obs, rew = _np(obs).copy(), _np(rew).copy()
+        obs_r, rew_r, done_r, succ_r, iters = O.reach_step(kuka, cfg, st, a)
+        dq = np.abs(_np(e.get_state()["q"]) - st.q).max(1)
+        bad += int((dq >= 1e-4).sum())
+        ok = dq < 1e-4
+        assert np.abs(rew.astype(np.float64) - rew_r)[ok].max() < 1e-4
+        assert np.abs(obs - obs_r)[ok].max() < 1e-4
+    assert bad <= 0.002 * 20 * n, bad         # trip-count flips at the 1e-4 residual gate
+
+
+def test_reward_done_success_thresholds(envs, O, kuka):
+    """Drive the branch of rl_reach_env.py:299-309 through the kernel: goals placed just inside / outside
+    reach_dis of where the arm ends up, and step counters around max_steps (strict > and <)."""
+    cfg = O.default_config()
+    n = 6
+    e = _mk(envs, n, auto_reset=False)
+    e.reset()
+    st = O.ReachState(n)
+    O.reach_reset(kuka, cfg, st)
+    a = np.zeros((n, 3), dtype=np.float32)
+    # where does a zero action end? (IK still corrects the 90 degree tool yaw)
+    probe = st.copy()
+    obs_p, *_ = O.reach_step(kuka, cfg, probe, a)
+    end = obs_p[0, :3].astype(np.float64)
+    offs = np.array([0.0099, 0.0101, 0.0099, 0.0101, 0.3, 0.0])
+    goal = np.tile(end, (n, 1)); goal[:, 0] += offs
+    step = np.array([10, 10, 500, 500, 499, 500], dtype=np.int32)      # counter before the step
+    st.goal[:] = goal.astype(np.float32); st.step[:] = step
+    e.set_state(q=st.q, goal=st.goal, step=st.step)
+    obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV))
+    obs_r, rew_r, done_r, succ_r, _ = O.reach_step(kuka, cfg, st, a)
+    assert np.array_equal(_np(done), done_r.astype(bool)) and np.array_equal(_np(succ), succ_r.astype(bool))
+    assert list(done_r) == [1, 0, 1, 1, 0, 1] and list(succ_r) == [1, 0, 0, 0, 0, 0]
+    assert _np(rew)[0] == 0.0 and abs(_np(rew)[2] + 0.099) < 2e-3 and abs(_np(rew)[5]) < 1e-3
+    assert np.abs(_np(rew) - rew_r).max() < 1e-6
+    e.close()
+
+
+def test_trajectory_with_autoreset_f64(envs, O, kuka):
+    """Free-running rollout (no teacher forcing): 560 steps x 96 envs with in-kernel auto-reset, crossing
+    the 501-step time-out and any successes.  In f64 the HIP path tracks the oracle over whole episodes."""
+    n, T = 96, 560
+    rng = np.random.default_rng(40)
+    cfg = O.default_config()
+    e = _mk(envs, n, seed=11, env_id_offset=77)
+    st = O.ReachState(n)
+    obs0 = _np(e.reset()).copy()
+    obs0_r = O.reach_reset(kuka, cfg, st, seed=11, env_id0=77)
+    assert np.abs(obs0 - obs0_r).max() <= 6e-8
+    # put a few goals next to the start pose so that successes happen
+    g = _np(e.get_state()["goal"]).copy()
+    g[:8] = obs0[:8, :3] + np.float32([0.03, 0.0, 0.0])
+    st.goal[:] = g; e.set_state(goal=g)
+    n_done = n_succ = 0
+    for t in range(T):
+        a = _actions(rng, n)
+        if t < 40:
+            a[:8] = np.float32([0.7, 0.0, 0.0])       # walk the first 8 envs toward their goal
+        obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV), want_terminal_obs=True)
+        obs, rew, done, succ, term = _np(obs).copy(), _np(rew).copy(), _np(done).copy(), _np(succ).copy(), _np(e.terminal_obs).copy()
+        obs_r, rew_r, done_r, succ_r, term_r = O.reach_step_autoreset(kuka, cfg, st, a, seed=11, env_id0=77)
+        assert np.array_equal(done, done_r.astype(bool)), t
+        assert np.array_equal(succ, succ_r.astype(bool)), t
+        assert np.abs(rew - rew_r).max() < 1e-4, t
+        assert np.abs(obs - obs_r).max() < 1e-4 and np.abs(term - term_r).max() < 1e-4, t
+        assert np.array_equal(obs[:, 3:], obs_r[:, 3:])              # goals (incl. re-sampled ones) bit-exact
+        n_done += int(done.sum()); n_succ += int(succ.sum())
+    assert n_succ >= 8 and n_done >= n                                # successes and 501-step time-outs both happened
+    s = e.get_state()
+    assert np.abs(_np(s["q"]) - st.q).max() < 1e-4
+    assert np.array_equal(_np(s["step"]), st.step) and np.array_equal(_np(s["episode"]).astype(np.uint32), st.episode)
+    ret, ln, su = e.episode_stats()
+    assert np.abs(_np(ret) - st.last_return).max() < 1e-3 and np.array_equal(_np(ln), st.last_len)
+    assert np.array_equal(_np(su), st.last_success)
+    c = e.counters()
+    assert c["episodes"] == n_done and c["successes"] == n_succ and c["env_steps"] == n * T and c["nonfinite"] == 0
+    e.close()
+
+
+def test_step_argument_errors(envs):
+    from armenv import ArmEnvError
+    e = _mk(envs, 8)
+    e.reset()
+    with pytest.raises(ValueError):
+        e.step(torch.zeros(8, 3))                                     # CPU tensor
+    with pytest.raises(ValueError):
+        e.step(torch.zeros(7, 3, device=DEV))
+    with pytest.raises(ArmEnvError):
+        envs.BatchedReachEnv(0, device=DEV)
+    with pytest.raises(ArmEnvError):
+        envs.BatchedReachEnv(8, device=DEV, precision=16)
+    with pytest.raises(ArmEnvError):
+        envs.BatchedReachEnv(8, device="cuda:63")
+    e.close()
+
+
+# ------------------------------------------------------------------------------ full size: properties
+
+def test_full_size_properties_65536(envs, O, kuka):
+    """BASELINE.json config 2 size.  The oracle checks a strided sample; everything else is a
+    size-independent property: determinism, shard invariance, box containment, IK residual, counters."""
+    n = 65536
+    rng = np.random.default_rng(50)
+    acts = [torch.from_numpy(_actions(rng, n)).to(DEV) for _ in range(12)]
+    cfg = O.default_config()
+
+    def run(env, lo=0, hi=n, keep=False):
+        out = []
+        env.reset()
+        for a in acts:
+            o, r, d, s = env.step(a[lo:hi].contiguous())
+            out.append((o.clone(), r.clone(), d.clone(), s.clone()))
+        return out
+
+    e = _mk(envs, n, seed=5)
+    ref = run(e)
+    st_full = e.get_state()
+    # determinism: a second handle with the same seed reproduces every byte
+    e2 = _mk(envs, n, seed=5)
+    again = run(e2)
+    for (o1, r1, d1, s1), (o2, r2, d2, s2) in zip(ref, again):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(s1, s2)
+    e2.close()
+    # shard invariance: two half-size handles with env_id_offset reproduce the big one (multi-GPU sharding)
+    h0 = _mk(envs, n // 2, seed=5, env_id_offset=0)
+    h1 = _mk(envs, n // 2, seed=5, env_id_offset=n // 2)
+    r0, r1 = run(h0, 0, n // 2), run(h1, n // 2, n)
+    for (o, r, d, s), (oa, ra, da, sa), (ob, rb, db, sb) in zip(ref, r0, r1):
+        assert torch.equal(o, torch.cat([oa, ob])) and torch.equal(r, torch.cat([ra, rb]))
+        assert torch.equal(d, torch.cat([da, db]))
+    h0.close(); h1.close()
+    # containment and reward identity
+    lo = torch.tensor([0.2, -0.3, 0.0], device=DEV) - 2e-4
+    hi = torch.tensor([0.7, 0.3, 0.55], device=DEV) + 2e-4
+    for o, r, d, s in ref:
+        assert bool(((o[:, :3] >= lo) & (o[:, :3] <= hi)).all())
+        assert bool(((o[:, 3:] >= lo + 2e-4) & (o[:, 3:] <= hi - 2e-4)).all())
+        dist = (o[:, :3].double() - o[:, 3:].double()).norm(dim=1)
+        live = ~d
+        assert float((r[live].double() + 10.0 * dist[live]).abs().max()) < 1e-5
+        assert bool((s <= d).all())
+    # oracle on a strided sample of the final state
+    idx = np.arange(0, n, 257)
+    st = O.ReachState(len(idx))
+    full = O.ReachState(n)
+    O.reach_reset(kuka, cfg, full, seed=5)
+    st.q[:] = full.q[idx]; st.goal[:] = full.goal[idx]; st.episode[:] = 1
+    for a in acts:
+        O.reach_step(kuka, cfg, st, _np(a)[idx])
+    assert np.abs(_np(st_full["q"])[idx] - st.q).max() < 1e-5
+    c = e.counters()
+    assert c["env_steps"] == n * len(acts) and c["nonfinite"] == 0
+    e.close()
+
+
+# ------------------------------------------------------------------------------ N=1 compat class (boundary)
+
+def test_rlreachenv_compat_surface(envs, O, kuka):
+    """The reference's own call pattern, main.py:83-128, on the drop-in class; goals follow Python's
+    `random` stream (golden G4), numbers follow the oracle."""
+    import random
+    g = golden_json("py_random_targets_seed0.json")
+    env = envs.RLReachEnv(is_render=False, is_good_view=False)
+    state_dim = env.observation_space.shape[0]
+    action_dim = env.action_space.shape[0]
+    action_bound = float(env.action_space.high[0]) + 0.3
+    assert (state_dim, action_dim) == (6, 3) and abs(action_bound - 0.7) < 1e-7
+    random.seed(0); np.random.seed(0)
+    cfg = O.default_config()
+    for ep in g["episodes"][:2]:
+        state = env.reset()
+        assert isinstance(state, np.ndarray) and state.dtype == np.float32 and state.shape == (6,)
+        assert np.array_equal(state[3:], np.float32(ep["goal"]))
+        st = O.ReachState(1)
+        O.reach_reset_with_goal(kuka, cfg, st, np.float32([ep["goal"]]))
+        for k in range(g["steps_per_episode"]):
+            action = (np.zeros(3) + np.random.normal(0, action_bound * 0.98, size=action_dim)).clip(-action_bound, action_bound)
+            state, reward, done, is_success = env.step(action)
+            obs_r, rew_r, done_r, succ_r, _ = O.reach_step(kuka, cfg, st, action.astype(np.float32)[None])
+            assert isinstance(reward, float) and isinstance(done, bool) and isinstance(is_success, bool)
+            assert state.dtype == np.float32 and np.abs(state - obs_r[0]).max() < 1e-6
+            assert abs(reward - rew_r[0]) < 1e-5 and done == bool(done_r[0]) and is_success == bool(succ_r[0])
+            assert np.array_equal(state[-3:], np.float32(ep["goal"]))
+    assert env.seed(3) == [3]
+    env.close()

@@ -1,0 +1,210 @@
+"""CPU tests: the oracle against every known answer the reference holds for the env hot path
+ and against its own invariants."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import golden_json, golden_npz
+
+
+def test_fk_known_answer_main_py_106(O, kuka):
+    g = golden_json("fk_kat.json")
+    p, _ = O.fk(kuka, g["q"])
+    # main.py:106 holds the float32-rounded getLinkState(kuka,6)[4]
+    assert np.abs(p[0] - np.array(g["p_f32"])).max() < 1e-7
+    assert np.abs(p[0].astype(np.float32) - np.float32(g["p_f32"])).max() <= 6.0e-8   # <= 1 f32 ulp
+
+
+def _quat_inv_from_rpy(O, rpy):
+    R = np.empty(9)
+    import ctypes as C
+    O.lib().orc_rpy_to_mat((C.c_double * 3)(*rpy), R.ctypes.data_as(C.c_void_p))
+    q = np.empty(4)
+    O.lib().orc_quat_from_mat(np.ascontiguousarray(R.reshape(3, 3).T).ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p))
+    return q
+
+
+@pytest.mark.parametrize("robot,first", [("kuka", 0), ("diana", 1)])
+def test_joint_frames_match_getjointinfo_dump(O, robot, first):
+    """parentFramePos = joint origin - parent link inertial origin; parentFrameOrn = inverse of the
+    origin rotation; limits -- envs/bmirobot_joints_info_pybullet.txt:1-16."""
+    rows = golden_json("joint_info.json")[robot][first:]
+    tab = O.ROBOTS[robot]
+    assert len(rows) == 7
+    for i, row in enumerate(rows):
+        want = np.array(tab["xyz"][i]) - np.array(tab["inertial"][i])
+        assert np.abs(want - np.array(row["parent_frame_pos"])).max() < 1e-9, (i, want, row["parent_frame_pos"])
+        assert row["axis"] == [0.0, 0.0, 1.0]
+        assert abs(row["lower"] + tab["limit"][i]) < 1e-12 and abs(row["upper"] - tab["limit"][i]) < 1e-12
+        q = _quat_inv_from_rpy(O, tab["rpy"][i])
+        w = np.array(row["parent_frame_orn"])
+        assert min(np.abs(q - w).max(), np.abs(q + w).max()) < 1e-9, (i, q, w)
+
+
+def test_product_urdf_assets_equal_oracle_tables(O):
+    """The product's URDF assets and the oracle's tables were entered independently."""
+    from armenv.urdf import builtin_chain
+    for robot in ("kuka", "diana"):
+        ch = builtin_chain(robot)
+        tab = O.ROBOTS[robot]
+        assert np.allclose(ch.origin_xyz, tab["xyz"], atol=0, rtol=0)
+        assert np.allclose(ch.origin_rpy, tab["rpy"], atol=0, rtol=0)
+        assert np.allclose(ch.limit_hi, tab["limit"], atol=0, rtol=0)
+        assert np.allclose(ch.inertial_xyz, tab["inertial"], atol=0, rtol=0)
+
+
+def test_diana_derived_positions(O, diana):
+    """SURVEY.md G1 derived values (numpy, not PyBullet outputs)."""
+    p, _ = O.fk(diana, [0.0] * 7)
+    assert np.abs(p[0] - [0, 0.1554, 1.2615]).max() < 1e-4
+    dy = O.make_chain("diana", base_rpy=(0, 0, math.pi))
+    p2, _ = O.fk(dy, [0.0] * 7)
+    assert np.abs(p2[0] - [0, -0.1554, 1.2615]).max() < 1e-4
+
+
+def test_philox_known_answers(O):
+    """Random123 kat_vectors, philox4x32 10 rounds."""
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_reward_truth_table(O):
+    g = golden_json("reward_truth.json")
+    cfg = O.default_config()
+    assert cfg.max_steps == g["max_steps"] and cfg.reach_dis == g["reach_dis"]
+    for row in g["rows"]:
+        r, d, s = O.reach_outcome(cfg, row["distance"], row["step_counter"])
+        assert (r, d, s) == (row["reward"], row["done"], row["success"]), row
+
+
+def test_target_quaternion(O):
+    q = O.default_config().target_quat
+    s = math.sqrt(0.5)
+    assert np.abs(np.array(q[:]) - [s, -s, 0, 0]).max() < 1e-15
+
+
+def test_jacobian_matches_finite_differences(O, kuka):
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        q = rng.uniform(-1.5, 1.5, 7)
+        J = O.jacobian(kuka, q)
+        h = 1e-6
+        for i in range(7):
+            dq = np.zeros(7); dq[i] = h
+            pp, _ = O.fk(kuka, q + dq); pm, _ = O.fk(kuka, q - dq)
+            assert np.abs((pp[0] - pm[0]) / (2 * h) - J[:3, i]).max() < 1e-8
+
+
+def test_dls_primal_equals_dual(O, kuka):
+    """(J^T J + l I)^-1 J^T e == J^T (J J^T + l I)^-1 e to 1e-9 in f64."""
+    rng = np.random.default_rng(2)
+    worst = 0.0
+    for _ in range(50):
+        q = rng.uniform(-2, 2, 7)
+        J = O.jacobian(kuka, q)
+        e = rng.normal(0, 0.05, 6)
+        a = O.dls_delta(J, e, 1e-5, 10.0, 0)
+        b = O.dls_delta(J, e, 1e-5, 10.0, 1)
+        ref = J.T @ np.linalg.solve(J @ J.T + 1e-5 * np.eye(6), e)
+        worst = max(worst, np.abs(a - b).max(), np.abs(b - ref).max())
+    assert worst < 1e-9
+
+
+def test_dls_clamp_45_degrees(O, kuka):
+    J = O.jacobian(kuka, O.INIT_Q)
+    d = O.dls_delta(J, np.array([0, 0, 0, 0, 0, 3.0]), 1e-5, math.pi / 4, 0)
+    assert abs(np.abs(d).max() - math.pi / 4) < 1e-12
+
+
+def test_orientation_error_small_and_wrapped(O):
+    # rotation by angle a about z: q = (0,0,sin(a/2),cos(a/2)); error of target vs identity is +a z
+    for a in (0.3, -0.3, 3.0, -3.0):
+        qt = [0, 0, math.sin(a / 2), math.cos(a / 2)]
+        e = O.orientation_error(qt, [0, 0, 0, 1], angle_f32=0)
+        assert np.abs(e - [0, 0, a]).max() < 1e-12
+    # the same rotation written with the opposite quaternion sign (w<0) wraps to the short way
+    a = 0.4
+    qt = [0, 0, -math.sin(a / 2), -math.cos(a / 2)]
+    e = O.orientation_error(qt, [0, 0, 0, 1], angle_f32=0)
+    assert np.abs(e - [0, 0, a]).max() < 1e-12
+    # identical orientations: axis falls back to (1,0,0), angle 0
+    assert np.abs(O.orientation_error([0, 0, 0, 1], [0, 0, 0, 1])).max() == 0.0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ik_postconditions(O, kuka, mode):
+    """After calculateInverseKinematics: |p - target| well below the residual threshold, tool
+    orientation at the target quaternion, iteration counts as probed in SURVEY.md Appendix E."""
+    cfg = O.default_config(); cfg.ik_exit_mode = mode
+    rng = np.random.default_rng(3)
+    st = O.ReachState(64)
+    O.reach_reset(kuka, cfg, st, seed=7)
+    hist = []
+    for t in range(40):
+        a = np.clip(rng.normal(0, 0.686, (64, 3)), -0.7, 0.7)
+        q0 = st.q.copy()
+        p0, _ = O.fk(kuka, q0)
+        obs, rew, done, succ, iters = O.reach_step(kuka, cfg, st, a)
+        tgt = np.clip(p0 + 0.02 * a.astype(np.float32).astype(np.float64), cfg.box_lo[:], cfg.box_hi[:])
+        p1, quat = O.fk(kuka, st.q)
+        assert np.linalg.norm(p1 - tgt, axis=1).max() < 1e-4
+        if t > 0:
+            qt = np.array(cfg.target_quat[:])
+            assert np.minimum(np.abs(quat - qt).max(1), np.abs(quat + qt).max(1)).max() < (1e-4 if mode == 0 else 1e-3)
+        assert np.abs(obs[:, :3] - p1.astype(np.float32)).max() == 0
+        hist.append(iters)
+    hist = np.array(hist)
+    assert hist[0].max() == (4 if mode == 0 else 3)       # 90 degree tool-yaw correction after reset
+    assert 1.5 + (1 - mode) < hist[1:].mean() < 2.1 + (1 - mode)
+    assert hist.max() <= 20
+
+
+def test_ik_iteration_cap(O, kuka):
+    cfg = O.default_config(); cfg.ik_max_iters = 2
+    q, it = O.ik(kuka, cfg, O.INIT_Q, [0.3, 0.2, 0.1])
+    assert it[0] == 2
+
+
+def test_reset_goals_in_box_and_f32(O, kuka):
+    cfg = O.default_config()
+    st = O.ReachState(4096)
+    obs = O.reach_reset(kuka, cfg, st, seed=123, env_id0=10)
+    lo, hi = np.float32(cfg.goal_lo[:]), np.float32(cfg.goal_hi[:])
+    assert (st.goal >= lo).all() and (st.goal <= hi).all()
+    assert (st.episode == 1).all() and (st.step == 0).all()
+    assert np.abs(obs[:, 3:] - st.goal).max() == 0
+    g = golden_json("fk_kat.json")
+    assert np.abs(obs[:, :3] - np.float32(g["p_f32"])).max() <= 6.0e-8
+    # goals depend on (seed, global env id, episode) only: shifting env_id0 shifts the stream
+    st2 = O.ReachState(4096)
+    O.reach_reset(kuka, cfg, st2, seed=123, env_id0=11)
+    assert np.array_equal(st2.goal[:-1], st.goal[1:])
+    # uniformity (coarse)
+    u = (st.goal - lo) / (hi - lo)
+    assert np.abs(u.mean(0) - 0.5).max() < 0.03
+
+
+def test_autoreset_bookkeeping(O, kuka):
+    cfg = O.default_config(); cfg.max_steps = 5
+    st = O.ReachState(8)
+    O.reach_reset(kuka, cfg, st, seed=1)
+    rets = np.zeros(8)
+    for t in range(6):
+        obs, rew, done, succ, term = O.reach_step_autoreset(kuka, cfg, st, np.zeros((8, 3)), seed=1)
+        rets += rew
+        assert done.all() == (t == 5)
+    assert (st.step == 0).all() and (st.episode == 2).all() and (st.last_len == 6).all()
+    assert np.allclose(st.last_return, rets) and (st.ep_return == 0).all()
+    assert np.abs(obs[:, 3:] - st.goal).max() == 0 and np.abs(term[:, 3:] - st.goal).max() > 0
+
+
+def test_actor_matches_reference_golden(O):
+    """G3: vectors produced by importing the reference's TD3_MLP (algo/TD3/net_mlp.py:29-40)."""
+    g = golden_npz("td3_actor_seed0.npz")
+    sd = {k: g[k.replace(".", "_")] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+    a = O.actor_forward(sd, g["states"], float(g["action_bound"]))
+    assert np.abs(a - g["actions"]).max() < 1e-5
+    assert np.abs(g["actions"][0] - [0.02861051, -0.01318958, -0.02435399]).max() < 1e-6   # SURVEY.md G3 spot value
