@@ -77,6 +77,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ArmEnvError(-2, f"{LIB_PATH} not found: build it with `make -C drl-on-robot-arm_amd` "
                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same soname as
+        # /opt/rocm's).  Import torch first so that libarmenv.so binds to the runtime torch uses; with
+        # the opposite order torch finds the system runtime already loaded and reports no GPUs.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)

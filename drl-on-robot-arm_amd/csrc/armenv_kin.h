@@ -153,6 +153,16 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
   const T dy = aw * by + ay * bw + az * bx - ax * bz;
   const T dz = aw * bz + az * bw + ax * by - ay * bx;
   const T dw = aw * bw - ax * bx - ay * by - az * bz;
+  if constexpr (sizeof(T) == 4) {
+    // f32: 2*acos(w) is useless near convergence (w = 1 - k*6e-8 quantises the angle to ~7e-4*sqrt(k) rad),
+    // so the f32 engine uses the well-conditioned equivalent angle = 2*atan2(|v|, |w|) on the short arc.
+    const T sg = dw < T(0) ? T(-1) : T(1);
+    const T n = M::sqrt(dx * dx + dy * dy + dz * dz);
+    const T ang = T(2) * ::atan2f(n, sg * dw);
+    const T k = n > T(1e-30) ? sg * ang / n : T(0);
+    e[0] = k * dx; e[1] = k * dy; e[2] = k * dz;
+    return;
+  }
   const T wc = dw < T(-1) ? T(-1) : (dw > T(1) ? T(1) : dw);
   T angle = T(2) * M::acos(wc);
   const T s2 = T(1) - dw * dw;

@@ -69,11 +69,13 @@ def test_fk_matches_oracle(envs, O, robot, fk_path, precision):
     assert ("generic" in e.kernel_name) == (fk_path == 1)
     pos, quat = e.fk(torch.from_numpy(q))
     p_ref, q_ref = O.fk(O.make_chain(robot), q)
-    tol = 1e-12 if precision == 64 else 5e-6
+    # the built-in fast path snaps the URDF's 11-digit rpy text to exact signed permutations
+    # (|delta R| ~ 5e-12); the generic path uses the same rpy-derived matrices as the oracle
+    tol = (5e-11 if fk_path == 0 else 1e-12) if precision == 64 else 5e-6
     assert np.abs(_np(pos) - p_ref).max() < tol
     dq = np.minimum(np.abs(_np(quat) - q_ref).max(1), np.abs(_np(quat) + q_ref).max(1))
     # getRotation switches branch on the trace / largest diagonal; both give the same rotation
-    assert np.median(dq) < (1e-12 if precision == 64 else 1e-5)
+    assert np.median(dq) < (tol if precision == 64 else 1e-5)
     assert dq.max() < (1e-6 if precision == 64 else 2e-2)
     e.close()
 
@@ -119,7 +121,9 @@ def test_ik_matches_oracle_f64(envs, O, robot, fk_path, mode):
     q_ref, it_ref = O.ik(ch, cfg, q0, tgt)
     same = _np(it_gpu) == it_ref
     assert same.mean() > 0.999                       # a residual within ~1e-15 of 1e-4 may flip one trip
-    assert np.abs(_np(q_gpu) - q_ref)[same].max() < 1e-6
+    # Diana from these arbitrary poses passes near singular configurations, where the damped solve
+    # amplifies the 3e-8 rad conditioning noise of 2*acos(w) by up to ~1/(2 sqrt(lambda)) = 158
+    assert np.abs(_np(q_gpu) - q_ref)[same].max() < (1e-6 if robot == "kuka" else 1e-5)
     assert it_ref.max() <= 20 and it_ref.min() >= (1 if mode == 0 else 0)
     e.close()
 
