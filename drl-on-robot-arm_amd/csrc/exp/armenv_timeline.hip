@@ -1,0 +1,666 @@
+// armenv.hip -- gfx950 kernels and the C ABI (include/armenv.h) of the batched arm-env engine.
+//
+// Data layout in HBM (N envs, T = f64 or f32 by ArmEnvConfig.precision), struct-of-arrays with the
+// env index fastest so that a wave's 64 lanes touch 64 consecutive elements of every array:
+//   q[7][N] T | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
+//   last_len[N] i32 | last_success[N] u8 | counters[4] u64
+// Caller-facing buffers keep the reference's array-of-struct shapes (action [N][3], obs [N][6]);
+// a wave still reads/writes one contiguous 768 B / 1536 B span of them.
+//
+// One env per lane, no LDS, no cross-lane traffic on the step path; the chain constants are
+// compile-time (built-in arms) or wave-uniform kernel arguments (generic chains).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "../../../include/armenv.h"
+#include "../armenv_kin.h"
+
+using namespace armenv;
+
+// ------------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------------
+
+template <typename T> struct EnvParams {
+  // state
+  T *q;
+  T *ep_return;
+  T *last_return;
+  float *goal;
+  int32_t *step;
+  uint32_t *episode;
+  int32_t *last_len;
+  uint8_t *last_success;
+  unsigned long long *counters;
+  int64_t n;
+  // task constants
+  T dv;
+  T reach_dis;
+  int32_t max_steps;
+  int32_t auto_reset;
+  T box_lo[3];
+  T box_hi[3];
+  double goal_lo[3];
+  double goal_hi[3];
+  T q_init[NJ];
+  T p_init[3];  // FK(q_init), computed on the device at create time
+  uint64_t seed;
+  uint64_t env_id0;
+  IKParams<T> ik;
+  ChainDev<T> chain;
+};
+
+struct StepIO {
+  const float *action;
+  float *obs;
+  float *reward;
+  uint8_t *done;
+  uint8_t *success;
+  float *terminal_obs;
+};
+
+// goal ~ U(box): a + (b - a) * u per axis as random.uniform does (rl_reach_env.py:180-182), then the
+// f32 cast of :213-215.  Always f64 arithmetic so that both precisions draw identical goals.
+template <typename T>
+AE_DEV void sample_goal(const EnvParams<T> &P, int64_t i, uint32_t episode, float (&g)[3]) {
+  double u0, u1, u2, u3;
+  philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 0u, u0, u1);
+  philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 1u, u2, u3);
+  g[0] = (float)(P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u0);
+  g[1] = (float)(P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u1);
+  g[2] = (float)(P.goal_lo[2] + (P.goal_hi[2] - P.goal_lo[2]) * u2);
+}
+
+template <typename T>
+AE_DEV void store_obs6(float *obs, int64_t i, const T (&p)[3], const float (&g)[3]) {
+  float2 *o = reinterpret_cast<float2 *>(obs + 6 * i);  // 24 B rows: 8-byte aligned
+  o[0] = make_float2((float)p[0], (float)p[1]);
+  o[1] = make_float2((float)p[2], g[0]);
+  o[2] = make_float2(g[1], g[2]);
+}
+
+// FK(q_init) once per handle, with the same device code the step uses.
+template <class C, typename T>
+__global__ void init_consts_kernel(EnvParams<T> P, T *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  T q[NJ];
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = P.q_init[i]; });
+  FKState<T> S;
+  fk<C, T>(P.chain, q, S);
+  out[0] = S.p[0]; out[1] = S.p[1]; out[2] = S.p[2];
+}
+
+// RLReachEnv.reset (rl_reach_env.py:132-217) for masked envs.
+template <typename T>
+__global__ __launch_bounds__(256) void reach_reset_kernel(EnvParams<T> P, const uint8_t *mask, const float *goal_in,
+                                                          float *obs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (mask && !mask[i]) return;
+  float g[3];
+  if (goal_in) {
+    g[0] = goal_in[3 * i]; g[1] = goal_in[3 * i + 1]; g[2] = goal_in[3 * i + 2];
+  } else {
+    const uint32_t ep = P.episode[i];
+    sample_goal(P, i, ep, g);
+    P.episode[i] = ep + 1u;
+  }
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.q_init[j]; });
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = g[k]; });
+  P.step[i] = 0;
+  P.ep_return[i] = T(0);
+  if (obs) store_obs6<T>(obs, i, P.p_init, g);
+}
+
+// RLReachEnv.step + _reward (rl_reach_env.py:219-319), one env per lane, fused:
+// load state -> FK -> target = clip(p + dv a) -> DLS IK loop -> FK -> distance / reward / done ->
+// obs pack -> episode accounting -> optional in-place reset -> store state.
+__device__ unsigned long long *g_tl;
+template <class C, typename T>
+__global__ __launch_bounds__(256) void reach_step_kernel(EnvParams<T> P, StepIO io) {
+  using M = Mth<T>;
+  unsigned long long t0 = wall_clock64();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const int64_t n = P.n;
+
+  T q[NJ];
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * n + i]; });
+  float g[3];
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; g[k] = P.goal[(int64_t)k * n + i]; });
+  int32_t step = P.step[i];
+  T ep_ret = P.ep_return[i];
+  T a[3];
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; a[k] = (T)io.action[3 * i + k]; });
+
+  FKState<T> S;
+  T tgt[3];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned long long t1 = wall_clock64();
+  int trips = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
+  unsigned long long t2 = wall_clock64();
+
+  step += 1;                                                                    // :264
+  const T dx = S.p[0] - (T)g[0], dy = S.p[1] - (T)g[1], dz = S.p[2] - (T)g[2];
+  const T dist = M::sqrt(dx * dx + dy * dy + dz * dz);                          // :281
+  T reward;
+  bool done, succ;
+  if (step > P.max_steps) { reward = -dist * T(10); done = true; succ = false; }          // :299-301
+  else if (dist < P.reach_dis) { reward = T(0); done = true; succ = true; }               // :303-306
+  else { reward = -dist * T(10); done = false; succ = false; }                            // :307-309
+  ep_ret += reward;
+
+  bool finite = true;
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
+  if (!finite) atomicAdd(&P.counters[3], 1ull);
+
+  io.reward[i] = (float)reward;
+  io.done[i] = done ? 1 : 0;
+  io.success[i] = succ ? 1 : 0;
+  if (io.terminal_obs) store_obs6<T>(io.terminal_obs, i, S.p, g);
+
+  if (done) {
+    P.last_return[i] = ep_ret;
+    P.last_len[i] = step;
+    P.last_success[i] = succ ? 1 : 0;
+    atomicAdd(&P.counters[0], 1ull);
+    if (succ) atomicAdd(&P.counters[1], 1ull);
+  }
+  if (done && P.auto_reset) {
+    const uint32_t ep = P.episode[i];
+    sample_goal(P, i, ep, g);
+    P.episode[i] = ep + 1u;
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
+    step = 0;
+    ep_ret = T(0);
+    store_obs6<T>(io.obs, i, P.p_init, g);
+  } else {
+    store_obs6<T>(io.obs, i, S.p, g);                                           // :319
+  }
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
+  P.step[i] = step;
+  P.ep_return[i] = ep_ret;
+  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)n);
+  unsigned long long t3 = wall_clock64();
+  int mx = trips;
+  for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+  unsigned long long anyd = __ballot(done);
+  if ((threadIdx.x & 63) == 0 && g_tl) { unsigned long long *r = g_tl + 8 * (i >> 6); r[0]=t0; r[1]=t1; r[2]=t2; r[3]=t3; r[4]=mx; r[5]=__popcll(anyd); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); r[6]=xcc; unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); r[7]=hw; }
+}
+
+// p.getLinkState(body, 6)[4], [5]
+template <class C, typename T>
+__global__ __launch_bounds__(256) void fk_kernel(EnvParams<T> P, int64_t n, const double *q_in, double *pos, double *quat) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T q[NJ];
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = (T)q_in[7 * i + j]; });
+  FKState<T> S;
+  fk<C, T>(P.chain, q, S);
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; pos[3 * i + k] = (double)S.p[k]; });
+  if (quat) {
+    T qc[4];
+    quat_from_frame<T>(S.W, qc);
+    static_for<0, 4>([&](auto KI) { constexpr int k = KI; quat[4 * i + k] = (double)qc[k]; });
+  }
+}
+
+// p.calculateInverseKinematics(body, 6, pos, orn, jointDamping)
+template <class C, typename T>
+__global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, const double *q_in, const double *tgt_in,
+                                                 double *q_out, int32_t *iters) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T q[NJ], tgt[3], a[3] = {T(0), T(0), T(0)};
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = (T)q_in[7 * i + j]; });
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; tgt[k] = (T)tgt_in[3 * i + k]; });
+  FKState<T> S;
+  const int it = ik_move<C, T, false>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q_out[7 * i + j] = (double)q[j]; });
+  if (iters) iters[i] = it;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *q, float *goal, int32_t *step,
+                                                        uint32_t *episode, double *ep_return) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[7 * i + j] = (double)P.q[(int64_t)j * P.n + i]; });
+  if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; goal[3 * i + k] = P.goal[(int64_t)k * P.n + i]; });
+  if (step) step[i] = P.step[i];
+  if (episode) episode[i] = P.episode[i];
+  if (ep_return) ep_return[i] = (double)P.ep_return[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void set_state_kernel(EnvParams<T> P, const double *q, const float *goal,
+                                                        const int32_t *step, const uint32_t *episode,
+                                                        const double *ep_return) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = (T)q[7 * i + j]; });
+  if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = goal[3 * i + k]; });
+  if (step) P.step[i] = step[i];
+  if (episode) P.episode[i] = episode[i];
+  if (ep_return) P.ep_return[i] = (T)ep_return[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void episode_stats_kernel(EnvParams<T> P, double *last_return, int32_t *last_len,
+                                                            uint8_t *last_success) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (last_return) last_return[i] = (double)P.last_return[i];
+  if (last_len) last_len[i] = P.last_len[i];
+  if (last_success) last_success[i] = P.last_success[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(ARMENV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+static void rpy_to_mat(const double rpy[3], double R[9]) {  // row-major, Rz(yaw) Ry(pitch) Rx(roll)
+  const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]);
+  const double cp = std::cos(rpy[1]), sp = std::sin(rpy[1]);
+  const double cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
+  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+
+template <class C> static bool chain_matches(const ArmEnvChain &ch) {
+  for (int k = 0; k < 3; ++k)
+    if (ch.base_xyz[k] != 0.0 || ch.base_rpy[k] != 0.0) return false;
+  for (int j = 0; j < NJ; ++j) {
+    double R[9];
+    rpy_to_mat(ch.origin_rpy[j], R);
+    for (int c = 0; c < 3; ++c) {
+      if (std::fabs(ch.origin_xyz[j][c] - C::xyz[j][c]) > 1e-12) return false;
+      for (int r = 0; r < 3; ++r) {
+        const double want = (r == C::perm[j][c]) ? (double)C::sgn[j][c] : 0.0;
+        if (std::fabs(R[3 * r + c] - want) > 1e-9) return false;
+      }
+    }
+  }
+  return true;
+}
+
+struct EngineBase {
+  virtual ~EngineBase() {}
+  virtual int init(const ArmEnvConfig &cfg) = 0;
+  virtual int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) = 0;
+  virtual int step(const StepIO &io, hipStream_t s) = 0;
+  virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
+  virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
+  virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, hipStream_t s) = 0;
+  virtual int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
+                        const double *ep_return, hipStream_t s) = 0;
+  virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
+  virtual int counters(uint64_t out[4], hipStream_t s) = 0;
+  virtual const char *name() const = 0;
+};
+
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+template <class C, typename T> struct Engine final : EngineBase {
+  EnvParams<T> P{};
+  void *pool = nullptr;
+  int block = 256;
+  std::string kname;
+
+  ~Engine() override {
+    if (pool) (void)hipFree(pool);
+  }
+
+  int init(const ArmEnvConfig &cfg) override {
+    const int64_t n = cfg.num_envs;
+    P.n = n;
+    // carve one allocation, 256-byte aligned sections
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
+    const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
+    const size_t o_ls = take(n), o_cnt = take(8 * 4), o_tmp = take(sizeof(T) * 4);
+    if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
+    HIP_TRY(hipMemset(pool, 0, off));
+    char *b = static_cast<char *>(pool);
+    P.q = reinterpret_cast<T *>(b + o_q);
+    P.ep_return = reinterpret_cast<T *>(b + o_er);
+    P.last_return = reinterpret_cast<T *>(b + o_lr);
+    P.goal = reinterpret_cast<float *>(b + o_goal);
+    P.step = reinterpret_cast<int32_t *>(b + o_step);
+    P.episode = reinterpret_cast<uint32_t *>(b + o_ep);
+    P.last_len = reinterpret_cast<int32_t *>(b + o_ll);
+    P.last_success = reinterpret_cast<uint8_t *>(b + o_ls);
+    P.counters = reinterpret_cast<unsigned long long *>(b + o_cnt);
+    T *tmp = reinterpret_cast<T *>(b + o_tmp);
+
+    P.dv = (T)cfg.dv;
+    P.reach_dis = (T)cfg.reach_dis;
+    P.max_steps = cfg.max_steps;
+    P.auto_reset = cfg.auto_reset;
+    P.seed = cfg.seed;
+    P.env_id0 = cfg.env_id_offset;
+    for (int k = 0; k < 3; ++k) {
+      P.box_lo[k] = (T)cfg.box_lo[k]; P.box_hi[k] = (T)cfg.box_hi[k];
+      P.goal_lo[k] = cfg.goal_lo[k]; P.goal_hi[k] = cfg.goal_hi[k];
+    }
+    for (int j = 0; j < NJ; ++j) {
+      P.q_init[j] = (T)cfg.q_init[j];
+      P.ik.lim_lo[j] = (T)cfg.chain.limit_lo[j];
+      P.ik.lim_hi[j] = (T)cfg.chain.limit_hi[j];
+    }
+    for (int k = 0; k < 4; ++k) P.ik.tq[k] = (T)cfg.target_quat[k];
+    P.ik.lambda = (T)cfg.ik_lambda;
+    P.ik.residual = (T)cfg.ik_residual;
+    P.ik.max_dtheta = (T)cfg.ik_max_dtheta;
+    P.ik.max_iters = cfg.ik_max_iters;
+    P.ik.exit_mode = cfg.ik_exit_mode;
+    P.ik.angle_f32 = cfg.ik_angle_f32;
+    P.ik.clamp_limits = cfg.clamp_joint_limits;
+    for (int j = 0; j < NJ; ++j) {
+      double R[9];
+      rpy_to_mat(cfg.chain.origin_rpy[j], R);
+      for (int k = 0; k < 9; ++k) P.chain.R[j][k] = (T)R[k];
+      for (int k = 0; k < 3; ++k) P.chain.xyz[j][k] = (T)cfg.chain.origin_xyz[j][k];
+    }
+    {
+      double R[9];
+      rpy_to_mat(cfg.chain.base_rpy, R);
+      for (int k = 0; k < 9; ++k) P.chain.base_R[k] = (T)R[k];
+      for (int k = 0; k < 3; ++k) P.chain.base_p[k] = (T)cfg.chain.base_xyz[k];
+    }
+    hipLaunchKernelGGL((init_consts_kernel<C, T>), dim3(1), dim3(64), 0, 0, P, tmp);
+    HIP_TRY(hipGetLastError());
+    T host_p[3];
+    HIP_TRY(hipMemcpy(host_p, tmp, sizeof host_p, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) P.p_init[k] = host_p[k];
+    if (const char *bs = getenv("ARMENV_BLOCK")) {
+      const int v = atoi(bs);
+      if (v == 64 || v == 128 || v == 256) block = v;
+    }
+    kname = std::string("reach_step<") + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
+    return ARMENV_OK;
+  }
+
+  int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) override {
+    hipLaunchKernelGGL((reach_reset_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, mask, goal, obs);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int step(const StepIO &io, hipStream_t s) override {
+    hipLaunchKernelGGL((reach_step_kernel<C, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) override {
+    hipLaunchKernelGGL((fk_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, pos, quat);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) override {
+    hipLaunchKernelGGL((ik_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, tgt, q_out, iters);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, hipStream_t s) override {
+    hipLaunchKernelGGL((get_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
+                       ep_return);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
+                const double *ep_return, hipStream_t s) override {
+    hipLaunchKernelGGL((set_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
+                       ep_return);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) override {
+    hipLaunchKernelGGL((episode_stats_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, last_return,
+                       last_len, last_success);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int counters(uint64_t out[4], hipStream_t s) override {
+    HIP_TRY(hipMemcpyAsync(out, P.counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ARMENV_OK;
+  }
+  const char *name() const override { return kname.c_str(); }
+};
+
+struct ArmEnv {
+  ArmEnvConfig cfg;
+  std::unique_ptr<EngineBase> eng;
+};
+
+template <typename T> static EngineBase *make_engine(const ArmEnvConfig &cfg) {
+  if (cfg.fk_path == ARMENV_FK_AUTO) {
+    if (chain_matches<KukaChain>(cfg.chain)) return new (std::nothrow) Engine<KukaChain, T>();
+    if (chain_matches<DianaChain>(cfg.chain)) return new (std::nothrow) Engine<DianaChain, T>();
+  }
+  return new (std::nothrow) Engine<GenericChain, T>();
+}
+
+static void fill_chain(ArmEnvChain *out, const double (*xyz)[3], const double (*rpy)[3], const double *lo,
+                       const double *hi) {
+  std::memset(out, 0, sizeof *out);
+  for (int j = 0; j < NJ; ++j) {
+    for (int k = 0; k < 3; ++k) { out->origin_xyz[j][k] = xyz[j][k]; out->origin_rpy[j][k] = rpy[j][k]; }
+    out->limit_lo[j] = lo[j];
+    out->limit_hi[j] = hi[j];
+  }
+}
+
+extern "C" {
+int armenv_dbg_set_timeline(unsigned long long *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &p, sizeof p); }
+
+int32_t armenv_abi_version(void) { return ARMENV_ABI_VERSION; }
+const char *armenv_last_error(void) { return g_err.c_str(); }
+
+int armenv_builtin_chain(int32_t robot, ArmEnvChain *out) {
+  if (!out) return fail(ARMENV_EINVAL, "armenv_builtin_chain: out is NULL");
+  if (robot == ARMENV_ROBOT_KUKA) fill_chain(out, KukaChain::xyz, KukaChain::rpy, KukaChain::limit_lo, KukaChain::limit_hi);
+  else if (robot == ARMENV_ROBOT_DIANA) fill_chain(out, DianaChain::xyz, DianaChain::rpy, DianaChain::limit_lo, DianaChain::limit_hi);
+  else return fail(ARMENV_EINVAL, "armenv_builtin_chain: unknown robot %d", robot);
+  return ARMENV_OK;
+}
+
+int armenv_default_config(int32_t task, ArmEnvConfig *c) {
+  if (!c) return fail(ARMENV_EINVAL, "armenv_default_config: cfg is NULL");
+  if (task != ARMENV_TASK_REACH && task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "unknown task %d", task);
+  std::memset(c, 0, sizeof *c);
+  c->abi_version = ARMENV_ABI_VERSION;
+  c->device = 0;
+  c->num_envs = 1;
+  c->task = task;
+  c->precision = 64;
+  c->fk_path = ARMENV_FK_AUTO;
+  c->auto_reset = 1;
+  c->seed = 0;
+  c->env_id_offset = 0;
+  c->dv = task == ARMENV_TASK_REACH ? 0.02 : 0.08;
+  c->reach_dis = 0.01;
+  c->max_steps = 500;
+  c->clamp_joint_limits = 0;
+  const double lo[3] = {0.2, -0.3, 0.0}, hi[3] = {0.7, 0.3, 0.55};
+  for (int k = 0; k < 3; ++k) { c->box_lo[k] = lo[k]; c->box_hi[k] = hi[k]; c->goal_lo[k] = lo[k]; c->goal_hi[k] = hi[k]; }
+  if (task == ARMENV_TASK_PUSH) c->box_hi[2] = 0.1;
+  // p.getQuaternionFromEuler([0, -pi, pi/2]) (Bullet setEulerZYX)
+  {
+    const double pi = 3.14159265358979323846;
+    const double hr = 0.0, hp = -pi * 0.5, hy = pi * 0.25;
+    const double cr = std::cos(hr), sr = std::sin(hr), cp = std::cos(hp), sp = std::sin(hp), cy = std::cos(hy), sy = std::sin(hy);
+    c->target_quat[0] = sr * cp * cy - cr * sp * sy;
+    c->target_quat[1] = cr * sp * cy + sr * cp * sy;
+    c->target_quat[2] = cr * cp * sy - sr * sp * cy;
+    c->target_quat[3] = cr * cp * cy + sr * sp * sy;
+  }
+  const double qi[NJ] = {0.006418, 0.413184, -0.011401, -1.589317, 0.005379, 1.137684, -0.006539};
+  for (int j = 0; j < NJ; ++j) c->q_init[j] = qi[j];
+  c->ik_lambda = 1e-5;
+  c->ik_residual = 1e-4;
+  c->ik_max_dtheta = 45.0 * 3.14159265358979323846 / 180.0;
+  c->ik_max_iters = 20;
+  c->ik_exit_mode = 0;
+  c->ik_angle_f32 = 1;
+  c->push_success_dis = 0.05;
+  c->push_cube_half = 0.02;
+  c->push_eef_radius = 0.03;
+  c->push_rest_z = 0.01;
+  c->push_place_min = 0.22;
+  c->push_place_max = 0.25;
+  return armenv_builtin_chain(ARMENV_ROBOT_KUKA, &c->chain);
+}
+
+int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
+  if (!cfg || !out) return fail(ARMENV_EINVAL, "armenv_create: NULL argument");
+  *out = nullptr;
+  if (cfg->abi_version != ARMENV_ABI_VERSION)
+    return fail(ARMENV_EINVAL, "armenv_create: abi_version %d, library is %d", cfg->abi_version, ARMENV_ABI_VERSION);
+  if (cfg->num_envs < 1) return fail(ARMENV_EINVAL, "armenv_create: num_envs must be >= 1");
+  if (cfg->precision != 64 && cfg->precision != 32) return fail(ARMENV_EINVAL, "armenv_create: precision must be 32 or 64");
+  if (cfg->task != ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_create: task %d not available", cfg->task);
+  if (cfg->ik_max_iters < 0 || cfg->ik_max_iters > 1000) return fail(ARMENV_EINVAL, "armenv_create: ik_max_iters out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(ARMENV_ENODEV, "armenv_create: no HIP device is visible (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(ARMENV_ENODEV, "armenv_create: device %d of %d", cfg->device, ndev);
+  DeviceGuard guard(cfg->device);
+  if (!guard.ok) return fail(ARMENV_ENODEV, "armenv_create: hipSetDevice(%d) failed", cfg->device);
+  std::unique_ptr<ArmEnv> env(new (std::nothrow) ArmEnv());
+  if (!env) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
+  env->cfg = *cfg;
+  env->eng.reset(cfg->precision == 64 ? make_engine<double>(*cfg) : make_engine<float>(*cfg));
+  if (!env->eng) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
+  const int rc = env->eng->init(*cfg);
+  if (rc != ARMENV_OK) return rc;
+  *out = env.release();
+  return ARMENV_OK;
+}
+
+void armenv_destroy(ArmEnv *env) {
+  if (!env) return;
+  DeviceGuard guard(env->cfg.device);
+  delete env;
+}
+
+#define ENV_ENTER(env)                                                                  \
+  if (!(env)) return fail(ARMENV_EINVAL, "%s: env is NULL", __func__);                  \
+  DeviceGuard guard_((env)->cfg.device);                                                \
+  if (!guard_.ok) return fail(ARMENV_ENODEV, "%s: hipSetDevice failed", __func__)
+
+int armenv_reset(ArmEnv *env, const uint8_t *mask_dev, float *obs_dev, void *stream) {
+  ENV_ENTER(env);
+  return env->eng->reset(mask_dev, nullptr, obs_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *goal_dev, float *obs_dev, void *stream) {
+  ENV_ENTER(env);
+  if (!goal_dev) return fail(ARMENV_EINVAL, "armenv_reset_with_goal: goal_dev is NULL");
+  return env->eng->reset(mask_dev, goal_dev, obs_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+                uint8_t *success_dev, float *terminal_obs_dev, void *stream) {
+  ENV_ENTER(env);
+  if (!action_dev) return fail(ARMENV_ESTATE, "armenv_step: action_dev is NULL and no fused policy is installed");
+  if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_step: NULL output buffer");
+  StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev};
+  return env->eng->step(io, static_cast<hipStream_t>(stream));
+}
+
+int armenv_fk(ArmEnv *env, int64_t n, const double *q_dev, double *pos_dev, double *quat_dev, void *stream) {
+  ENV_ENTER(env);
+  if (n < 0 || (n > 0 && (!q_dev || !pos_dev))) return fail(ARMENV_EINVAL, "armenv_fk: bad arguments");
+  if (n == 0) return ARMENV_OK;
+  return env->eng->fk(n, q_dev, pos_dev, quat_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_pos_dev, double *q_out_dev,
+              int32_t *iters_dev, void *stream) {
+  ENV_ENTER(env);
+  if (n < 0 || (n > 0 && (!q_dev || !target_pos_dev || !q_out_dev))) return fail(ARMENV_EINVAL, "armenv_ik: bad arguments");
+  if (n == 0) return ARMENV_OK;
+  return env->eng->ik(n, q_dev, target_pos_dev, q_out_dev, iters_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_get_state(ArmEnv *env, double *q_dev, float *goal_dev, int32_t *step_dev, uint32_t *episode_dev,
+                     double *ep_return_dev, double *aux_dev, void *stream) {
+  ENV_ENTER(env);
+  if (aux_dev) return fail(ARMENV_EINVAL, "armenv_get_state: aux is only defined for the push task");
+  return env->eng->get_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, const int32_t *step_dev,
+                     const uint32_t *episode_dev, const double *ep_return_dev, const double *aux_dev, void *stream) {
+  ENV_ENTER(env);
+  if (aux_dev) return fail(ARMENV_EINVAL, "armenv_set_state: aux is only defined for the push task");
+  return env->eng->set_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len_dev, uint8_t *last_success_dev,
+                         void *stream) {
+  ENV_ENTER(env);
+  return env->eng->episode_stats(last_return_dev, last_len_dev, last_success_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_counters(ArmEnv *env, uint64_t out[4], void *stream) {
+  ENV_ENTER(env);
+  if (!out) return fail(ARMENV_EINVAL, "armenv_counters: out is NULL");
+  return env->eng->counters(out, static_cast<hipStream_t>(stream));
+}
+
+int armenv_set_policy(ArmEnv *env, int32_t policy, const float *, const float *, const float *, const float *,
+                      const float *, const float *, int32_t, float, float, float, void *) {
+  ENV_ENTER(env);
+  if (policy == ARMENV_POLICY_EXTERNAL) return ARMENV_OK;
+  return fail(ARMENV_ESTATE, "armenv_set_policy: fused policies are not available in this build");
+}
+
+int64_t armenv_num_envs(const ArmEnv *env) { return env ? env->cfg.num_envs : 0; }
+int32_t armenv_obs_dim(const ArmEnv *env) { return env ? (env->cfg.task == ARMENV_TASK_PUSH ? 9 : 6) : 0; }
+int32_t armenv_action_dim(const ArmEnv *) { return 3; }
+const char *armenv_kernel_name(const ArmEnv *env) { return env ? env->eng->name() : ""; }
+
+}  // extern "C"

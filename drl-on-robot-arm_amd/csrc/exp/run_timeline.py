@@ -1,0 +1,32 @@
+import sys, os, ctypes as C
+import numpy as np, torch
+ROOT=os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT,'..','..'))
+from armenv import _lib as L
+L.LIB_PATH=os.path.join(ROOT,'libarmenv_tl.so')
+from armenv import envs
+prec=int(sys.argv[1]) if len(sys.argv)>1 else 64
+n=65536
+e=envs.BatchedReachEnv(n, device='cuda:0', precision=prec)
+lib=L.load()
+tl=torch.zeros((n//64,8),dtype=torch.int64,device='cuda:0')
+lib.armenv_dbg_set_timeline.argtypes=[C.c_void_p]
+assert lib.armenv_dbg_set_timeline(C.c_void_p(tl.data_ptr()))==0
+g=torch.Generator(device='cuda:0'); g.manual_seed(0)
+acts=[(torch.randn((n,3),device='cuda:0',generator=g)*0.686).clamp_(-0.7,0.7) for _ in range(8)]
+e.reset()
+for k in range(30): e.step(acts[k%8])
+torch.cuda.synchronize()
+for k in range(3):
+    e.step(acts[k%8]); torch.cuda.synchronize()
+    t=tl.cpu().numpy().astype(np.int64)
+    t0=t[:,0].min()
+    st=(t[:,0]-t0)/100.0; ld=(t[:,1]-t[:,0])/100.0; lp=(t[:,2]-t[:,1])/100.0; fin=(t[:,3]-t[:,2])/100.0; end=(t[:,3]-t0)/100.0
+    print(f"step {k}: kernel span {end.max():.2f} us | start: mean {st.mean():.2f} max {st.max():.2f} | load: mean {ld.mean():.2f} max {ld.max():.2f} | loop: mean {lp.mean():.2f} min {lp.min():.2f} max {lp.max():.2f} | epilogue mean {fin.mean():.2f} max {fin.max():.2f}")
+    for tr in np.unique(t[:,4]):
+        m=t[:,4]==tr; print(f"   trips={tr}: waves {m.sum()} loop mean {lp[m].mean():.2f} us; end mean {end[m].mean():.2f}")
+    m=t[:,5]>0; print(f"   waves with done lanes: {m.sum()}, epilogue mean {fin[m].mean() if m.any() else 0:.2f} vs {fin[~m].mean():.2f}")
+    hw=t[:,7]; xcc=t[:,6]; cu=(hw>>8)&0xf; sh=(hw>>12)&1; se=(hw>>13)&0x7; simd=(hw>>4)&3
+    key=xcc*100000+se*1000+sh*100+cu
+    u,c=np.unique(key,return_counts=True); print("   distinct CUs used:",len(u)," waves/CU hist:",np.bincount(c))
+    key2=key*10+simd; u2,c2=np.unique(key2,return_counts=True); print("   distinct SIMDs:",len(u2)," waves/SIMD hist:",np.bincount(c2))
