@@ -6,8 +6,13 @@ configs[1]; N>1 = configs[4], envs sharded over GPUs, RCCL all-gather of episode
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step = one armenv_step call (one fused HIP kernel launch) advancing every env of the rank once with a
-pre-generated random-policy action batch already resident in HBM.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one batch of actions: every env of the rank advances once with a
+pre-generated random-policy action batch already resident in HBM.  Two launch shapes run the same per-step code:
+  --mode rollout (default, `value`): armenv_rollout, R steps per kernel launch, env state kept in registers,
+                 per-step outputs written to [R][N][...] buffers (bit-identical to R armenv_step calls);
+  --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
+                 beside the headline and reported under "step_api".
+Rank 0 prints ONE JSON line.
 The CPU oracle is timed beside it (rank 0, N=1 only) on a bounded sample -- as a baseline, never as
 the thing measured.
 """
@@ -28,8 +33,12 @@ import torch.distributed as dist
 
 ENVS_PER_GPU = 65536
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic bytes per env-step (DESIGN.md "Kernels"): state r/w + caller I/O of reach_step
-ALGO_BYTES = {64: 190, 32: 126}
+F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X f64 vector (FMA = 2 flop), 1/2 of the 157.3 TF f32 vector peak
+# algorithmic bytes: caller I/O per env-step, and state read+written once per launch
+IO_BYTES = 12 + 24 + 4 + 1 + 1                 # action in; obs, reward, done, success out
+STATE_BYTES = {64: 2 * (56 + 8) + 12 + 2 * 4, 32: 2 * (28 + 4) + 12 + 2 * 4}   # q, ep_return r+w; goal r; step r+w
+# algorithmic flops of the f64/f32 reach step: per IK update and per FK-only exit trip
+FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + residual + per-step sincos/reward
 
 
 def cpu_baseline(precision, seconds=12.0):
@@ -63,6 +72,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--gather-every", type=int, default=100, help="steps between episode-return all-gathers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
+    ap.add_argument("--rollout-steps", type=int, default=50, help="env steps fused per armenv_rollout launch")
     args = ap.parse_args()
 
     from armenv import envs
@@ -82,31 +93,51 @@ def main():
     ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous() for _ in range(16)]
     gather = ReturnGatherer(n, dev, world)
     env.reset()
+    R = max(1, min(args.rollout_steps, args.steps))
+    if args.mode == "rollout":
+        acts = torch.stack([ring[i % 16] for i in range(R)]).contiguous()      # [R, N, 3] resident in HBM
+        bufs = {}
 
-    def run(k, timed):
-        for i in range(k):
-            env.step(ring[i % 16])
-            if world > 1 and (i + 1) % args.gather_every == 0:
+    def run(k):
+        """exactly k env steps of every env of this rank"""
+        if args.mode == "step":
+            for i in range(k):
+                env.step(ring[i % 16])
+                if world > 1 and (i + 1) % args.gather_every == 0:
+                    gather.launch(env.episode_stats()[0])
+            return k
+        done_steps, launches = 0, 0
+        while done_steps < k:
+            r = min(R, k - done_steps)
+            env.rollout(r, acts if r == R else acts[:r].contiguous(), out=bufs if r == R else None)
+            done_steps += r; launches += 1
+            if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
                 gather.launch(env.episode_stats()[0])
+        return launches
 
-    run(args.warmup, False)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps, True)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        gather.result()
+    def timed(k):
         torch.cuda.synchronize(dev)
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0 = env.counters()
+        t0 = time.perf_counter()
+        ev0.record()
+        launches = run(k)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            gather.result()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        c1 = env.counters()
+        return wall, ev0.elapsed_time(ev1), launches, {k_: c1[k_] - c0[k_] for k_ in c1}
+
+    run(args.warmup)
+    wall, gpu_ms, launches, dc = timed(args.steps)
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
@@ -114,34 +145,55 @@ def main():
     wall_max = float(t.item())
     counters = env.counters()
 
+    step_api = None
+    if args.mode == "rollout" and world == 1:
+        args.mode = "step"                      # the gym-style one-launch-per-step path, timed beside the headline
+        k2 = min(args.steps, 500)
+        run(10)
+        w2, g2, _, _ = timed(k2)
+        step_api = {"value": n * k2 / w2, "unit": "env-steps/s", "steps": k2, "avg_launch_us": g2 * 1e3 / k2,
+                    "kernel": env.kernel_name}
+        args.mode = "rollout"
+
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / wall_max
-        launch_us = gpu_ms * 1e3 / args.steps            # HIP events on the launch stream, per launch
-        algo = ALGO_BYTES[args.precision] * n            # bytes one launch moves, algorithmically
+        launch_us = gpu_ms * 1e3 / launches              # HIP events on the launch stream, per kernel launch
+        steps_per_launch = args.steps / launches
+        kernel = env.kernel_name if args.mode == "step" else env.kernel_name.replace("reach_step", "reach_rollout")
+        algo = (IO_BYTES * steps_per_launch + STATE_BYTES[args.precision]) * n   # bytes one launch moves, algorithmically
         achieved = algo / (launch_us * 1e-6) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # filled from rocprofv3 --pmc passes (profiles/README.md)
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from separate rocprofv3 --pmc passes (profiles/README.md)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(env.kernel_name, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(kernel, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        updates = dc["ik_updates"] / max(1, dc["env_steps"])
+        flops = (updates * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n * steps_per_launch
         line = {
             "metric": "env-steps/sec at N parallel envs (rl_reach_env)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
-            "config": {"workload": "rl_reach_env %d parallel envs per GPU, random policy clip(N(0,0.686),+-0.7), "
-                                   "step() throughput only, KUKA iiwa chain, auto-reset on" % n,
-                       "envs_per_gpu": n, "total_envs": total_envs, "kernel": env.kernel_name,
+            "config": {"workload": "rl_reach_env %d parallel envs per GPU, random policy clip(N(0,0.686),+-0.7) pre-generated "
+                                   "in HBM, step() throughput only, KUKA iiwa chain, auto-reset on" % n,
+                       "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode,
+                       "steps_per_launch": steps_per_launch,
                        "parallelism": "env-sharded x%d, RCCL all-gather of episode returns every %d steps (logging only)"
                                       % (world, args.gather_every) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": env.kernel_name, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo},
+                         "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo},
+            # the path is VALU-bound, not HBM-bound: the same launch against the f64 vector peak
+            "roofline_valu": {"achieved": flops / (launch_us * 1e-6) / 1e12, "peak": F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3,
+                              "unit": "TFLOP/s", "ik_updates_per_env_step": updates,
+                              "frac": flops / (launch_us * 1e-6) / 1e12 / (F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3)},
             "episodes_finished": counters["episodes"], "nonfinite_states": counters["nonfinite"],
         }
+        if step_api:
+            line["step_api"] = step_api
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.precision)
         print(json.dumps(line), flush=True)

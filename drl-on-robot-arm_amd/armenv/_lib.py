@@ -52,12 +52,13 @@ SYMBOLS = {
     "armenv_reset": (C.c_int, [_P, _P, _P, _P]),
     "armenv_reset_with_goal": (C.c_int, [_P, _P, _P, _P, _P]),
     "armenv_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "armenv_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "armenv_fk": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P]),
     "armenv_ik": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "armenv_get_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "armenv_set_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "armenv_episode_stats": (C.c_int, [_P, _P, _P, _P, _P]),
-    "armenv_counters": (C.c_int, [_P, C.POINTER(C.c_uint64 * 4), _P]),
+    "armenv_counters": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8), _P]),
     "armenv_set_policy": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
     "armenv_num_envs": (C.c_int64, [_P]),
     "armenv_obs_dim": (C.c_int32, [_P]),

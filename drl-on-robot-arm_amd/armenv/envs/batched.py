@@ -119,6 +119,50 @@ class BatchedArmEnv:
     def terminal_obs(self):
         return self._terminal
 
+    def set_policy(self, kind="random", action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7, actor_state_dict=None):
+        """Install the fused exploration policy of main.py:116-117 for `rollout(actions=None)`:
+        a = clip(actor(obs) + N(0, noise_sigma), +-noise_clip).  kind: "external" | "random" | "actor"."""
+        code = {"external": L.POLICY_EXTERNAL, "random": L.POLICY_RANDOM, "actor": L.POLICY_ACTOR}[kind]
+        w = [None] * 6
+        hidden = 0
+        if code == L.POLICY_ACTOR:
+            keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+            w = [actor_state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in keys]
+            hidden = int(w[0].shape[0])
+        L.check(self._lib.armenv_set_policy(self._h, code, *[_ptr(t) for t in w], hidden, float(action_bound),
+                                            float(noise_sigma), float(noise_clip), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._policy = kind
+
+    def rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False):
+        """`steps` env steps of all envs in one kernel launch (the inner loop of main.py:108-128).
+        actions: float32 [steps, N, 3] on the device, or None to use the fused policy (set_policy).
+        Returns a dict of [steps, N, ...] tensors: obs, reward, done, success (+ actions, terminal_obs)."""
+        n, dev, T = self.num_envs, self.device, int(steps)
+        if actions is not None:
+            if actions.device != dev or actions.dtype != torch.float32 or tuple(actions.shape) != (T, n, 3) \
+                    or not actions.is_contiguous():
+                raise ValueError(f"actions must be a contiguous float32 tensor [{T}, {n}, 3] on {dev}")
+        if out is None:
+            out = {}
+        def buf(name, shape, dt):
+            t = out.get(name)
+            if t is None or tuple(t.shape) != shape:
+                t = torch.empty(shape, dtype=dt, device=dev)
+                out[name] = t
+            return t
+        obs = buf("obs", (T, n, self.obs_dim), torch.float32)
+        rew = buf("reward", (T, n), torch.float32)
+        done = buf("done_u8", (T, n), torch.uint8)
+        succ = buf("success_u8", (T, n), torch.uint8)
+        acts = buf("actions", (T, n, 3), torch.float32) if want_actions else None
+        term = buf("terminal_obs", (T, n, self.obs_dim), torch.float32) if want_terminal_obs else None
+        L.check(self._lib.armenv_rollout(self._h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(succ),
+                                         _ptr(acts), _ptr(term), self._stream()))
+        out["done"] = done.view(torch.bool)
+        out["success"] = succ.view(torch.bool)
+        return out
+
     # ------------------------------------------------------------------ engine calls the reference makes
     def fk(self, q):
         """p.getLinkState(body, 6)[4], [5]: q [n,7] f64 -> (pos [n,3], quat xyzw [n,4]) f64."""
@@ -178,9 +222,9 @@ class BatchedArmEnv:
         return ret, ln, su
 
     def counters(self):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         L.check(self._lib.armenv_counters(self._h, C.byref(out), self._stream()))
-        return dict(episodes=out[0], successes=out[1], env_steps=out[2], nonfinite=out[3])
+        return dict(episodes=out[0], successes=out[1], env_steps=out[2], nonfinite=out[3], ik_updates=out[4])
 
 
 class BatchedReachEnv(BatchedArmEnv):

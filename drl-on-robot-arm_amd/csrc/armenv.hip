@@ -93,7 +93,9 @@ __global__ void init_consts_kernel(EnvParams<T> P, T *out) {
   T q[NJ];
   static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = P.q_init[i]; });
   FKState<T> S;
-  fk<C, T>(P.chain, q, S);
+  T cq[NJ], sq[NJ];
+  sincos_all<T>(q, cq, sq);
+  fk<C, T>(P.chain, cq, sq, S);
   out[0] = S.p[0]; out[1] = S.p[1]; out[2] = S.p[2];
 }
 
@@ -119,71 +121,223 @@ __global__ __launch_bounds__(256) void reach_reset_kernel(EnvParams<T> P, const 
   if (obs) store_obs6<T>(obs, i, P.p_init, g);
 }
 
+// Optional per-wave timeline (make timeline; csrc/exp/run_timeline.py): wall-clock stamps at kernel entry, after
+// the state loads, after the IK loop and at exit, plus IK update count and placement.  Off in the product build.
+#ifdef ARMENV_TIMELINE
+__device__ unsigned long long *g_timeline;
+#define TL_STAMP(name) const unsigned long long name = wall_clock64()
+#else
+#define TL_STAMP(name)
+#endif
+
+// Fused exploration policy of the rollout loop (/root/reference/main.py:116-117):
+//   a = clip(actor(obs) + N(0, sigma), +-clip);  kind RANDOM = zero actor.
+struct PolicyParams {
+  int32_t kind;      // ARMENV_POLICY_*
+  float sigma;       // action_bound * opt.gamma = 0.686 in run()
+  float clip;        // action_bound = 0.7
+  float bound;       // actor output scale
+};
+
+// Three N(0,1) draws for (env, episode, step): Philox block 0x80000000|step of the env's stream (reset draws use
+// blocks < 2^31), Box-Muller in f32 on u = (w + 1) * 2^-32 in (0, 1].
+AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step, float (&nz)[3]) {
+  uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), episode, 0x80000000u | step};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)c[0] + 1.0f) * k, u1 = (float)c[1] * k, u2 = ((float)c[2] + 1.0f) * k, u3 = (float)c[3] * k;
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  nz[0] = r0 * c0; nz[1] = r0 * s0; nz[2] = r1 * c1;
+  (void)s1;
+}
+
+// Per-lane state of one reach env and the body of one env step.  The single-step kernel and the T-step rollout
+// kernel both run this code, so a rollout is bit-identical to T step launches.
+template <class C, typename T> struct ReachLane {
+  using M = Mth<T>;
+  T q[NJ];
+  float g[3];
+  int32_t step;
+  T ep_ret;
+  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;   // flushed to the handle's counters once per launch
+
+  AE_DEV void load(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * n + i]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; g[k] = P.goal[(int64_t)k * n + i]; });
+    step = P.step[i];
+    ep_ret = P.ep_return[i];
+  }
+
+  AE_DEV void store(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
+    P.step[i] = step;
+    P.ep_return[i] = ep_ret;
+    if (n_done) atomicAdd(&P.counters[0], (unsigned long long)n_done);
+    if (n_succ) atomicAdd(&P.counters[1], (unsigned long long)n_succ);
+    if (n_bad) atomicAdd(&P.counters[3], (unsigned long long)n_bad);
+    // one add per wave for the IK-update total (wave reduction first)
+    if (__ballot(1) == ~0ull) {
+      unsigned u = n_upd;
+      for (int o = 32; o; o >>= 1) u += __shfl_xor(u, o);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[4], (unsigned long long)u);
+    } else if (n_upd) {   // ragged last wave
+      atomicAdd(&P.counters[4], (unsigned long long)n_upd);
+    }
+  }
+
+  // RLReachEnv.step + _reward (rl_reach_env.py:219-319) with action a; writes row i of the caller's buffers.
+  // Returns the number of IK updates.
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io) {
+    const int64_t n = P.n;
+    FKState<T> S;
+    T tgt[3];
+    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
+
+    n_upd += (uint32_t)updates;
+    step += 1;                                                                    // :264
+    const T dx = S.p[0] - (T)g[0], dy = S.p[1] - (T)g[1], dz = S.p[2] - (T)g[2];
+    const T dist = M::sqrt(M::fma(dx, dx, M::fma(dy, dy, dz * dz)));              // :281
+    T reward;
+    bool done, succ;
+    if (step > P.max_steps) { reward = -dist * T(10); done = true; succ = false; }          // :299-301
+    else if (dist < P.reach_dis) { reward = T(0); done = true; succ = true; }               // :303-306
+    else { reward = -dist * T(10); done = false; succ = false; }                            // :307-309
+    ep_ret += reward;
+
+    bool finite = true;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
+    if (!finite) n_bad += 1;
+
+    io.reward[i] = (float)reward;
+    io.done[i] = done ? 1 : 0;
+    io.success[i] = succ ? 1 : 0;
+    if (io.terminal_obs) store_obs6<T>(io.terminal_obs, i, S.p, g);
+
+    if (done) {
+      P.last_return[i] = ep_ret;
+      P.last_len[i] = step;
+      P.last_success[i] = succ ? 1 : 0;
+      n_done += 1;
+      if (succ) n_succ += 1;
+    }
+    if (done && P.auto_reset) {
+      const uint32_t ep = P.episode[i];
+      sample_goal(P, i, ep, g);
+      P.episode[i] = ep + 1u;
+      static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
+      step = 0;
+      ep_ret = T(0);
+      store_obs6<T>(io.obs, i, P.p_init, g);
+      cur_obs[0] = (float)P.p_init[0]; cur_obs[1] = (float)P.p_init[1]; cur_obs[2] = (float)P.p_init[2];
+    } else {
+      store_obs6<T>(io.obs, i, S.p, g);                                           // :319
+      cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    }
+    return updates;
+  }
+
+  float cur_obs[3];   // eef part of the observation the policy sees next (goal part is g)
+};
+
 // RLReachEnv.step + _reward (rl_reach_env.py:219-319), one env per lane, fused:
 // load state -> FK -> target = clip(p + dv a) -> DLS IK loop -> FK -> distance / reward / done ->
 // obs pack -> episode accounting -> optional in-place reset -> store state.
 template <class C, typename T>
 __global__ __launch_bounds__(256) void reach_step_kernel(EnvParams<T> P, StepIO io) {
-  using M = Mth<T>;
+  TL_STAMP(tl0);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  ReachLane<C, T> L;
+  L.load(P, i);
+  T a[3];
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; a[k] = (T)io.action[3 * i + k]; });
+#ifdef ARMENV_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  TL_STAMP(tl1);
+  const int updates = L.env_step(P, i, a, io);
+  (void)updates;
+  TL_STAMP(tl2);
+  L.store(P, i);
+  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)P.n);
+#ifdef ARMENV_TIMELINE
+  {
+    TL_STAMP(tl3);
+    int mx = updates;
+    for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    const unsigned long long dn = __ballot(L.n_done != 0);
+    if ((threadIdx.x & 63) == 0 && g_timeline) {
+      unsigned long long *r = g_timeline + 8 * (i >> 6);
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      r[0] = tl0; r[1] = tl1; r[2] = tl2; r[3] = tl3; r[4] = mx; r[5] = __popcll(dn); r[6] = xcc; r[7] = hw;
+    }
+  }
+#endif
+}
+
+// The rollout inner loop of /root/reference/main.py:108-128 for `steps` consecutive env steps in ONE launch: the env
+// state stays in registers, every step's outputs go to row t of [steps][N][...] buffers, and the action of step t
+// is either read from actions[t] (external policy, identical to `steps` calls of reach_step_kernel) or produced
+// in-kernel by the fused exploration policy.  Because lanes never synchronise, a lane that needs extra IK updates
+// in one step does not hold the other envs back for the rest of the launch: per-step cost approaches the MEAN
+// update count instead of the per-launch MAX.
+template <class C, typename T>
+__global__ __launch_bounds__(256) void reach_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
+                                                            const float *actions, StepIO io0, float *actions_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const int64_t n = P.n;
-
-  T q[NJ];
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * n + i]; });
-  float g[3];
-  static_for<0, 3>([&](auto KI) { constexpr int k = KI; g[k] = P.goal[(int64_t)k * n + i]; });
-  int32_t step = P.step[i];
-  T ep_ret = P.ep_return[i];
-  T a[3];
-  static_for<0, 3>([&](auto KI) { constexpr int k = KI; a[k] = (T)io.action[3 * i + k]; });
-
-  FKState<T> S;
-  T tgt[3];
-  ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
-
-  step += 1;                                                                    // :264
-  const T dx = S.p[0] - (T)g[0], dy = S.p[1] - (T)g[1], dz = S.p[2] - (T)g[2];
-  const T dist = M::sqrt(dx * dx + dy * dy + dz * dz);                          // :281
-  T reward;
-  bool done, succ;
-  if (step > P.max_steps) { reward = -dist * T(10); done = true; succ = false; }          // :299-301
-  else if (dist < P.reach_dis) { reward = T(0); done = true; succ = true; }               // :303-306
-  else { reward = -dist * T(10); done = false; succ = false; }                            // :307-309
-  ep_ret += reward;
-
-  bool finite = true;
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
-  if (!finite) atomicAdd(&P.counters[3], 1ull);
-
-  io.reward[i] = (float)reward;
-  io.done[i] = done ? 1 : 0;
-  io.success[i] = succ ? 1 : 0;
-  if (io.terminal_obs) store_obs6<T>(io.terminal_obs, i, S.p, g);
-
-  if (done) {
-    P.last_return[i] = ep_ret;
-    P.last_len[i] = step;
-    P.last_success[i] = succ ? 1 : 0;
-    atomicAdd(&P.counters[0], 1ull);
-    if (succ) atomicAdd(&P.counters[1], 1ull);
+  ReachLane<C, T> L;
+  L.load(P, i);
+  uint32_t episode = (pol.kind != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
+  float an[3] = {0.f, 0.f, 0.f};
+  if (actions) { an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2]; }
+  for (int32_t t = 0; t < steps; ++t) {
+    T a[3];
+    if (actions) {
+      a[0] = (T)an[0]; a[1] = (T)an[1]; a[2] = (T)an[2];
+      if (t + 1 < steps) {   // prefetch the next step's action; its latency hides under this step's IK
+        const float *nx = actions + ((int64_t)(t + 1) * n + i) * 3;
+        an[0] = nx[0]; an[1] = nx[1]; an[2] = nx[2];
+      }
+    } else {
+      float nz[3];
+      // the episode index of the stream is the number of resets so far minus one (the running episode)
+      policy_noise(P.seed, P.env_id0 + (uint64_t)i, episode - 1u, (uint32_t)L.step, nz);
+      static_for<0, 3>([&](auto KI) {
+        constexpr int k = KI;
+        float v = nz[k] * pol.sigma;          // zero actor + N(0, sigma)
+        v = fminf(fmaxf(v, -pol.clip), pol.clip);
+        a[k] = (T)v;
+        an[k] = v;
+      });
+    }
+    StepIO io;
+    io.action = nullptr;
+    io.obs = io0.obs + (int64_t)t * n * 6;
+    io.reward = io0.reward + (int64_t)t * n;
+    io.done = io0.done + (int64_t)t * n;
+    io.success = io0.success + (int64_t)t * n;
+    io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * 6 : nullptr;
+    if (actions_out) {
+      float *ao = actions_out + ((int64_t)t * n + i) * 3;
+      if (actions) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
+      else { ao[0] = an[0]; ao[1] = an[1]; ao[2] = an[2]; }
+    }
+    const uint32_t before = L.n_done;
+    L.env_step(P, i, a, io);
+    if (L.n_done != before && P.auto_reset) episode += 1u;
   }
-  if (done && P.auto_reset) {
-    const uint32_t ep = P.episode[i];
-    sample_goal(P, i, ep, g);
-    P.episode[i] = ep + 1u;
-    static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
-    step = 0;
-    ep_ret = T(0);
-    store_obs6<T>(io.obs, i, P.p_init, g);
-  } else {
-    store_obs6<T>(io.obs, i, S.p, g);                                           // :319
-  }
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
-  P.step[i] = step;
-  P.ep_return[i] = ep_ret;
-  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)n);
+  L.store(P, i);
+  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)n * (unsigned long long)steps);
 }
 
 // p.getLinkState(body, 6)[4], [5]
@@ -194,7 +348,9 @@ __global__ __launch_bounds__(256) void fk_kernel(EnvParams<T> P, int64_t n, cons
   T q[NJ];
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = (T)q_in[7 * i + j]; });
   FKState<T> S;
-  fk<C, T>(P.chain, q, S);
+  T cq[NJ], sq[NJ];
+  sincos_all<T>(q, cq, sq);
+  fk<C, T>(P.chain, cq, sq, S);
   static_for<0, 3>([&](auto KI) { constexpr int k = KI; pos[3 * i + k] = (double)S.p[k]; });
   if (quat) {
     T qc[4];
@@ -319,13 +475,15 @@ struct EngineBase {
   virtual int init(const ArmEnvConfig &cfg) = 0;
   virtual int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) = 0;
   virtual int step(const StepIO &io, hipStream_t s) = 0;
+  virtual int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) = 0;
+  PolicyParams pol{ARMENV_POLICY_EXTERNAL, 0.f, 0.f, 0.f};
   virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
   virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
   virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, hipStream_t s) = 0;
   virtual int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
                         const double *ep_return, hipStream_t s) = 0;
   virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
-  virtual int counters(uint64_t out[4], hipStream_t s) = 0;
+  virtual int counters(uint64_t out[8], hipStream_t s) = 0;
   virtual const char *name() const = 0;
 };
 
@@ -349,7 +507,7 @@ template <class C, typename T> struct Engine final : EngineBase {
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
-    const size_t o_ls = take(n), o_cnt = take(8 * 4), o_tmp = take(sizeof(T) * 4);
+    const size_t o_ls = take(n), o_cnt = take(8 * 8), o_tmp = take(sizeof(T) * 4);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
     char *b = static_cast<char *>(pool);
@@ -422,6 +580,12 @@ template <class C, typename T> struct Engine final : EngineBase {
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
+  int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {
+    hipLaunchKernelGGL((reach_rollout_kernel<C, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps, actions,
+                       io0, actions_out);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
   int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) override {
     hipLaunchKernelGGL((fk_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, pos, quat);
     HIP_TRY(hipGetLastError());
@@ -451,8 +615,8 @@ template <class C, typename T> struct Engine final : EngineBase {
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
-  int counters(uint64_t out[4], hipStream_t s) override {
-    HIP_TRY(hipMemcpyAsync(out, P.counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  int counters(uint64_t out[8], hipStream_t s) override {
+    HIP_TRY(hipMemcpyAsync(out, P.counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return ARMENV_OK;
   }
@@ -483,6 +647,12 @@ static void fill_chain(ArmEnvChain *out, const double (*xyz)[3], const double (*
 }
 
 extern "C" {
+
+#ifdef ARMENV_TIMELINE
+int armenv_dbg_set_timeline(unsigned long long *buf_dev) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf_dev, sizeof buf_dev);
+}
+#endif
 
 int32_t armenv_abi_version(void) { return ARMENV_ABI_VERSION; }
 const char *armenv_last_error(void) { return g_err.c_str(); }
@@ -634,17 +804,36 @@ int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len
   return env->eng->episode_stats(last_return_dev, last_len_dev, last_success_dev, static_cast<hipStream_t>(stream));
 }
 
-int armenv_counters(ArmEnv *env, uint64_t out[4], void *stream) {
+int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream) {
   ENV_ENTER(env);
   if (!out) return fail(ARMENV_EINVAL, "armenv_counters: out is NULL");
   return env->eng->counters(out, static_cast<hipStream_t>(stream));
 }
 
 int armenv_set_policy(ArmEnv *env, int32_t policy, const float *, const float *, const float *, const float *,
-                      const float *, const float *, int32_t, float, float, float, void *) {
+                      const float *, const float *, int32_t, float action_bound, float noise_sigma, float noise_clip,
+                      void *) {
   ENV_ENTER(env);
-  if (policy == ARMENV_POLICY_EXTERNAL) return ARMENV_OK;
-  return fail(ARMENV_ESTATE, "armenv_set_policy: fused policies are not available in this build");
+  if (policy == ARMENV_POLICY_EXTERNAL || policy == ARMENV_POLICY_RANDOM) {
+    if (policy == ARMENV_POLICY_RANDOM && !(noise_sigma >= 0.f && noise_clip > 0.f))
+      return fail(ARMENV_EINVAL, "armenv_set_policy: need noise_sigma >= 0 and noise_clip > 0");
+    env->eng->pol = PolicyParams{policy, noise_sigma, noise_clip, action_bound};
+    return ARMENV_OK;
+  }
+  return fail(ARMENV_ESTATE, "armenv_set_policy: the fused actor is not available in this build");
+}
+
+int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,
+                   uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev, void *stream) {
+  ENV_ENTER(env);
+  if (steps < 0) return fail(ARMENV_EINVAL, "armenv_rollout: steps < 0");
+  if (steps == 0) return ARMENV_OK;
+  if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_rollout: NULL output buffer");
+  if (!actions_dev && env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
+    return fail(ARMENV_ESTATE, "armenv_rollout: actions_dev is NULL and no fused policy is installed");
+  if (steps == 0) return ARMENV_OK;
+  StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev};
+  return env->eng->rollout(steps, actions_dev, io, actions_out_dev, static_cast<hipStream_t>(stream));
 }
 
 int64_t armenv_num_envs(const ArmEnv *env) { return env ? env->cfg.num_envs : 0; }

@@ -51,7 +51,7 @@ template <typename T> struct FKState {
 // the joint rotation is a 2x2 rotation of two columns: 15 VALU ops + one sincos per joint.
 // Generic chains take the full 3x3 products.
 template <class C, typename T>
-AE_DEV void fk(const ChainDev<T> &ch, const T (&q)[NJ], FKState<T> &S) {
+AE_DEV void fk(const ChainDev<T> &ch, const T (&cq)[NJ], const T (&sq)[NJ], FKState<T> &S) {
   using M = Mth<T>;
   if constexpr (C::kGeneric) {
     static_for<0, 9>([&](auto I) { constexpr int i = I; S.W[3 * (i % 3) + (i / 3)] = ch.base_R[i]; });
@@ -91,8 +91,7 @@ AE_DEV void fk(const ChainDev<T> &ch, const T (&q)[NJ], FKState<T> &S) {
         static_for<0, 3>([&](auto RI) { constexpr int r = RI; A[3 * c + r] = (s > 0) ? S.W[3 * k + r] : -S.W[3 * k + r]; });
       });
     }
-    T sn, cs;
-    M::sincos(q[j], sn, cs);
+    const T sn = sq[j], cs = cq[j];
     static_for<0, 3>([&](auto RI) {
       constexpr int r = RI;
       S.W[0 + r] = M::fma(cs, A[0 + r], sn * A[3 + r]);
@@ -104,42 +103,70 @@ AE_DEV void fk(const ChainDev<T> &ch, const T (&q)[NJ], FKState<T> &S) {
   });
 }
 
+template <typename T>
+AE_DEV void sincos_all(const T (&q)[NJ], T (&cq)[NJ], T (&sq)[NJ]) {
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; Mth<T>::sincos(q[j], sq[j], cq[j]); });
+}
+
+// (c,s) <- (cos(q+d), sin(q+d)) from (cos q, sin q) for |d| <= pi/4 (the DLS scale-back bounds every update by
+// max_dtheta), with the fdlibm __kernel_sin/__kernel_cos minimax polynomials (< 1 ulp on that interval): no
+// range reduction, ~22 VALU ops instead of a full sincos per joint per IK trip.
+template <typename T>
+AE_DEV void rotate_small(T &c, T &s, T d) {
+  using M = Mth<T>;
+  const T z = d * d;
+  T ps = T(1.58969099521155010221e-10);
+  ps = M::fma(ps, z, T(-2.50507602534068634195e-08));
+  ps = M::fma(ps, z, T(2.75573137070700676789e-06));
+  ps = M::fma(ps, z, T(-1.98412698298579493134e-04));
+  ps = M::fma(ps, z, T(8.33333333332248946124e-03));
+  ps = M::fma(ps, z, T(-1.66666666666666324348e-01));
+  const T sd = M::fma(d * z, ps, d);
+  T pc = T(-1.13596475577881948265e-11);
+  pc = M::fma(pc, z, T(2.08757232129817482790e-09));
+  pc = M::fma(pc, z, T(-2.75573143513906633035e-07));
+  pc = M::fma(pc, z, T(2.48015872894767294178e-05));
+  pc = M::fma(pc, z, T(-1.38888888888741095749e-03));
+  pc = M::fma(pc, z, T(4.16666666666666019037e-02));
+  const T cd = M::fma(z * z, pc, M::fma(T(-0.5), z, T(1)));
+  const T cn = M::fma(c, cd, -(s * sd));
+  const T sn = M::fma(s, cd, c * sd);
+  c = cn;
+  s = sn;
+}
+
+// reciprocal: v_rcp + two Newton steps (f64) / one (f32); used where a few-ulp quotient is enough (LDL^T pivots)
+template <typename T>
+AE_DEV T fast_rcp(T d) {
+  T r = __builtin_amdgcn_rcp(d);
+  r = Mth<T>::fma(Mth<T>::fma(-d, r, T(1)), r, r);
+  if constexpr (sizeof(T) == 8) r = Mth<T>::fma(Mth<T>::fma(-d, r, T(1)), r, r);
+  return r;
+}
+
 // btMatrix3x3::getRotation (Bullet src/LinearMath/btMatrix3x3.h): rotation matrix -> quaternion xyzw.
 // m(r,c) = W[3*c + r].
 template <typename T>
 AE_DEV void quat_from_frame(const T (&W)[9], T (&q)[4]) {
   using M = Mth<T>;
   const T m00 = W[0], m10 = W[1], m20 = W[2], m01 = W[3], m11 = W[4], m21 = W[5], m02 = W[6], m12 = W[7], m22 = W[8];
+  // Same case selection as getRotation (trace > 0, else the largest diagonal element), evaluated with selects
+  // so that a wave whose lanes disagree on the case pays one sqrt and one divide, not four branches.
   const T trace = m00 + m11 + m22;
-  if (trace > T(0)) {
-    T s = M::sqrt(trace + T(1));
-    q[3] = s * T(0.5);
-    s = T(0.5) / s;
-    q[0] = (m21 - m12) * s;
-    q[1] = (m02 - m20) * s;
-    q[2] = (m10 - m01) * s;
-  } else if (m00 < m11 ? (m11 < m22) : (m00 < m22)) {  // i = 2, j = 0, k = 1
-    T s = M::sqrt(m22 - m00 - m11 + T(1));
-    q[2] = s * T(0.5);
-    s = T(0.5) / s;
-    q[3] = (m10 - m01) * s;
-    q[0] = (m02 + m20) * s;
-    q[1] = (m12 + m21) * s;
-  } else if (m00 < m11) {  // i = 1, j = 2, k = 0
-    T s = M::sqrt(m11 - m22 - m00 + T(1));
-    q[1] = s * T(0.5);
-    s = T(0.5) / s;
-    q[3] = (m02 - m20) * s;
-    q[2] = (m21 + m12) * s;
-    q[0] = (m01 + m10) * s;
-  } else {  // i = 0, j = 1, k = 2
-    T s = M::sqrt(m00 - m11 - m22 + T(1));
-    q[0] = s * T(0.5);
-    s = T(0.5) / s;
-    q[3] = (m21 - m12) * s;
-    q[1] = (m10 + m01) * s;
-    q[2] = (m20 + m02) * s;
-  }
+  const bool cw = trace > T(0);
+  const bool cz = !cw && (m00 < m11 ? (m11 < m22) : (m00 < m22));
+  const bool cy = !cw && !cz && (m00 < m11);
+  // cx otherwise
+  const T t = cw ? (trace + T(1)) : cz ? (m22 - m00 - m11 + T(1)) : cy ? (m11 - m22 - m00 + T(1)) : (m00 - m11 - m22 + T(1));
+  const T r = M::sqrt(t);
+  const T big = r * T(0.5);
+  const T h = T(0.5) / r;
+  const T d21 = m21 - m12, d02 = m02 - m20, d10 = m10 - m01;
+  const T s10 = m10 + m01, s20 = m20 + m02, s21 = m21 + m12;
+  q[0] = cw ? d21 * h : cz ? s20 * h : cy ? s10 * h : big;
+  q[1] = cw ? d02 * h : cz ? s21 * h : cy ? big : s10 * h;
+  q[2] = cw ? d10 * h : cz ? big : cy ? s21 * h : s20 * h;
+  q[3] = cw ? big : cz ? d10 * h : cy ? d02 * h : d21 * h;
 }
 
 // IKTrajectoryHelper::computeIK orientation part: deltaQ = endQ * startQ^-1, angle = 2 acos(w) wrapped to
@@ -149,15 +176,17 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
   using M = Mth<T>;
   const T bx = -qc[0], by = -qc[1], bz = -qc[2], bw = qc[3];
   const T ax = tq[0], ay = tq[1], az = tq[2], aw = tq[3];
-  const T dx = aw * bx + ax * bw + ay * bz - az * by;
-  const T dy = aw * by + ay * bw + az * bx - ax * bz;
-  const T dz = aw * bz + az * bw + ax * by - ay * bx;
-  const T dw = aw * bw - ax * bx - ay * by - az * bz;
+  // explicit fma chains: the build uses -ffp-contract=off so that every kernel that inlines this code (step,
+  // rollout, ik) rounds identically
+  const T dx = M::fma(aw, bx, M::fma(ax, bw, M::fma(ay, bz, -(az * by))));
+  const T dy = M::fma(aw, by, M::fma(ay, bw, M::fma(az, bx, -(ax * bz))));
+  const T dz = M::fma(aw, bz, M::fma(az, bw, M::fma(ax, by, -(ay * bx))));
+  const T dw = M::fma(aw, bw, -M::fma(ax, bx, M::fma(ay, by, az * bz)));
   if constexpr (sizeof(T) == 4) {
     // f32: 2*acos(w) is useless near convergence (w = 1 - k*6e-8 quantises the angle to ~7e-4*sqrt(k) rad),
     // so the f32 engine uses the well-conditioned equivalent angle = 2*atan2(|v|, |w|) on the short arc.
     const T sg = dw < T(0) ? T(-1) : T(1);
-    const T n = M::sqrt(dx * dx + dy * dy + dz * dz);
+    const T n = M::sqrt(M::fma(dx, dx, M::fma(dy, dy, dz * dz)));
     const T ang = T(2) * ::atan2f(n, sg * dw);
     const T k = n > T(1e-30) ? sg * ang / n : T(0);
     e[0] = k * dx; e[1] = k * dy; e[2] = k * dz;
@@ -165,7 +194,7 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
   }
   const T wc = dw < T(-1) ? T(-1) : (dw > T(1) ? T(1) : dw);
   T angle = T(2) * M::acos(wc);
-  const T s2 = T(1) - dw * dw;
+  const T s2 = M::fma(-dw, dw, T(1));
   T a0, a1, a2;
   if (s2 < T(10) * M::eps) {
     a0 = T(1); a1 = T(0); a2 = T(0);
@@ -176,10 +205,10 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
   if (angle_f32) angle = (T)(float)angle;
   if (angle > M::pi) angle -= T(2) * M::pi;
   if (angle_f32) angle = (T)(float)angle;
-  const T n = M::sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-  e[0] = angle * (a0 / n);
-  e[1] = angle * (a1 / n);
-  e[2] = angle * (a2 / n);
+  const T rn = T(1) / M::sqrt(M::fma(a0, a0, M::fma(a1, a1, a2 * a2)));   // btVector3::normalize: *= 1/length
+  e[0] = angle * (a0 * rn);
+  e[1] = angle * (a1 * rn);
+  e[2] = angle * (a2 * rn);
 }
 
 // One damped-least-squares update in the dual 6x6 form  dtheta = J^T (J J^T + lambda I)^-1 e,
@@ -192,9 +221,9 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
   static_for<0, NJ>([&](auto II) {
     constexpr int i = II;
     const T r0 = S.p[0] - S.pj[i][0], r1 = S.p[1] - S.pj[i][1], r2 = S.p[2] - S.pj[i][2];
-    Jl[i][0] = S.z[i][1] * r2 - S.z[i][2] * r1;
-    Jl[i][1] = S.z[i][2] * r0 - S.z[i][0] * r2;
-    Jl[i][2] = S.z[i][0] * r1 - S.z[i][1] * r0;
+    Jl[i][0] = M::fma(S.z[i][1], r2, -(S.z[i][2] * r1));
+    Jl[i][1] = M::fma(S.z[i][2], r0, -(S.z[i][0] * r2));
+    Jl[i][2] = M::fma(S.z[i][0], r1, -(S.z[i][1] * r0));
   });
   // A = J J^T + lambda I, lower triangle, A[r][c] with row r of J = (r<3 ? Jl[.][r] : z[.][r-3])
   T A[6][6];
@@ -224,7 +253,7 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
       d = M::fma(-L[j][k], v[k], d);
     });
     D[j] = d;
-    invD[j] = T(1) / d;
+    invD[j] = fast_rcp<T>(d);
     static_for<j + 1, 6>([&](auto II) {
       constexpr int i = II;
       T s = A[i][j];
@@ -281,8 +310,13 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
   using M = Mth<T>;
   T diff_prev = T(1e30);
   int it = 0;
+  T cq[NJ], sq[NJ];
+  sincos_all<T>(q, cq, sq);
+  // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced
+  // incrementally, otherwise cos/sin are recomputed from q
+  const bool small_steps = P.max_dtheta <= T(0.7854);
   for (;; ++it) {
-    fk<C, T>(ch, q, S);
+    fk<C, T>(ch, cq, sq, S);
     if constexpr (FROM_ACTION) {
       if (it == 0) {
         static_for<0, 3>([&](auto KI) {
@@ -298,7 +332,7 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     e[0] = tgt[0] - S.p[0];
     e[1] = tgt[1] - S.p[1];
     e[2] = tgt[2] - S.p[2];
-    const T diff = M::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    const T diff = M::sqrt(M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2])));
     const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff_prev > P.residual) : !(diff > P.residual));
     if (stop) break;
     T qc[4], eo[3], dth[NJ];
@@ -307,6 +341,11 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
     dls_update<T>(S, e, P, dth);
     static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
+    if (small_steps) {
+      static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
+    } else {
+      sincos_all<T>(q, cq, sq);
+    }
     diff_prev = diff;
   }
   if (P.clamp_limits) {
@@ -314,7 +353,8 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
       constexpr int i = II;
       q[i] = q[i] < P.lim_lo[i] ? P.lim_lo[i] : (q[i] > P.lim_hi[i] ? P.lim_hi[i] : q[i]);
     });
-    fk<C, T>(ch, q, S);
+    sincos_all<T>(q, cq, sq);
+    fk<C, T>(ch, cq, sq, S);
   }
   return it;
 }

@@ -142,6 +142,18 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                 uint8_t *success_dev, float *terminal_obs_dev, void *stream);
 
+/* Replaces the rollout inner loop of /root/reference/main.py:108-128 (take_action -> noise -> step -> store) for
+ * `steps` consecutive env steps of all N envs in ONE kernel launch; the env state stays in registers between steps.
+ *   actions_dev  f32 [steps][N][3]: external policy -- results are bit-identical to `steps` armenv_step calls.
+ *                NULL: the fused policy installed with armenv_set_policy produces the actions in-kernel.
+ *   obs_dev f32 [steps][N][obs_dim], reward_dev f32 [steps][N], done_dev / success_dev u8 [steps][N]: row t holds
+ *   what armenv_step would have returned at step t.  actions_out_dev (nullable, f32 [steps][N][3]) receives the
+ *   actions taken; terminal_obs_dev (nullable) as in armenv_step, per step.
+ * Lanes never synchronise inside the launch, so an env that needs extra IK iterations in one step does not stall
+ * the others: throughput follows the mean IK cost per step, not the per-launch maximum. */
+int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,
+                   uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev, void *stream);
+
 /* Replaces p.getLinkState(body, 6)[4], [5] (call sites rl_reach_env.py:202,237,271): world position
  * f64 [n][3] and orientation quaternion xyzw f64 [n][4] (nullable) of the link-7 frame for joint
  * vectors q f64 [n][7].  Uses the handle's chain; n is independent of num_envs. */
@@ -168,15 +180,17 @@ int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, co
 int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len_dev, uint8_t *last_success_dev,
                          void *stream);
 
-/* Totals since creation, copied to host (synchronises `stream`): out[0] episodes finished,
- * out[1] successes, out[2] env-steps executed, out[3] non-finite joint states seen. */
-int armenv_counters(ArmEnv *env, uint64_t out[4], void *stream);
+/* Totals since creation, copied to host (synchronises `stream`): out[0] episodes finished, out[1] successes,
+ * out[2] env-steps executed, out[3] non-finite joint states seen, out[4] IK (DLS) updates applied, out[5..7] 0. */
+int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream);
 
 /* Installs the TD3 actor (PolicyNet, /root/reference/algo/TD3/net_mlp.py:29-40; take_action
  * algo/TD3/TD3_mlp.py:82-97) for fused stepping: a = action_bound * tanh(W3 relu(W2 relu(W1 s + b1) + b2) + b3),
  * then the rollout loop's exploration a = clip(a + N(0, noise_sigma), +-noise_clip) (main.py:116-117).
  * Weights are DEVICE pointers in torch Linear layout ([out][in], f32) and are copied.
- * policy = ARMENV_POLICY_RANDOM ignores the weights (zero actor, noise only). */
+ * policy = ARMENV_POLICY_RANDOM ignores the weights (zero actor, noise only); ARMENV_POLICY_EXTERNAL removes the
+ * fused policy.  The noise of (env, episode, step) is Philox block 0x80000000|step of that env's stream, Box-Muller
+ * in f32, so it does not depend on launch geometry, sharding or how steps are grouped into rollouts. */
 int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const float *b1_dev, const float *W2_dev,
                       const float *b2_dev, const float *W3_dev, const float *b3_dev, int32_t hidden_dim,
                       float action_bound, float noise_sigma, float noise_clip, void *stream);

@@ -288,3 +288,22 @@ def reach_outcome(cfg, dist, step_counter):
     r = C.c_double(); d = C.c_uint8(); s = C.c_uint8()
     lib().orc_reach_outcome(C.byref(cfg), C.c_double(dist), C.c_int32(step_counter), C.byref(r), C.byref(d), C.byref(s))
     return r.value, bool(d.value), bool(s.value)
+
+
+def random_policy_actions(st, seed=0, env_id0=0, sigma=0.7 * 0.98, clip=0.7):
+    a = np.zeros((st.n, 3), dtype=np.float32)
+    lib().orc_random_policy_actions(C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(st.n), _p(st.episode), _p(st.step),
+                                    C.c_float(sigma), C.c_float(clip), _p(a))
+    return a
+
+
+def reach_rollout(chain, cfg, st, steps, actions=None, seed=0, env_id0=0, sigma=0.7 * 0.98, clip=0.7):
+    """`steps` auto-reset steps; actions [steps,N,3] or None for the fused random policy.  Returns dict of
+    [steps, N, ...] arrays like the engine's rollout."""
+    out = dict(obs=[], reward=[], done=[], success=[], actions=[], terminal_obs=[])
+    for t in range(steps):
+        a = actions[t] if actions is not None else random_policy_actions(st, seed, env_id0, sigma, clip)
+        o, r, d, s, term = reach_step_autoreset(chain, cfg, st, a, seed=seed, env_id0=env_id0)
+        for k, v in zip(("obs", "reward", "done", "success", "actions", "terminal_obs"), (o, r, d, s, a, term)):
+            out[k].append(np.array(v, copy=True))
+    return {k: np.stack(v) for k, v in out.items()}

@@ -449,3 +449,73 @@ def test_rlreachenv_compat_surface(envs, O, kuka):
             assert np.array_equal(state[-3:], np.float32(ep["goal"]))
     assert env.seed(3) == [3]
     env.close()
+
+
+# ------------------------------------------------------------------------------ rollout engine (C1)
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_rollout_external_actions_equals_step_calls_bitwise(envs, precision):
+    """armenv_rollout with external actions is the same arithmetic as T armenv_step launches."""
+    n, T = 4096 + 64 + 3, 37
+    rng = np.random.default_rng(60)
+    acts = torch.from_numpy(np.stack([_actions(rng, n) for _ in range(T)])).to(DEV)
+    a = _mk(envs, n, seed=9, precision=precision, max_steps=20)       # short episodes: resets inside the rollout
+    b = _mk(envs, n, seed=9, precision=precision, max_steps=20)
+    a.reset(); b.reset()
+    out = a.rollout(T, acts, want_actions=True, want_terminal_obs=True)
+    for t in range(T):
+        o, r, d, s = b.step(acts[t], want_terminal_obs=True)
+        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r), t
+        assert torch.equal(out["done"][t], d) and torch.equal(out["success"][t], s), t
+        assert torch.equal(out["terminal_obs"][t], b.terminal_obs), t
+    assert torch.equal(out["actions"], acts)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert a.counters() == b.counters()
+    assert a.counters()["episodes"] >= n
+    a.close(); b.close()
+
+
+def test_rollout_random_policy_matches_oracle(envs, O, kuka):
+    """Fused random policy (zero actor + clipped Gaussian noise, main.py:116-117) inside the rollout kernel."""
+    n, T = 512, 60
+    cfg = O.default_config(); cfg.max_steps = 25
+    e = _mk(envs, n, seed=21, env_id_offset=5, max_steps=25)
+    e.set_policy("random", action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7)
+    st = O.ReachState(n)
+    e.reset(); O.reach_reset(kuka, cfg, st, seed=21, env_id0=5)
+    out = e.rollout(T, None, want_actions=True, want_terminal_obs=True)
+    ref = O.reach_rollout(kuka, cfg, st, T, None, seed=21, env_id0=5)
+    acts = _np(out["actions"])
+    assert np.abs(acts - ref["actions"]).max() < 2e-6
+    # std of N(0, 0.686) clipped at +-0.7 is 0.499
+    assert 0.47 < acts.std() < 0.53 and np.abs(acts).max() <= 0.7 and abs(acts.mean()) < 0.01
+    assert np.array_equal(_np(out["done"]), ref["done"].astype(bool))
+    assert np.array_equal(_np(out["success"]), ref["success"].astype(bool))
+    assert np.abs(_np(out["obs"]) - ref["obs"]).max() < 1e-5
+    assert np.abs(_np(out["terminal_obs"]) - ref["terminal_obs"]).max() < 1e-5
+    assert np.abs(_np(out["reward"]) - ref["reward"]).max() < 1e-4
+    assert ref["done"].sum() >= 2 * n
+    # splitting the same rollout into two launches gives the same trajectory (noise keyed by episode/step)
+    e2 = _mk(envs, n, seed=21, env_id_offset=5, max_steps=25)
+    e2.set_policy("random")
+    e2.reset()
+    o1 = {k: v.clone() for k, v in e2.rollout(23, None, want_actions=True).items()}
+    o2 = e2.rollout(T - 23, None, want_actions=True)
+    assert torch.equal(torch.cat([o1["obs"], o2["obs"]]), out["obs"])
+    assert torch.equal(torch.cat([o1["actions"], o2["actions"]]), out["actions"])
+    e.close(); e2.close()
+
+
+def test_rollout_argument_errors(envs):
+    from armenv import ArmEnvError
+    e = _mk(envs, 64)
+    e.reset()
+    with pytest.raises(ArmEnvError, match="no fused policy"):
+        e.rollout(4, None)
+    with pytest.raises(ValueError):
+        e.rollout(4, torch.zeros(3, 64, 3, device=DEV))
+    out = e.rollout(0, torch.zeros(0, 64, 3, device=DEV))
+    assert out["obs"].shape == (0, 64, 6)
+    e.close()
