@@ -1,6 +1,7 @@
 """Env registry with the reference's names (/root/reference/envs/__init__.py:1-4), so that
 ``getattr(envs, opt.env)`` (/root/reference/main.py:83) resolves here too."""
 from .rl_reach_env import RLReachEnv
-from .batched import BatchedArmEnv, BatchedReachEnv
+from .rl_push_env import RLPushEnv
+from .batched import BatchedArmEnv, BatchedReachEnv, BatchedPushEnv
 
-__all__ = ["RLReachEnv", "BatchedArmEnv", "BatchedReachEnv"]
+__all__ = ["RLReachEnv", "RLPushEnv", "BatchedArmEnv", "BatchedReachEnv", "BatchedPushEnv"]

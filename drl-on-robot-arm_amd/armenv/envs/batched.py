@@ -185,17 +185,22 @@ class BatchedArmEnv:
 
     # ------------------------------------------------------------------ state exchange / stats
     def get_state(self):
+        """Reach: q, goal, step, episode, ep_return.  Push: aux [N,8] (cube xyz, target xyz, d_last, 0) replaces goal."""
         n, dev = self.num_envs, self.device
+        push = self.task == L.TASK_PUSH
         st = dict(q=torch.empty((n, 7), dtype=torch.float64, device=dev),
-                  goal=torch.empty((n, 3), dtype=torch.float32, device=dev),
                   step=torch.empty(n, dtype=torch.int32, device=dev),
                   episode=torch.empty(n, dtype=torch.int32, device=dev),   # u32 bits
                   ep_return=torch.empty(n, dtype=torch.float64, device=dev))
-        L.check(self._lib.armenv_get_state(self._h, _ptr(st["q"]), _ptr(st["goal"]), _ptr(st["step"]),
-                                           _ptr(st["episode"]), _ptr(st["ep_return"]), None, self._stream()))
+        if push:
+            st["aux"] = torch.empty((n, 8), dtype=torch.float64, device=dev)
+        else:
+            st["goal"] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        L.check(self._lib.armenv_get_state(self._h, _ptr(st["q"]), _ptr(st.get("goal")), _ptr(st["step"]),
+                                           _ptr(st["episode"]), _ptr(st["ep_return"]), _ptr(st.get("aux")), self._stream()))
         return st
 
-    def set_state(self, q=None, goal=None, step=None, episode=None, ep_return=None):
+    def set_state(self, q=None, goal=None, step=None, episode=None, ep_return=None, aux=None):
         dev = self.device
 
         def prep(x, dt, shape):
@@ -205,10 +210,10 @@ class BatchedArmEnv:
             assert tuple(x.shape) == shape, (tuple(x.shape), shape)
             return x
         n = self.num_envs
-        q_, g_, s_, e_, r_ = (prep(q, torch.float64, (n, 7)), prep(goal, torch.float32, (n, 3)),
-                              prep(step, torch.int32, (n,)), prep(episode, torch.int32, (n,)),
-                              prep(ep_return, torch.float64, (n,)))
-        L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), None,
+        q_, g_, s_, e_, r_, a_ = (prep(q, torch.float64, (n, 7)), prep(goal, torch.float32, (n, 3)),
+                                  prep(step, torch.int32, (n,)), prep(episode, torch.int32, (n,)),
+                                  prep(ep_return, torch.float64, (n,)), prep(aux, torch.float64, (n, 8)))
+        L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), _ptr(a_),
                                            self._stream()))
         torch.cuda.current_stream(dev).synchronize()   # temporaries above must outlive the copy
 
@@ -237,3 +242,15 @@ class BatchedReachEnv(BatchedArmEnv):
         lo = [0.2, -0.3, 0.0] * 2
         hi = [0.7, 0.3, 0.55] * 2
         self.observation_space = Box(low=lo, high=hi)                                 # rl_reach_env.py:93-96
+
+
+class BatchedPushEnv(BatchedArmEnv):
+    """N x RLPushEnv (/root/reference/envs/rl_push_env.py): arm pipeline exact (dv 0.08, z in [0, 0.1]); the cube
+    follows a simplified sphere-vs-box push-out model instead of Bullet's rigid-body step (DESIGN.md section 4);
+    reward / done / success follow rl_push_env.py:368-445.  obs f32 [N, 9] = [eef, cube, target]."""
+    task = L.TASK_PUSH
+    obs_dim = 9
+
+    def __init__(self, num_envs, **kw):
+        super().__init__(num_envs, **kw)
+        self.observation_space = Box(low=[0.2, -0.3, 0.0], high=[0.7, 0.3, 0.55])       # rl_push_env.py:101-104

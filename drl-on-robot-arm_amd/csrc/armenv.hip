@@ -39,6 +39,7 @@ template <typename T> struct EnvParams {
   int32_t *last_len;
   uint8_t *last_success;
   unsigned long long *counters;
+  T *aux;  // push only: [7][N] = cube xyz, target xyz, d_last
   int64_t n;
   // task constants
   T dv;
@@ -53,6 +54,9 @@ template <typename T> struct EnvParams {
   T p_init[3];  // FK(q_init), computed on the device at create time
   uint64_t seed;
   uint64_t env_id0;
+  // push task (rl_push_env.py): simplified pusher model + reward constants
+  T push_success_dis, push_cube_half, push_eef_radius;
+  double push_rest_z, push_place_min, push_place_max;
   IKParams<T> ik;
   ChainDev<T> chain;
 };
@@ -84,6 +88,12 @@ AE_DEV void store_obs6(float *obs, int64_t i, const T (&p)[3], const float (&g)[
   o[0] = make_float2((float)p[0], (float)p[1]);
   o[1] = make_float2((float)p[2], g[0]);
   o[2] = make_float2(g[1], g[2]);
+}
+
+template <typename T>
+AE_DEV void store_obs9(float *obs, int64_t i, const T (&p)[3], const T (&c)[3], const T (&t)[3]) {
+  float *o = obs + 9 * i;
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; o[k] = (float)p[k]; o[3 + k] = (float)c[k]; o[6 + k] = (float)t[k]; });
 }
 
 // FK(q_init) once per handle, with the same device code the step uses.
@@ -158,6 +168,7 @@ AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint3
 // kernel both run this code, so a rollout is bit-identical to T step launches.
 template <class C, typename T> struct ReachLane {
   using M = Mth<T>;
+  static constexpr int kObs = 6;
   T q[NJ];
   float g[3];
   int32_t step;
@@ -245,15 +256,182 @@ template <class C, typename T> struct ReachLane {
   float cur_obs[3];   // eef part of the observation the policy sees next (goal part is g)
 };
 
-// RLReachEnv.step + _reward (rl_reach_env.py:219-319), one env per lane, fused:
-// load state -> FK -> target = clip(p + dv a) -> DLS IK loop -> FK -> distance / reward / done ->
-// obs pack -> episode accounting -> optional in-place reset -> store state.
-template <class C, typename T>
-__global__ __launch_bounds__(256) void reach_step_kernel(EnvParams<T> P, StepIO io) {
+// ---- push task (/root/reference/envs/rl_push_env.py) ---------------------------------------------------------------
+// Placement of cube and target: rejection sampling, <= 1000 tries, six draws per try (:195-214); f64 always.
+template <typename T>
+AE_DEV void push_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&cube)[3], T (&target)[3]) {
+  double cx = 0, cy = 0, tx = 0, ty = 0;
+  for (uint32_t t = 0; t < 1000u; ++t) {
+    double u0, u1, u2, u3, u4, u5;
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 0u, u0, u1);
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 1u, u2, u3);
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 2u, u4, u5);
+    cx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u0;
+    cy = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u1;
+    tx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u3;
+    ty = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u4;
+    const double dx = cx - tx, dy = cy - ty;
+    const double d = ::sqrt(::fma(dx, dx, dy * dy));   // both rest at the same z
+    if (d >= P.push_place_min && d <= P.push_place_max) break;
+    (void)u2; (void)u5;
+  }
+  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = (T)P.push_rest_z;
+  target[0] = (T)tx; target[1] = (T)ty; target[2] = (T)P.push_rest_z;
+}
+
+template <class C, typename T> struct PushLane {
+  using M = Mth<T>;
+  static constexpr int kObs = 9;
+  T q[NJ];
+  T cube[3], target[3], d_last;
+  int32_t step;
+  T ep_ret;
+  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;
+  float cur_obs[3];
+
+  AE_DEV T dist_ct() const {
+    const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
+    return M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
+  }
+
+  AE_DEV void load(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * n + i]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = P.aux[(int64_t)k * n + i]; target[k] = P.aux[(int64_t)(3 + k) * n + i]; });
+    d_last = P.aux[(int64_t)6 * n + i];
+    step = P.step[i];
+    ep_ret = P.ep_return[i];
+  }
+
+  AE_DEV void store(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
+    P.aux[(int64_t)6 * n + i] = d_last;
+    P.step[i] = step;
+    P.ep_return[i] = ep_ret;
+    if (n_done) atomicAdd(&P.counters[0], (unsigned long long)n_done);
+    if (n_succ) atomicAdd(&P.counters[1], (unsigned long long)n_succ);
+    if (n_bad) atomicAdd(&P.counters[3], (unsigned long long)n_bad);
+    if (n_upd) atomicAdd(&P.counters[4], (unsigned long long)n_upd);
+  }
+
+  // stepSimulation (:349), simplified: sphere (tool, radius r at the eef) vs axis-aligned box (cube, half-size h)
+  // overlap test; on overlap the cube is displaced horizontally -- along the contact normal by the penetration
+  // depth when the tool centre is outside the footprint, ahead of the tool along its travel p0 -> p when inside.
+  AE_DEV void contact(const EnvParams<T> &P, const T (&p0)[3], const T (&p)[3]) {
+    const T h = P.push_cube_half, r = P.push_eef_radius;
+    if (M::fabs(p[2] - cube[2]) >= h + r) return;
+    const T lx = cube[0] - h, hx = cube[0] + h, ly = cube[1] - h, hy = cube[1] + h;
+    const T qx = p[0] < lx ? lx : (p[0] > hx ? hx : p[0]);
+    const T qy = p[1] < ly ? ly : (p[1] > hy ? hy : p[1]);
+    const T gx = p[0] - qx, gy = p[1] - qy;
+    const T gap = M::sqrt(M::fma(gx, gx, gy * gy));
+    if (gap >= r) return;
+    if (gap > T(1e-9)) {
+      const T depth = r - gap;
+      cube[0] -= depth * (gx / gap);
+      cube[1] -= depth * (gy / gap);
+    } else {
+      T mx = p[0] - p0[0], my = p[1] - p0[1];
+      const T mn = M::sqrt(M::fma(mx, mx, my * my));
+      if (mn < T(1e-3)) return;   // < 1 mm of horizontal travel: the tool presses down on the cube, no sweep
+      mx /= mn; my /= mn;
+      const T s = (r + h) - M::fma(cube[0] - p[0], mx, (cube[1] - p[1]) * my);
+      if (s > T(0)) { cube[0] = M::fma(s, mx, cube[0]); cube[1] = M::fma(s, my, cube[1]); }
+    }
+  }
+
+  // RLPushEnv.step + _reward (rl_push_env.py:310-440)
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io) {
+    FKState<T> S;
+    T tgt[3];
+    T p0[3];
+    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
+    n_upd += (uint32_t)updates;
+    contact(P, p0, S.p);                                                          // :349
+    step += 1;                                                                    // :355
+    const T d_cur = dist_ct();                                                    // :388
+    T test = d_cur - d_last;                                                      // :390-392
+    if (M::fabs(test) < T(1e-5)) test = T(0.01);                                  // :393-394
+    d_last = d_cur;                                                               // :396-397
+    const float fx = (float)cube[0] - (float)target[0], fy = (float)cube[1] - (float)target[1],
+                fz = (float)cube[2] - (float)target[2];                           // :378-384 float32 states
+    const float dt32 = sqrtf(fmaf(fx, fx, fmaf(fy, fy, fz * fz)));                 // :400
+    T reward;
+    bool done;
+    if (step > P.max_steps) { reward = (T)(-dt32 * 50.0f); done = true; }                       // :418-420
+    else if ((double)dt32 < (double)P.push_success_dis) { reward = T(100); done = true; }       // :422-424
+    else { reward = -test * T(100); done = false; }                                             // :427-428
+    const bool succ = d_cur < P.push_success_dis;                                               // :430-432
+    ep_ret += reward;
+
+    bool finite = true;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
+    if (!finite) n_bad += 1;
+
+    io.reward[i] = (float)reward;
+    io.done[i] = done ? 1 : 0;
+    io.success[i] = succ ? 1 : 0;
+    if (io.terminal_obs) store_obs9<T>(io.terminal_obs, i, S.p, cube, target);
+    if (done) {
+      P.last_return[i] = ep_ret;
+      P.last_len[i] = step;
+      P.last_success[i] = succ ? 1 : 0;
+      n_done += 1;
+      if (succ) n_succ += 1;
+    }
+    if (done && P.auto_reset) {
+      const uint32_t ep = P.episode[i];
+      push_sample(P, i, ep, cube, target);
+      P.episode[i] = ep + 1u;
+      d_last = dist_ct();                                                         // :243-245
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
+      step = 0;
+      ep_ret = T(0);
+      store_obs9<T>(io.obs, i, P.p_init, cube, target);
+      cur_obs[0] = (float)P.p_init[0]; cur_obs[1] = (float)P.p_init[1]; cur_obs[2] = (float)P.p_init[2];
+    } else {
+      store_obs9<T>(io.obs, i, S.p, cube, target);                               // :308
+      cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    }
+    return updates;
+  }
+};
+
+// RLPushEnv.reset (rl_push_env.py:145-256) for masked envs; goal_in f32 [N][6] = cube xyz, target xyz.
+template <typename T>
+__global__ __launch_bounds__(256) void push_reset_kernel(EnvParams<T> P, const uint8_t *mask, const float *goal_in, float *obs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (mask && !mask[i]) return;
+  const int64_t n = P.n;
+  T cube[3], target[3];
+  if (goal_in) {
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = (T)goal_in[6 * i + k]; target[k] = (T)goal_in[6 * i + 3 + k]; });
+  } else {
+    const uint32_t ep = P.episode[i];
+    push_sample(P, i, ep, cube, target);
+    P.episode[i] = ep + 1u;
+  }
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.q_init[j]; });
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
+  const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
+  P.aux[(int64_t)6 * n + i] = Mth<T>::sqrt(Mth<T>::fma(x, x, Mth<T>::fma(y, y, z * z)));
+  P.step[i] = 0;
+  P.ep_return[i] = T(0);
+  if (obs) store_obs9<T>(obs, i, P.p_init, cube, target);
+}
+
+// One env step per launch: load state -> FK -> target = clip(p + dv a) -> DLS IK loop -> FK -> (push: contact) ->
+// reward / done -> obs pack -> episode accounting -> optional in-place reset -> store state.
+// Lane = ReachLane (rl_reach_env.py:219-319) or PushLane (rl_push_env.py:310-440).
+template <class Lane, typename T>
+__global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io) {
   TL_STAMP(tl0);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
-  ReachLane<C, T> L;
+  Lane L;
   L.load(P, i);
   T a[3];
   static_for<0, 3>([&](auto KI) { constexpr int k = KI; a[k] = (T)io.action[3 * i + k]; });
@@ -285,17 +463,18 @@ __global__ __launch_bounds__(256) void reach_step_kernel(EnvParams<T> P, StepIO 
 
 // The rollout inner loop of /root/reference/main.py:108-128 for `steps` consecutive env steps in ONE launch: the env
 // state stays in registers, every step's outputs go to row t of [steps][N][...] buffers, and the action of step t
-// is either read from actions[t] (external policy, identical to `steps` calls of reach_step_kernel) or produced
+// is either read from actions[t] (external policy, identical to `steps` calls of env_step_kernel) or produced
 // in-kernel by the fused exploration policy.  Because lanes never synchronise, a lane that needs extra IK updates
 // in one step does not hold the other envs back for the rest of the launch: per-step cost approaches the MEAN
 // update count instead of the per-launch MAX.
-template <class C, typename T>
-__global__ __launch_bounds__(256) void reach_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
-                                                            const float *actions, StepIO io0, float *actions_out) {
+template <class Lane, typename T>
+__global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
+                                                          const float *actions, StepIO io0, float *actions_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const int64_t n = P.n;
-  ReachLane<C, T> L;
+  constexpr int kObs = Lane::kObs;
+  Lane L;
   L.load(P, i);
   uint32_t episode = (pol.kind != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
   float an[3] = {0.f, 0.f, 0.f};
@@ -322,11 +501,11 @@ __global__ __launch_bounds__(256) void reach_rollout_kernel(EnvParams<T> P, Poli
     }
     StepIO io;
     io.action = nullptr;
-    io.obs = io0.obs + (int64_t)t * n * 6;
+    io.obs = io0.obs + (int64_t)t * n * kObs;
     io.reward = io0.reward + (int64_t)t * n;
     io.done = io0.done + (int64_t)t * n;
     io.success = io0.success + (int64_t)t * n;
-    io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * 6 : nullptr;
+    io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
     if (actions_out) {
       float *ao = actions_out + ((int64_t)t * n + i) * 3;
       if (actions) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
@@ -376,9 +555,13 @@ __global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, cons
 
 template <typename T>
 __global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *q, float *goal, int32_t *step,
-                                                        uint32_t *episode, double *ep_return) {
+                                                        uint32_t *episode, double *ep_return, double *aux) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
+  if (aux && P.aux) {
+    static_for<0, 7>([&](auto KI) { constexpr int k = KI; aux[8 * i + k] = (double)P.aux[(int64_t)k * P.n + i]; });
+    aux[8 * i + 7] = 0.0;
+  }
   if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[7 * i + j] = (double)P.q[(int64_t)j * P.n + i]; });
   if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; goal[3 * i + k] = P.goal[(int64_t)k * P.n + i]; });
   if (step) step[i] = P.step[i];
@@ -389,9 +572,10 @@ __global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *
 template <typename T>
 __global__ __launch_bounds__(256) void set_state_kernel(EnvParams<T> P, const double *q, const float *goal,
                                                         const int32_t *step, const uint32_t *episode,
-                                                        const double *ep_return) {
+                                                        const double *ep_return, const double *aux) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
+  if (aux && P.aux) static_for<0, 7>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * P.n + i] = (T)aux[8 * i + k]; });
   if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = (T)q[7 * i + j]; });
   if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = goal[3 * i + k]; });
   if (step) P.step[i] = step[i];
@@ -479,9 +663,10 @@ struct EngineBase {
   PolicyParams pol{ARMENV_POLICY_EXTERNAL, 0.f, 0.f, 0.f};
   virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
   virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
-  virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, hipStream_t s) = 0;
+  virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
+                        hipStream_t s) = 0;
   virtual int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
-                        const double *ep_return, hipStream_t s) = 0;
+                        const double *ep_return, const double *aux, hipStream_t s) = 0;
   virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
   virtual int counters(uint64_t out[8], hipStream_t s) = 0;
   virtual const char *name() const = 0;
@@ -493,6 +678,7 @@ template <class C, typename T> struct Engine final : EngineBase {
   EnvParams<T> P{};
   void *pool = nullptr;
   int block = 256;
+  int task = ARMENV_TASK_REACH;
   std::string kname;
 
   ~Engine() override {
@@ -508,6 +694,8 @@ template <class C, typename T> struct Engine final : EngineBase {
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
     const size_t o_ls = take(n), o_cnt = take(8 * 8), o_tmp = take(sizeof(T) * 4);
+    task = cfg.task;
+    const size_t o_aux = take(task == ARMENV_TASK_PUSH ? sizeof(T) * 7 * n : 0);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
     char *b = static_cast<char *>(pool);
@@ -521,6 +709,13 @@ template <class C, typename T> struct Engine final : EngineBase {
     P.last_success = reinterpret_cast<uint8_t *>(b + o_ls);
     P.counters = reinterpret_cast<unsigned long long *>(b + o_cnt);
     T *tmp = reinterpret_cast<T *>(b + o_tmp);
+    P.aux = task == ARMENV_TASK_PUSH ? reinterpret_cast<T *>(b + o_aux) : nullptr;
+    P.push_success_dis = (T)cfg.push_success_dis;
+    P.push_cube_half = (T)cfg.push_cube_half;
+    P.push_eef_radius = (T)cfg.push_eef_radius;
+    P.push_rest_z = cfg.push_rest_z;
+    P.push_place_min = cfg.push_place_min;
+    P.push_place_max = cfg.push_place_max;
 
     P.dv = (T)cfg.dv;
     P.reach_dis = (T)cfg.reach_dis;
@@ -566,23 +761,33 @@ template <class C, typename T> struct Engine final : EngineBase {
       const int v = atoi(bs);
       if (v == 64 || v == 128 || v == 256) block = v;
     }
-    kname = std::string("reach_step<") + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
+    kname = std::string(task == ARMENV_TASK_PUSH ? "push_step<" : "reach_step<") + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
     return ARMENV_OK;
   }
 
   int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) override {
-    hipLaunchKernelGGL((reach_reset_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, mask, goal, obs);
+    if (task == ARMENV_TASK_PUSH)
+      hipLaunchKernelGGL((push_reset_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, mask, goal, obs);
+    else
+      hipLaunchKernelGGL((reach_reset_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, mask, goal, obs);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
   int step(const StepIO &io, hipStream_t s) override {
-    hipLaunchKernelGGL((reach_step_kernel<C, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+    if (task == ARMENV_TASK_PUSH)
+      hipLaunchKernelGGL((env_step_kernel<PushLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+    else
+      hipLaunchKernelGGL((env_step_kernel<ReachLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
   int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {
-    hipLaunchKernelGGL((reach_rollout_kernel<C, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps, actions,
-                       io0, actions_out);
+    if (task == ARMENV_TASK_PUSH)
+      hipLaunchKernelGGL((env_rollout_kernel<PushLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
+                         actions, io0, actions_out);
+    else
+      hipLaunchKernelGGL((env_rollout_kernel<ReachLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
+                         actions, io0, actions_out);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
@@ -596,16 +801,17 @@ template <class C, typename T> struct Engine final : EngineBase {
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
-  int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, hipStream_t s) override {
+  int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
+                hipStream_t s) override {
     hipLaunchKernelGGL((get_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
-                       ep_return);
+                       ep_return, aux);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
   int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
-                const double *ep_return, hipStream_t s) override {
+                const double *ep_return, const double *aux, hipStream_t s) override {
     hipLaunchKernelGGL((set_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
-                       ep_return);
+                       ep_return, aux);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
@@ -719,7 +925,7 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
     return fail(ARMENV_EINVAL, "armenv_create: abi_version %d, library is %d", cfg->abi_version, ARMENV_ABI_VERSION);
   if (cfg->num_envs < 1) return fail(ARMENV_EINVAL, "armenv_create: num_envs must be >= 1");
   if (cfg->precision != 64 && cfg->precision != 32) return fail(ARMENV_EINVAL, "armenv_create: precision must be 32 or 64");
-  if (cfg->task != ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_create: task %d not available", cfg->task);
+  if (cfg->task != ARMENV_TASK_REACH && cfg->task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_create: unknown task %d", cfg->task);
   if (cfg->ik_max_iters < 0 || cfg->ik_max_iters > 1000) return fail(ARMENV_EINVAL, "armenv_create: ik_max_iters out of range");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -787,15 +993,17 @@ int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_
 int armenv_get_state(ArmEnv *env, double *q_dev, float *goal_dev, int32_t *step_dev, uint32_t *episode_dev,
                      double *ep_return_dev, double *aux_dev, void *stream) {
   ENV_ENTER(env);
-  if (aux_dev) return fail(ARMENV_EINVAL, "armenv_get_state: aux is only defined for the push task");
-  return env->eng->get_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, static_cast<hipStream_t>(stream));
+  if (aux_dev && env->cfg.task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_get_state: aux is only defined for the push task");
+  if (goal_dev && env->cfg.task == ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_get_state: push keeps cube/target in aux, not goal");
+  return env->eng->get_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, const int32_t *step_dev,
                      const uint32_t *episode_dev, const double *ep_return_dev, const double *aux_dev, void *stream) {
   ENV_ENTER(env);
-  if (aux_dev) return fail(ARMENV_EINVAL, "armenv_set_state: aux is only defined for the push task");
-  return env->eng->set_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, static_cast<hipStream_t>(stream));
+  if (aux_dev && env->cfg.task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_set_state: aux is only defined for the push task");
+  if (goal_dev && env->cfg.task == ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_set_state: push keeps cube/target in aux, not goal");
+  return env->eng->set_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len_dev, uint8_t *last_success_dev,

@@ -306,7 +306,7 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 // which is the post-step FK of _reward() (:271).  Returns the number of updates applied.
 template <class C, typename T, bool FROM_ACTION>
 AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
-                   const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S) {
+                   const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr) {
   using M = Mth<T>;
   T diff_prev = T(1e30);
   int it = 0;
@@ -319,6 +319,7 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     fk<C, T>(ch, cq, sq, S);
     if constexpr (FROM_ACTION) {
       if (it == 0) {
+        if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
         static_for<0, 3>([&](auto KI) {
           constexpr int k = KI;
           T v = M::fma(a[k], dv, S.p[k]);

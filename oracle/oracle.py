@@ -307,3 +307,62 @@ def reach_rollout(chain, cfg, st, steps, actions=None, seed=0, env_id0=0, sigma=
         for k, v in zip(("obs", "reward", "done", "success", "actions", "terminal_obs"), (o, r, d, s, a, term)):
             out[k].append(np.array(v, copy=True))
     return {k: np.stack(v) for k, v in out.items()}
+
+
+# ------------------------------------------------------------------ push env
+
+class PushState(ReachState):
+    """adds aux [N,8] = cube xyz, target xyz, d_last, pad"""
+
+    def __init__(self, n):
+        super().__init__(n)
+        self.aux = np.zeros((n, 8))
+
+
+def push_reset(chain, cfg, st, seed=0, env_id0=0, mask=None):
+    obs = np.zeros((st.n, 9), dtype=np.float32)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_push_reset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(st.n), _p(m),
+                         _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(obs))
+    if mask is None:
+        st.ep_return[:] = 0
+    else:
+        st.ep_return[np.asarray(mask, dtype=bool)] = 0
+    return obs
+
+
+def push_reset_with_goal(chain, cfg, st, goal6):
+    obs = np.zeros((st.n, 9), dtype=np.float32)
+    g = np.ascontiguousarray(goal6, dtype=np.float32).reshape(st.n, 6)
+    lib().orc_push_reset_with_goal(C.byref(chain), C.byref(cfg), C.c_int64(st.n), _p(g), _p(st.q), _p(st.aux), _p(st.step), _p(obs))
+    st.ep_return[:] = 0
+    return obs
+
+
+def push_step(chain, cfg, st, action):
+    n = st.n
+    a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
+    obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
+    done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); iters = np.zeros(n, dtype=np.int32)
+    lib().orc_push_step(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(st.q), _p(st.aux), _p(st.step), _p(a), _p(obs),
+                        _p(rew), _p(done), _p(succ), _p(iters))
+    st.ep_return += rew
+    return obs, rew, done, succ, iters
+
+
+def push_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0):
+    n = st.n
+    a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
+    obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
+    done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); term = np.zeros((n, 9), dtype=np.float32)
+    lib().orc_push_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
+                                  _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a), _p(obs),
+                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success))
+    return obs, rew, done, succ, term
+
+
+def push_outcome(cfg, cube, target, d_last, step_counter):
+    r = C.c_double(); d = C.c_uint8(); s = C.c_uint8(); dl = C.c_double(d_last)
+    lib().orc_push_outcome(C.byref(cfg), (C.c_double * 3)(*cube), (C.c_double * 3)(*target), C.byref(dl), C.c_int32(step_counter),
+                           C.byref(r), C.byref(d), C.byref(s))
+    return r.value, bool(d.value), bool(s.value), dl.value

@@ -15,6 +15,8 @@ reference's importable Python (config, algo.TD3) -- never reference source text.
                                (7 draws per reset envs/rl_reach_env.py:180-183,210-212; 3 per step :316-318)
   G5 reward_truth.json         (distance, step_counter) -> (reward, done, success) of
                                envs/rl_reach_env.py:299-309 (strict '>' and '<')
+  G7 push_reward_truth.json    (cube, target, d_last, step_counter) -> (reward, done, is_success) of
+                               envs/rl_push_env.py:387-432 with its float32 / float64 mix
 """
 import ast
 import json
@@ -116,6 +118,36 @@ def g5_reward_truth():
               open(os.path.join(OUT, "reward_truth.json"), "w"), indent=1)
 
 
+def g7_push_reward_truth():
+    """(cube, target, d_last, step_counter) -> (reward, done, is_success, new d_last) of envs/rl_push_env.py:387-432,
+    evaluated with explicit dtypes: object_state/target_state are float32 (:378-384), their norm is float32 (:400),
+    comparisons against Python floats happen in float64 (numpy 1.x scalar promotion, the reference's era)."""
+    max_steps = 500
+    rows = []
+    target = np.array([0.45, 0.10, 0.01])
+    for step in (1, 499, 500, 501):
+        for off, d_last in ((0.2300, 0.2300), (0.2300, 0.2300 + 5e-6), (0.2300, 0.2312), (0.2200, 0.2300),
+                            (0.0501, 0.0600), (0.0499, 0.0600), (0.05, 0.07), (0.0, 0.03)):
+            cube = target + np.array([off, 0.0, 0.0])
+            d_cur = float(np.linalg.norm(cube - target))                       # :388 (f64 obs)
+            test = d_cur - d_last                                              # :390-392
+            if abs(test) < 1e-5:
+                test = 0.01                                                    # :393-394
+            dt32 = np.linalg.norm(cube.astype(np.float32) - target.astype(np.float32))   # :400, float32
+            assert dt32.dtype == np.float32
+            if step > max_steps:
+                reward, done = float(np.float32(-dt32 * np.float32(50))), True  # :418-420
+            elif float(dt32) < 0.05:
+                reward, done = 100.0, True                                     # :422-424
+            else:
+                reward, done = -test * 100, False                              # :427-428
+            succ = bool(d_cur < 0.05)                                          # :430-432, 442-445
+            rows.append({"cube": cube.tolist(), "target": target.tolist(), "d_last": d_last, "step_counter": step,
+                         "reward": reward, "done": done, "success": succ, "d_new": d_cur})
+    json.dump({"max_steps": max_steps, "rows": rows, "source": "envs/rl_push_env.py:387-432"},
+              open(os.path.join(OUT, "push_reward_truth.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth()
+    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth()
     print("fixtures written to", OUT)

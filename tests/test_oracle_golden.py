@@ -208,3 +208,60 @@ def test_actor_matches_reference_golden(O):
     a = O.actor_forward(sd, g["states"], float(g["action_bound"]))
     assert np.abs(a - g["actions"]).max() < 1e-5
     assert np.abs(g["actions"][0] - [0.02861051, -0.01318958, -0.02435399]).max() < 1e-6   # SURVEY.md G3 spot value
+
+
+# ------------------------------------------------------------------------------ push (P1-P4)
+
+def test_push_reward_truth_table(O):
+    g = golden_json("push_reward_truth.json")
+    cfg = O.default_config("push")
+    for row in g["rows"]:
+        r, d, s, dl = O.push_outcome(cfg, row["cube"], row["target"], row["d_last"], row["step_counter"])
+        assert d == row["done"] and s == row["success"], row
+        assert abs(r - row["reward"]) <= 1e-12 * max(1.0, abs(row["reward"])), (r, row)
+        assert dl == row["d_new"]
+
+
+def test_push_placement_and_reset(O, kuka):
+    cfg = O.default_config("push")
+    st = O.PushState(4096)
+    obs = O.push_reset(kuka, cfg, st, seed=3)
+    d = np.linalg.norm(st.aux[:, 0:3] - st.aux[:, 3:6], axis=1)
+    assert (d >= 0.22).all() and (d <= 0.25).all()                       # rl_push_env.py:213
+    assert (st.aux[:, 2] == 0.01).all() and (st.aux[:, 5] == 0.01).all()  # :199,206
+    assert np.allclose(st.aux[:, 6], d) and (st.episode == 1).all()
+    lo, hi = np.array(cfg.goal_lo[:2]), np.array(cfg.goal_hi[:2])
+    for k in (0, 3):
+        assert (st.aux[:, k:k + 2] >= lo).all() and (st.aux[:, k:k + 2] <= hi).all()
+    assert np.abs(obs[:, 3:9] - st.aux[:, :6].astype(np.float32)).max() == 0
+    g = golden_json("fk_kat.json")
+    assert np.abs(obs[:, :3] - np.float32(g["p_f32"])).max() <= 6e-8
+
+
+def test_push_arm_pipeline_and_contact(O, kuka):
+    """dv = 0.08, z clipped to [0, 0.1] (rl_push_env.py:314,322); idle steps cost -1 (:393-394,427); the cube moves
+    only when the tool overlaps it, away from the tool, and the shaped reward is -100 * (d_now - d_last)."""
+    cfg = O.default_config("push")
+    st = O.PushState(1)
+    O.push_reset_with_goal(kuka, cfg, st, [[0.55, 0.0, 0.01, 0.55, 0.23, 0.01]])
+    obs, r, d, s, it = O.push_step(kuka, cfg, st, np.zeros((1, 3)))
+    assert abs(obs[0, 2] - 0.1) < 1e-4 and r[0] == -1.0 and not d[0]     # first step: z 0.496 -> clip 0.1
+    # go down next to the cube on the far side from the target (y < 0), then sweep in +y through the cube
+    for _ in range(40):
+        p = obs[0, :3]
+        a = np.clip((np.array([0.55, -0.08, 0.01]) - p) / 0.08, -1, 1)
+        obs, r, d, s, it = O.push_step(kuka, cfg, st, a[None])
+    assert np.abs(obs[0, :3] - [0.55, -0.08, 0.01]).max() < 2e-3 and np.allclose(st.aux[0, :3], [0.55, 0.0, 0.01], atol=1e-7)
+    moved = False
+    for _ in range(12):
+        c0 = st.aux[0, :3].copy(); dl = st.aux[0, 6]
+        obs, r, d, s, it = O.push_step(kuka, cfg, st, np.array([[0.0, 0.3, 0.0]]))
+        c1 = st.aux[0, :3]
+        if c1[1] > c0[1] + 1e-6:
+            moved = True
+            assert abs(c1[0] - c0[0]) < 1e-3 and c1[2] == c0[2]
+            assert r[0] > 0 and (r[0] == 100.0 if d[0] else abs(r[0] - (-(st.aux[0, 6] - dl) * 100)) < 1e-9)   # closer
+            # the tool sphere no longer overlaps the box footprint
+            gap = np.linalg.norm(np.maximum(np.abs(obs[0, :2] - c1[:2]) - 0.02, 0))
+            assert gap >= 0.03 - 1e-3
+    assert moved
