@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--gather-every", type=int, default=100, help="steps between episode-return all-gathers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--task", default="reach", choices=["reach", "push"],
+                    help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--rollout-steps", type=int, default=50, help="env steps fused per armenv_rollout launch")
     args = ap.parse_args()
@@ -88,9 +90,13 @@ def main():
     init_process_group("nccl", dev)
 
     n = args.envs_per_gpu
-    env = envs.BatchedReachEnv(n, device=dev, seed=0, env_id_offset=rank * n, precision=args.precision)
+    Env = envs.BatchedReachEnv if args.task == "reach" else envs.BatchedPushEnv
+    env = Env(n, device=dev, seed=0, env_id_offset=rank * n, precision=args.precision)
     gen = torch.Generator(device=dev); gen.manual_seed(1000 + rank)
-    ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous() for _ in range(16)]
+    if args.task == "reach":      # run() exploration with a zero actor, main.py:116-117
+        ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous() for _ in range(16)]
+    else:                         # train_push_with_TD3 exploration, unclipped, main.py:457,484
+        ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.392).contiguous() for _ in range(16)]
     gather = ReturnGatherer(n, dev, world)
     env.reset()
     R = max(1, min(args.rollout_steps, args.steps))
@@ -160,8 +166,12 @@ def main():
         value = total_envs * args.steps / wall_max
         launch_us = gpu_ms * 1e3 / launches              # HIP events on the launch stream, per kernel launch
         steps_per_launch = args.steps / launches
-        kernel = env.kernel_name if args.mode == "step" else env.kernel_name.replace("reach_step", "reach_rollout")
-        algo = (IO_BYTES * steps_per_launch + STATE_BYTES[args.precision]) * n   # bytes one launch moves, algorithmically
+        kernel = env.kernel_name if args.mode == "step" else env.kernel_name.replace("_step", "_rollout")
+        io_b, st_b = IO_BYTES, STATE_BYTES[args.precision]
+        if args.task == "push":   # obs 36 B instead of 24; state: cube/target/d_last (7 reals) r+w instead of goal
+            io_b += 12
+            st_b += 2 * 7 * (args.precision // 8) - 12
+        algo = (io_b * steps_per_launch + st_b) * n   # bytes one launch moves, algorithmically
         achieved = algo / (launch_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from separate rocprofv3 --pmc passes (profiles/README.md)
@@ -173,12 +183,14 @@ def main():
         updates = dc["ik_updates"] / max(1, dc["env_steps"])
         flops = (updates * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n * steps_per_launch
         line = {
-            "metric": "env-steps/sec at N parallel envs (rl_reach_env)",
+            "metric": "env-steps/sec at N parallel envs (rl_%s_env)" % args.task,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
-            "config": {"workload": "rl_reach_env %d parallel envs per GPU, random policy clip(N(0,0.686),+-0.7) pre-generated "
-                                   "in HBM, step() throughput only, KUKA iiwa chain, auto-reset on" % n,
+            "config": {"workload": ("rl_reach_env %d parallel envs per GPU, random policy clip(N(0,0.686),+-0.7) pre-generated "
+                                    "in HBM, step() throughput only, KUKA iiwa chain, auto-reset on" % n) if args.task == "reach" else
+                                   ("rl_push_env %d parallel envs per GPU (arm FK/IK + cube contact/overlap test), random policy "
+                                    "N(0,0.392) pre-generated in HBM, step() throughput only, auto-reset on" % n),
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode,
                        "steps_per_launch": steps_per_launch,
                        "parallelism": "env-sharded x%d, RCCL all-gather of episode returns every %d steps (logging only)"
