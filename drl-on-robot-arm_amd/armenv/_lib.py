@@ -60,6 +60,7 @@ SYMBOLS = {
     "armenv_episode_stats": (C.c_int, [_P, _P, _P, _P, _P]),
     "armenv_counters": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8), _P]),
     "armenv_set_policy": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "armenv_actor_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "armenv_num_envs": (C.c_int64, [_P]),
     "armenv_obs_dim": (C.c_int32, [_P]),
     "armenv_action_dim": (C.c_int32, [_P]),

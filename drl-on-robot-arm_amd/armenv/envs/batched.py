@@ -134,6 +134,13 @@ class BatchedArmEnv:
         torch.cuda.current_stream(self.device).synchronize()
         self._policy = kind
 
+    def actor_forward(self, states):
+        """TD3_MLP.take_action without noise (algo/TD3/TD3_mlp.py:82-97) for states f32 [n, obs_dim]."""
+        st = states.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, self.obs_dim)
+        out = torch.empty((st.shape[0], 3), dtype=torch.float32, device=self.device)
+        L.check(self._lib.armenv_actor_forward(self._h, st.shape[0], _ptr(st), _ptr(out), self._stream()))
+        return out
+
     def rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False):
         """`steps` env steps of all envs in one kernel launch (the inner loop of main.py:108-128).
         actions: float32 [steps, N, 3] on the device, or None to use the fused policy (set_policy).

@@ -21,6 +21,7 @@
 
 #include "../../include/armenv.h"
 #include "armenv_kin.h"
+#include "armenv_actor.h"
 
 using namespace armenv;
 
@@ -147,7 +148,37 @@ struct PolicyParams {
   float sigma;       // action_bound * opt.gamma = 0.686 in run()
   float clip;        // action_bound = 0.7
   float bound;       // actor output scale
+  ActorParams actor; // ARMENV_POLICY_ACTOR only
 };
+
+// TD3_MLP.take_action (/root/reference/algo/TD3/TD3_mlp.py:82-97) for n states, n a multiple of 64.
+template <int IN>
+__global__ __launch_bounds__(256) void actor_kernel(ActorParams A, int64_t n, const float *states, float *actions) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 64
+  const int64_t ic = i < n ? i : n - 1;
+  float s[IN], a[3];
+  static_for<0, IN>([&](auto DI) { constexpr int d = DI; s[d] = states[ic * IN + d]; });
+  actor_forward_wave<IN>(A, s, a);
+  if (i < n) { actions[3 * i] = a[0]; actions[3 * i + 1] = a[1]; actions[3 * i + 2] = a[2]; }
+}
+
+// torch Linear layouts ([out][in]) -> the operand layouts of armenv_actor.h
+__global__ void actor_pack_kernel(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                                  int in_dim, float *W1P, float *W2P, float *B2W3) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ACTOR_HID * 12) {
+    const int k = t / 12, j = t % 12;
+    W1P[t] = j < in_dim ? W1[k * in_dim + j] : (j == 11 ? b1[k] : 0.f);
+  }
+  if (t < ACTOR_HID * ACTOR_HID) {
+    const int c = t & 3, l32 = (t >> 2) & 31, part = (t >> 7) & 1, k = t >> 8;
+    W2P[t] = W2[(32 * (4 * part + c) + l32) * ACTOR_HID + k];
+  }
+  if (t < ACTOR_HID * 4) {
+    const int n = t >> 2, c = t & 3;
+    B2W3[t] = c == 0 ? b2[n] : W3[(c - 1) * ACTOR_HID + n];
+  }
+}
 
 // Three N(0,1) draws for (env, episode, step): Philox block 0x80000000|step of the env's stream (reset draws use
 // blocks < 2^31), Box-Muller in f32 on u = (w + 1) * 2^-32 in (0, 1].
@@ -254,6 +285,17 @@ template <class C, typename T> struct ReachLane {
   }
 
   float cur_obs[3];   // eef part of the observation the policy sees next (goal part is g)
+  // eef of the current state, for the first policy call of a launch (later ones reuse the step's exit FK)
+  AE_DEV void refresh_obs(const EnvParams<T> &P) {
+    FKState<T> S;
+    T cq[NJ], sq[NJ];
+    sincos_all<T>(q, cq, sq);
+    fk<C, T>(P.chain, cq, sq, S);
+    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+  }
+  AE_DEV void policy_obs(float (&s)[6]) const {
+    s[0] = cur_obs[0]; s[1] = cur_obs[1]; s[2] = cur_obs[2]; s[3] = g[0]; s[4] = g[1]; s[5] = g[2];
+  }
 };
 
 // ---- push task (/root/reference/envs/rl_push_env.py) ---------------------------------------------------------------
@@ -288,6 +330,16 @@ template <class C, typename T> struct PushLane {
   T ep_ret;
   uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;
   float cur_obs[3];
+  AE_DEV void refresh_obs(const EnvParams<T> &P) {
+    FKState<T> S;
+    T cq[NJ], sq[NJ];
+    sincos_all<T>(q, cq, sq);
+    fk<C, T>(P.chain, cq, sq, S);
+    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+  }
+  AE_DEV void policy_obs(float (&s)[9]) const {
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; s[k] = cur_obs[k]; s[3 + k] = (float)cube[k]; s[6 + k] = (float)target[k]; });
+  }
 
   AE_DEV T dist_ct() const {
     const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
@@ -477,6 +529,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   Lane L;
   L.load(P, i);
   uint32_t episode = (pol.kind != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
+  if (!actions && pol.kind == ARMENV_POLICY_ACTOR) L.refresh_obs(P);
   float an[3] = {0.f, 0.f, 0.f};
   if (actions) { an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2]; }
   for (int32_t t = 0; t < steps; ++t) {
@@ -488,13 +541,19 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
         an[0] = nx[0]; an[1] = nx[1]; an[2] = nx[2];
       }
     } else {
+      float mu[3] = {0.f, 0.f, 0.f};
+      if (pol.kind == ARMENV_POLICY_ACTOR) {   // wave-uniform
+        float s[kObs];
+        L.policy_obs(s);
+        actor_forward_wave<kObs>(pol.actor, s, mu);                      // take_action, TD3_mlp.py:82-97
+      }
       float nz[3];
       // the episode index of the stream is the number of resets so far minus one (the running episode)
       policy_noise(P.seed, P.env_id0 + (uint64_t)i, episode - 1u, (uint32_t)L.step, nz);
       static_for<0, 3>([&](auto KI) {
         constexpr int k = KI;
-        float v = nz[k] * pol.sigma;          // zero actor + N(0, sigma)
-        v = fminf(fmaxf(v, -pol.clip), pol.clip);
+        float v = fmaf(nz[k], pol.sigma, mu[k]);                          // + N(0, sigma), main.py:116
+        v = fminf(fmaxf(v, -pol.clip), pol.clip);                         // .clip(-bound, bound), main.py:117
         a[k] = (T)v;
         an[k] = v;
       });
@@ -655,12 +714,18 @@ template <class C> static bool chain_matches(const ArmEnvChain &ch) {
 }
 
 struct EngineBase {
-  virtual ~EngineBase() {}
+  virtual ~EngineBase() {
+    if (actor_buf) (void)hipFree(actor_buf);
+  }
   virtual int init(const ArmEnvConfig &cfg) = 0;
   virtual int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) = 0;
   virtual int step(const StepIO &io, hipStream_t s) = 0;
   virtual int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) = 0;
-  PolicyParams pol{ARMENV_POLICY_EXTERNAL, 0.f, 0.f, 0.f};
+  PolicyParams pol{};
+  float *actor_buf = nullptr;   // packed W1P | W2P | B2W3 on the handle's device
+  int set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                int in_dim, float bound, hipStream_t s);
+  int actor_forward(int64_t n, const float *states, float *actions, hipStream_t s);
   virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
   virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
   virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
@@ -673,6 +738,35 @@ struct EngineBase {
 };
 
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                          const float *b3, int in_dim, float bound, hipStream_t s) {
+  const size_t n1 = ACTOR_HID * 12, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
+  if (!actor_buf && hipMalloc(reinterpret_cast<void **>(&actor_buf), (n1 + n2 + n3) * sizeof(float)) != hipSuccess)
+    return fail(ARMENV_ENOMEM, "armenv_set_policy: hipMalloc failed");
+  float *W1P = actor_buf, *W2P = actor_buf + n1, *B2W3 = actor_buf + n1 + n2;
+  hipLaunchKernelGGL(actor_pack_kernel, dim3((unsigned)(n2 / 256)), dim3(256), 0, s, W1, b1, W2, b2, W3, in_dim, W1P, W2P, B2W3);
+  HIP_TRY(hipGetLastError());
+  float hb3[3];
+  HIP_TRY(hipMemcpyAsync(hb3, b3, sizeof hb3, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  pol.actor.W1P = reinterpret_cast<const float4 *>(W1P);
+  pol.actor.W2P = reinterpret_cast<const float4 *>(W2P);
+  pol.actor.B2W3 = reinterpret_cast<const float4 *>(B2W3);
+  for (int k = 0; k < 3; ++k) pol.actor.b3[k] = hb3[k];
+  pol.actor.bound = bound;
+  pol.actor.in_dim = in_dim;
+  return ARMENV_OK;
+}
+
+int EngineBase::actor_forward(int64_t n, const float *states, float *actions, hipStream_t s) {
+  if (!pol.actor.W2P) return fail(ARMENV_ESTATE, "armenv_actor_forward: no actor installed (armenv_set_policy)");
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (pol.actor.in_dim == 6) hipLaunchKernelGGL((actor_kernel<6>), dim3(grid), dim3(256), 0, s, pol.actor, n, states, actions);
+  else hipLaunchKernelGGL((actor_kernel<9>), dim3(grid), dim3(256), 0, s, pol.actor, n, states, actions);
+  HIP_TRY(hipGetLastError());
+  return ARMENV_OK;
+}
 
 template <class C, typename T> struct Engine final : EngineBase {
   EnvParams<T> P{};
@@ -1018,17 +1112,36 @@ int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream) {
   return env->eng->counters(out, static_cast<hipStream_t>(stream));
 }
 
-int armenv_set_policy(ArmEnv *env, int32_t policy, const float *, const float *, const float *, const float *,
-                      const float *, const float *, int32_t, float action_bound, float noise_sigma, float noise_clip,
-                      void *) {
+int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const float *b1_dev, const float *W2_dev,
+                      const float *b2_dev, const float *W3_dev, const float *b3_dev, int32_t hidden_dim, float action_bound,
+                      float noise_sigma, float noise_clip, void *stream) {
   ENV_ENTER(env);
-  if (policy == ARMENV_POLICY_EXTERNAL || policy == ARMENV_POLICY_RANDOM) {
-    if (policy == ARMENV_POLICY_RANDOM && !(noise_sigma >= 0.f && noise_clip > 0.f))
-      return fail(ARMENV_EINVAL, "armenv_set_policy: need noise_sigma >= 0 and noise_clip > 0");
-    env->eng->pol = PolicyParams{policy, noise_sigma, noise_clip, action_bound};
-    return ARMENV_OK;
+  if (policy != ARMENV_POLICY_EXTERNAL && policy != ARMENV_POLICY_RANDOM && policy != ARMENV_POLICY_ACTOR)
+    return fail(ARMENV_EINVAL, "armenv_set_policy: unknown policy %d", policy);
+  if (policy != ARMENV_POLICY_EXTERNAL && !(noise_sigma >= 0.f && noise_clip > 0.f))
+    return fail(ARMENV_EINVAL, "armenv_set_policy: need noise_sigma >= 0 and noise_clip > 0");
+  if (policy == ARMENV_POLICY_ACTOR) {
+    if (!W1_dev || !b1_dev || !W2_dev || !b2_dev || !W3_dev || !b3_dev) return fail(ARMENV_EINVAL, "armenv_set_policy: NULL weight pointer");
+    if (hidden_dim != ACTOR_HID)
+      return fail(ARMENV_EINVAL, "armenv_set_policy: hidden_dim %d; the fused actor is built for %d (config.py:56)", hidden_dim, ACTOR_HID);
+    if (env->cfg.num_envs % 64 != 0)
+      return fail(ARMENV_EINVAL, "armenv_set_policy: the fused actor needs num_envs to be a multiple of 64 (full wavefronts)");
+    const int rc = env->eng->set_actor(W1_dev, b1_dev, W2_dev, b2_dev, W3_dev, b3_dev, armenv_obs_dim(env), action_bound,
+                                       static_cast<hipStream_t>(stream));
+    if (rc != ARMENV_OK) return rc;
   }
-  return fail(ARMENV_ESTATE, "armenv_set_policy: the fused actor is not available in this build");
+  env->eng->pol.kind = policy;
+  env->eng->pol.sigma = noise_sigma;
+  env->eng->pol.clip = noise_clip;
+  env->eng->pol.bound = action_bound;
+  return ARMENV_OK;
+}
+
+int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, void *stream) {
+  ENV_ENTER(env);
+  if (n < 0 || (n > 0 && (!states_dev || !actions_dev))) return fail(ARMENV_EINVAL, "armenv_actor_forward: bad arguments");
+  if (n == 0) return ARMENV_OK;
+  return env->eng->actor_forward(n, states_dev, actions_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,

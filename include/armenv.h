@@ -195,6 +195,11 @@ int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const fl
                       const float *b2_dev, const float *W3_dev, const float *b3_dev, int32_t hidden_dim,
                       float action_bound, float noise_sigma, float noise_clip, void *stream);
 
+/* The installed actor alone (TD3_MLP.take_action without noise, /root/reference/algo/TD3/TD3_mlp.py:82-97):
+ * states f32 [n][obs_dim] -> actions f32 [n][3], f32 arithmetic, layer 2 on the f32 MFMA.  Needs a prior
+ * armenv_set_policy(ARMENV_POLICY_ACTOR, ...). */
+int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, void *stream);
+
 /* Shape / capability queries. */
 int64_t armenv_num_envs(const ArmEnv *env);
 int32_t armenv_obs_dim(const ArmEnv *env);

@@ -297,13 +297,29 @@ def random_policy_actions(st, seed=0, env_id0=0, sigma=0.7 * 0.98, clip=0.7):
     return a
 
 
-def reach_rollout(chain, cfg, st, steps, actions=None, seed=0, env_id0=0, sigma=0.7 * 0.98, clip=0.7):
-    """`steps` auto-reset steps; actions [steps,N,3] or None for the fused random policy.  Returns dict of
-    [steps, N, ...] arrays like the engine's rollout."""
+def policy_noise(st, seed=0, env_id0=0):
+    nz = np.zeros((st.n, 3), dtype=np.float32)
+    lib().orc_policy_noise_batch(C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(st.n), _p(st.episode), _p(st.step), _p(nz))
+    return nz
+
+
+def reach_rollout(chain, cfg, st, steps, actions=None, seed=0, env_id0=0, sigma=0.7 * 0.98, clip=0.7, actor=None,
+                  bound=0.7, obs0=None):
+    """`steps` auto-reset steps; actions [steps,N,3], or None for the fused policy: zero actor (random) or, with
+    actor = state-dict and obs0 = the current observation, a = clip(actor(obs) + sigma * N(0,1), +-clip)
+    (/root/reference/main.py:114-117).  Returns dict of [steps, N, ...] arrays like the engine's rollout."""
     out = dict(obs=[], reward=[], done=[], success=[], actions=[], terminal_obs=[])
+    obs = obs0
     for t in range(steps):
-        a = actions[t] if actions is not None else random_policy_actions(st, seed, env_id0, sigma, clip)
+        if actions is not None:
+            a = actions[t]
+        elif actor is None:
+            a = random_policy_actions(st, seed, env_id0, sigma, clip)
+        else:
+            mu = actor_forward(actor, obs, bound)
+            a = np.clip(mu + np.float32(sigma) * policy_noise(st, seed, env_id0), -np.float32(clip), np.float32(clip)).astype(np.float32)
         o, r, d, s, term = reach_step_autoreset(chain, cfg, st, a, seed=seed, env_id0=env_id0)
+        obs = o
         for k, v in zip(("obs", "reward", "done", "success", "actions", "terminal_obs"), (o, r, d, s, a, term)):
             out[k].append(np.array(v, copy=True))
     return {k: np.stack(v) for k, v in out.items()}

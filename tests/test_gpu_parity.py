@@ -670,3 +670,84 @@ def test_rlpushenv_compat_surface(envs):
         assert state.shape == (9,) and isinstance(done, bool) and set(info) == {"is_success"}
         assert info["is_success"].dtype == np.float32 and reward == -1.0 and not done
     env.close()
+
+
+# ------------------------------------------------------------------------------ fused TD3 actor (A1, config 3)
+
+def _golden_actor():
+    g = golden_npz("td3_actor_seed0.npz")
+    sd = {k: g[k.replace(".", "_")] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+    return g, sd
+
+
+def test_actor_forward_matches_reference_golden(envs, O):
+    """G3 was produced by importing the reference's TD3_MLP (algo/TD3/TD3_mlp.py:33-97, net_mlp.py:29-40);
+    tolerance 1e-5 on actions in f32."""
+    g, sd = _golden_actor()
+    e = _mk(envs, 64)
+    e.set_policy("actor", action_bound=float(g["action_bound"]), actor_state_dict={k: torch.from_numpy(v) for k, v in sd.items()})
+    for n in (1024, 1000, 1, 65):                                    # ragged tails of the last wavefront
+        a = _np(e.actor_forward(torch.from_numpy(g["states"][:n])))
+        assert a.shape == (n, 3)
+        assert np.abs(a - g["actions"][:n]).max() < 1e-5
+        assert np.abs(a - O.actor_forward(sd, g["states"][:n], float(g["action_bound"]))).max() < 1e-5
+    e.close()
+
+
+def test_actor_forward_asymmetric_weights(envs, O):
+    """Transpose-detecting check of the MFMA operand/accumulator maps: random, non-symmetric weights with a
+    distinct scale per layer, and biases that make about half the units fire."""
+    rng = np.random.default_rng(80)
+    sd = {"fc1.weight": rng.normal(0, 0.8, (256, 6)), "fc1.bias": rng.normal(0, 0.3, 256),
+          "fc2.weight": rng.normal(0, 0.09, (256, 256)) * np.linspace(0.5, 1.5, 256)[None, :], "fc2.bias": rng.normal(0, 0.2, 256),
+          "fc3.weight": rng.normal(0, 0.12, (3, 256)), "fc3.bias": rng.normal(0, 0.1, 3)}
+    sd = {k: v.astype(np.float32) for k, v in sd.items()}
+    states = rng.uniform(-1, 1, (640, 6)).astype(np.float32)
+    e = _mk(envs, 64)
+    e.set_policy("actor", action_bound=0.7, actor_state_dict={k: torch.from_numpy(v) for k, v in sd.items()})
+    a = _np(e.actor_forward(torch.from_numpy(states)))
+    ref = O.actor_forward(sd, states, 0.7)
+    t = torch.from_numpy
+    h = torch.relu(t(states) @ t(sd["fc1.weight"]).T + t(sd["fc1.bias"]))
+    h = torch.relu(h @ t(sd["fc2.weight"]).T + t(sd["fc2.bias"]))
+    tref = (torch.tanh(h @ t(sd["fc3.weight"]).T + t(sd["fc3.bias"])) * 0.7).numpy()
+    assert np.abs(ref - tref).max() < 2e-6 and np.abs(a - tref).max() < 5e-6 and ref.std() > 0.1
+    e.close()
+
+
+def test_rollout_fused_actor_matches_oracle(envs, O, kuka):
+    """BASELINE config 3 path: TD3 actor folded into the rollout kernel + exploration noise (main.py:114-117)."""
+    g, sd = _golden_actor()
+    n, T = 256, 45
+    cfg = O.default_config(); cfg.max_steps = 20
+    e = _mk(envs, n, seed=31, max_steps=20)
+    e.set_policy("actor", action_bound=0.7, noise_sigma=0.1, noise_clip=0.7, actor_state_dict={k: torch.from_numpy(v) for k, v in sd.items()})
+    st = O.ReachState(n)
+    obs0 = _np(e.reset()).copy(); obs0_r = O.reach_reset(kuka, cfg, st, seed=31)
+    out = e.rollout(T, None, want_actions=True)
+    ref = O.reach_rollout(kuka, cfg, st, T, None, seed=31, sigma=0.1, clip=0.7, actor=sd, bound=0.7, obs0=obs0_r)
+    assert np.abs(_np(out["actions"]) - ref["actions"]).max() < 2e-5
+    assert np.array_equal(_np(out["done"]), ref["done"].astype(bool))
+    assert np.abs(_np(out["obs"]) - ref["obs"]).max() < 1e-5
+    assert np.abs(_np(out["reward"]) - ref["reward"]).max() < 1e-4
+    assert ref["done"].sum() >= 2 * n and np.abs(ref["actions"]).mean() > 0.02
+    e.close()
+
+
+def test_set_policy_errors(envs):
+    from armenv import ArmEnvError
+    g, sd = _golden_actor()
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    e = _mk(envs, 100)                                               # not a multiple of 64
+    with pytest.raises(ArmEnvError, match="multiple of 64"):
+        e.set_policy("actor", actor_state_dict=tsd)
+    e.close()
+    e = _mk(envs, 64)
+    with pytest.raises(ArmEnvError, match="no actor"):
+        e.actor_forward(torch.zeros(4, 6))
+    bad = dict(tsd); bad["fc1.weight"] = torch.zeros(128, 6); bad["fc1.bias"] = torch.zeros(128)
+    with pytest.raises(ArmEnvError, match="hidden_dim"):
+        e.set_policy("actor", actor_state_dict=bad)
+    with pytest.raises(ArmEnvError, match="noise"):
+        e.set_policy("random", noise_sigma=-1.0)
+    e.close()
