@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--task", default="reach", choices=["reach", "push"],
                     help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768)")
+    ap.add_argument("--policy", default="external", choices=["external", "random", "actor"],
+                    help="external = pre-generated actions in HBM (configs[1], headline); random / actor = fused in-kernel "
+                         "policy (actor = configs[2]: TD3 actor forward folded into the rollout kernel)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--rollout-steps", type=int, default=50, help="env steps fused per armenv_rollout launch")
     args = ap.parse_args()
@@ -97,6 +100,18 @@ def main():
         ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous() for _ in range(16)]
     else:                         # train_push_with_TD3 exploration, unclipped, main.py:457,484
         ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.392).contiguous() for _ in range(16)]
+    if args.policy != "external":
+        args.mode = "rollout"
+        bound, sig = (0.7, 0.7 * 0.98) if args.task == "reach" else (0.4, 0.4 * 0.98)
+        sd = None
+        if args.policy == "actor":      # weights of TD3_MLP(6,3,0.7) under torch.manual_seed(0): golden G3
+            g = np.load(os.path.join(ROOT, "tests", "golden", "td3_actor_seed0.npz"))
+            sd = {k: torch.from_numpy(g[k.replace(".", "_")]) for k in
+                  ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+            if args.task != "reach":
+                raise SystemExit("--policy actor: the golden actor has 6 inputs (reach)")
+        env.set_policy(args.policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if args.task == "reach" else 1e9,
+                       actor_state_dict=sd)
     gather = ReturnGatherer(n, dev, world)
     env.reset()
     R = max(1, min(args.rollout_steps, args.steps))
@@ -115,7 +130,8 @@ def main():
         done_steps, launches = 0, 0
         while done_steps < k:
             r = min(R, k - done_steps)
-            env.rollout(r, acts if r == R else acts[:r].contiguous(), out=bufs if r == R else None)
+            a_in = None if args.policy != "external" else (acts if r == R else acts[:r].contiguous())
+            env.rollout(r, a_in, out=bufs if r == R else None)
             done_steps += r; launches += 1
             if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
                 gather.launch(env.episode_stats()[0])
@@ -152,7 +168,7 @@ def main():
     counters = env.counters()
 
     step_api = None
-    if args.mode == "rollout" and world == 1:
+    if args.mode == "rollout" and world == 1 and args.policy == "external":
         args.mode = "step"                      # the gym-style one-launch-per-step path, timed beside the headline
         k2 = min(args.steps, 500)
         run(10)
@@ -168,6 +184,8 @@ def main():
         steps_per_launch = args.steps / launches
         kernel = env.kernel_name if args.mode == "step" else env.kernel_name.replace("_step", "_rollout")
         io_b, st_b = IO_BYTES, STATE_BYTES[args.precision]
+        if args.policy != "external":
+            io_b -= 12                      # no action read
         if args.task == "push":   # obs 36 B instead of 24; state: cube/target/d_last (7 reals) r+w instead of goal
             io_b += 12
             st_b += 2 * 7 * (args.precision // 8) - 12
@@ -191,7 +209,7 @@ def main():
                                     "in HBM, step() throughput only, KUKA iiwa chain, auto-reset on" % n) if args.task == "reach" else
                                    ("rl_push_env %d parallel envs per GPU (arm FK/IK + cube contact/overlap test), random policy "
                                     "N(0,0.392) pre-generated in HBM, step() throughput only, auto-reset on" % n),
-                       "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode,
+                       "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch,
                        "parallelism": "env-sharded x%d, RCCL all-gather of episode returns every %d steps (logging only)"
                                       % (world, args.gather_every) if world > 1 else "single GPU"},
@@ -204,6 +222,11 @@ def main():
                               "frac": flops / (launch_us * 1e-6) / 1e12 / (F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3)},
             "episodes_finished": counters["episodes"], "nonfinite_states": counters["nonfinite"],
         }
+        if args.policy == "actor":
+            # 2 * (6*256 + 256*256 + 256*3) flop per env-step; layer 2 on the f32 MFMA
+            af = 2 * (6 * 256 + 256 * 256 + 256 * 3) * n * steps_per_launch
+            line["roofline_mfma"] = {"bound": "mfma", "achieved": af / (launch_us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                     "frac": af / (launch_us * 1e-6) / 1e12 / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         if step_api:
             line["step_api"] = step_api
         if world == 1 and not args.no_cpu_baseline:

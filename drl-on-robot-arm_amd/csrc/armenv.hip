@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void actor_kernel(ActorParams A, int64_t n, co
 __global__ void actor_pack_kernel(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                                   int in_dim, float *W1P, float *W2P, float *B2W3) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < ACTOR_HID * 12) {
+  if (t < ACTOR_HID * 12) {   // [kk][row k = 2kk + r][12] == [k][12]
     const int k = t / 12, j = t % 12;
     W1P[t] = j < in_dim ? W1[k * in_dim + j] : (j == 11 ? b1[k] : 0.f);
   }
@@ -750,7 +750,7 @@ int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, con
   float hb3[3];
   HIP_TRY(hipMemcpyAsync(hb3, b3, sizeof hb3, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  pol.actor.W1P = reinterpret_cast<const float4 *>(W1P);
+  pol.actor.W1P = W1P;
   pol.actor.W2P = reinterpret_cast<const float4 *>(W2P);
   pol.actor.B2W3 = reinterpret_cast<const float4 *>(B2W3);
   for (int k = 0; k < 3; ++k) pol.actor.b3[k] = hb3[k];

@@ -25,7 +25,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int ACTOR_HID = 256;
 
 struct ActorParams {
-  const float4 *W1P;   // [256][3]  float4: w0..w3 | w4..w7 | w8, 0, 0, b1   (inputs beyond in_dim are zero)
+  const float *W1P;    // [128 kk][2 rows k = 2kk, 2kk+1][12]: w0..w8 (zero beyond in_dim), 0, 0, b1 -- read through the
+                       // scalar cache (wave-uniform address), never through the vector memory path
   const float4 *W2P;   // [256 k][2 part][32 lane]: (W2[32*(4 part + c) + lane][k], c = 0..3)
   const float4 *B2W3;  // [256]: (b2[n], W3[0][n], W3[1][n], W3[2][n])
   float b3[3];
@@ -58,31 +59,56 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float (&s)[IN], float
       constexpr int nt = NI;
       static_for<0, 16>([&](auto RI) { constexpr int r = RI; acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f; });
     });
-    float4 a0 = w2[(half * 2 + part) * 32];
-#pragma unroll 2
-    for (int kk = 0; kk < ACTOR_HID / 2; ++kk) {
-      const int k = 2 * kk + half;
-      // prefetch next k-pair's A operand (the last iteration re-reads the current one; harmless)
-      const int kn = (kk + 1 < ACTOR_HID / 2) ? k + 2 : k;
-      const float4 n0 = w2[(kn * 2 + part) * 32];
-      // layer 1 for this lane's k, both env tiles (B operand)
-      const float4 wa = A.W1P[k * 3 + 0], wb = A.W1P[k * 3 + 1], wc = A.W1P[k * 3 + 2];
-      const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
-      float hA = wc.w, hB = wc.w;
+    // Software pipeline, two k-pairs deep: while the eight MFMAs of k-pair kk occupy the matrix pipe (8 x 64 cycles),
+    // the VALU computes layer 1 for kk+1 from W1 rows fetched during kk-1, and the loads for kk+2 are in flight.
+    // W1 rows: both halves of the wave need a different row (k = 2kk + lane/32), i.e. two wave-uniform rows per
+    // k-pair.  Fetching them per lane through the vector path (64 lanes x 16 B of identical addresses, three times
+    // per k-pair) halved the MFMA rate (57 vs 110 TF); through the scalar cache they cost nothing visible.
+    typedef const float __attribute__((address_space(4))) *scalar_ptr;
+    const scalar_ptr w1s = (scalar_ptr)A.W1P;
+    struct Rows { float r0[12], r1[12]; };
+    auto load_rows = [&](int kk, Rows &R) {
+      const int kc = kk < ACTOR_HID / 2 ? kk : ACTOR_HID / 2 - 1;   // the tail prefetches re-read the last pair
+      static_for<0, 12>([&](auto JI) { constexpr int j = JI; R.r0[j] = w1s[kc * 24 + j]; R.r1[j] = w1s[kc * 24 + 12 + j]; });
+    };
+    auto load_a = [&](int kk) {
+      const int kc = kk < ACTOR_HID / 2 ? kk : ACTOR_HID / 2 - 1;
+      return w2[((2 * kc + half) * 2 + part) * 32];
+    };
+    auto layer1 = [&](const Rows &R, float &hA, float &hB) {
+      float a0 = R.r0[11], a1 = R.r1[11], b0 = R.r0[11], b1 = R.r1[11];
       static_for<0, IN>([&](auto DI) {
         constexpr int d = DI;
-        hA = fmaf(w[d], sA[d], hA);
-        hB = fmaf(w[d], sB[d], hB);
+        a0 = fmaf(R.r0[d], sA[d], a0); a1 = fmaf(R.r1[d], sA[d], a1);
+        b0 = fmaf(R.r0[d], sB[d], b0); b1 = fmaf(R.r1[d], sB[d], b1);
       });
-      hA = fmaxf(hA, 0.f);
-      hB = fmaxf(hB, 0.f);
-      const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+      hA = fmaxf(half ? a1 : a0, 0.f);
+      hB = fmaxf(half ? b1 : b0, 0.f);
+    };
+    // Software pipeline: while the eight MFMAs of k-pair kk occupy the matrix pipe (8 x 64 cycles), the VALU computes
+    // layer 1 for kk+1 and the loads for kk+2 (A operand) / kk+1 (W1 rows) are in flight.
+    Rows R;
+    float hA, hB, hA_n, hB_n;
+    load_rows(0, R);
+    layer1(R, hA, hB);
+    float4 a_cur = load_a(0), a_nxt = load_a(1);
+    load_rows(1, R);
+#pragma unroll 1
+    for (int kk = 0; kk < ACTOR_HID / 2; ++kk) {
+      const float4 a_nn = load_a(kk + 2);
+      // keep the loads above the MFMAs: hipcc otherwise sinks them to their first use and exposes an L2 round trip
+      __builtin_amdgcn_sched_barrier(0);
+      const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
       static_for<0, 4>([&](auto NI) {
         constexpr int nt = NI;
         acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hA, acc[nt][0], 0, 0, 0);
         acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hB, acc[nt][1], 0, 0, 0);
       });
-      a0 = n0;
+      layer1(R, hA_n, hB_n);                                // layer 1 for kk+1
+      load_rows(kk + 2, R);
+      __builtin_amdgcn_sched_barrier(0);
+      hA = hA_n; hB = hB_n;
+      a_cur = a_nxt; a_nxt = a_nn;
     }
     // layer 2 bias + relu, layer 3 partial sums over the 64 neurons this lane holds per env tile in this pass
     static_for<0, 4>([&](auto NI) {
