@@ -200,6 +200,47 @@ int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const fl
  * armenv_set_policy(ARMENV_POLICY_ACTOR, ...). */
 int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, void *stream);
 
+/* ---- trajectory store + HER-"future" sampler (consumer of the rollout buffers; replaces the per-sample Python loops of
+ * /root/reference/utils/rl_utils.py:108-152 and :154-199).  Buffers are the time-major tensors armenv_rollout writes:
+ * obs0 f32 [N][D] (observation before step 0), obs_after f32 [T][N][D] (= obs_dev), next_obs f32 [T][N][D]
+ * (= terminal_obs_dev), action f32 [T][N][3], reward f32 [T][N], done u8 [T][N].  A trajectory (rl_utils.py:91-105) is one
+ * complete episode of one env inside the chunk. */
+
+/* Episode index, two passes around a caller-side inclusive prefix sum (e.g. torch.cumsum) of counts:
+ *   armenv_count_episodes -> counts_dev i32 [N];   offsets = inclusive cumsum(counts) as i64 [N];
+ *   armenv_write_episodes -> episodes_dev i32 [E][3] = (env, t_start, length), E = offsets[N-1].
+ * starts_at_reset != 0: every env was reset right before step 0 of the chunk. */
+int armenv_count_episodes(int32_t device, int64_t T, int64_t N, const uint8_t *done_dev, int32_t starts_at_reset,
+                          int32_t *counts_dev, void *stream);
+int armenv_write_episodes(int32_t device, int64_t T, int64_t N, const uint8_t *done_dev, int32_t starts_at_reset,
+                          const int32_t *counts_dev, const int64_t *offsets_dev, int32_t *episodes_dev, void *stream);
+
+typedef struct ArmEnvHerArgs {
+  int64_t T, N;
+  int32_t obs_dim;            /* 6: reach relabel rule (rl_utils.py:140-141); 9: push rule (:187-188) */
+  int32_t use_her;
+  const float *obs0_dev, *obs_after_dev, *next_obs_dev, *action_dev, *reward_dev;
+  const uint8_t *done_dev;
+  const int32_t *episodes_dev;      /* [E][3] */
+  const int64_t *num_episodes_dev;  /* device scalar E (no host sync needed to size the draw) */
+  int64_t batch;                    /* B */
+  const int32_t *picks_dev;         /* nullable i32 [B][4] = (episode, step_state, use_her, step_goal): caller-supplied
+                                       draws (parity tests feed the reference's own draws); NULL: Philox(seed, draw) */
+  uint64_t seed, draw;
+  float her_ratio, dis_threshold;   /* 0.8 (config.py:80), 0.1 (rl_utils.py:119) */
+  float *states_dev;                /* out f32 [B][D] */
+  float *actions_dev;               /* out f32 [B][3] */
+  float *next_states_dev;           /* out f32 [B][D] */
+  float *rewards_dev;               /* out f32 [B] */
+  uint8_t *dones_dev;               /* out u8 [B] */
+  int32_t *picks_out_dev;           /* nullable out i32 [B][4] */
+} ArmEnvHerArgs;
+
+/* ReplayBuffer_Trajectory_{reach,push}.sample(batch, use_her, dis_threshold, her_ratio) for B samples in one launch:
+ * uniform episode, uniform step, with probability her_ratio a future state's first three dims become the goal,
+ * reward -0.1 / 1.0 and done by the distance threshold. */
+int armenv_her_sample(int32_t device, const ArmEnvHerArgs *args, void *stream);
+
 /* Shape / capability queries. */
 int64_t armenv_num_envs(const ArmEnv *env);
 int32_t armenv_obs_dim(const ArmEnv *env);

@@ -15,6 +15,8 @@ reference's importable Python (config, algo.TD3) -- never reference source text.
                                (7 draws per reset envs/rl_reach_env.py:180-183,210-212; 3 per step :316-318)
   G5 reward_truth.json         (distance, step_counter) -> (reward, done, success) of
                                envs/rl_reach_env.py:299-309 (strict '>' and '<')
+  G6 her_{reach,push}_seed0.npz  ReplayBuffer_Trajectory_{reach,push}.sample outputs + the draws it made
+                               (utils/rl_utils.py:108-199), produced by importing the reference
   G7 push_reward_truth.json    (cube, target, d_last, step_counter) -> (reward, done, is_success) of
                                envs/rl_push_env.py:387-432 with its float32 / float64 mix
 """
@@ -148,6 +150,101 @@ def g7_push_reward_truth():
               open(os.path.join(OUT, "push_reward_truth.json"), "w"), indent=1)
 
 
+def g6_her_samples():
+    """G6: outputs of the reference's ReplayBuffer_Trajectory_{reach,push}.sample (utils/rl_utils.py:108-199) on synthetic
+    trajectories, together with the draws it made (trajectory, step, HER coin, future step), recorded by wrapping
+    random.sample / np.random.randint / np.random.uniform while the reference runs.  Trajectories are laid out in the
+    engine's rollout-chunk layout (time-major [T][N][..], episodes back to back per env column, chunk starts at a reset;
+    every column ends with an unfinished episode that must not be sampled)."""
+    sys.path.insert(0, REF)
+    from utils import rl_utils
+    for task, D, Buf in (("reach", 6, rl_utils.ReplayBuffer_Trajectory_reach), ("push", 9, rl_utils.ReplayBuffer_Trajectory_push)):
+        rng = np.random.default_rng(6 if D == 6 else 9)
+        N, T = 6, 64
+        obs0 = np.zeros((N, D), np.float32); obs_after = np.zeros((T, N, D), np.float32)
+        next_obs = np.zeros((T, N, D), np.float32); action = np.zeros((T, N, 3), np.float32)
+        reward = np.zeros((T, N), np.float32); done = np.zeros((T, N), np.uint8)
+        buf = Buf(1000)
+        trajs = []
+        sdt = np.float32 if D == 6 else np.float64      # reach obs are float32, push obs float64 (rl_push_env.py:308)
+
+        def first_obs():
+            o = rng.uniform(0.2, 0.6, D).astype(np.float32)
+            return o
+
+        for n in range(N):
+            t = 0
+            cur = first_obs(); obs0[n] = cur
+            while True:
+                L = int(rng.integers(3, 14))
+                complete = t + L <= T - 2
+                if not complete:
+                    L = T - t
+                traj = rl_utils.Trajectory(cur.astype(sdt))
+                for j in range(L):
+                    a = rng.normal(0, 0.3, 3).astype(np.float32)
+                    nxt = cur.copy(); nxt[:3] += rng.normal(0, 0.03, 3).astype(np.float32)
+                    r = np.float32(rng.normal()); d = bool(complete and j == L - 1)
+                    traj.store_step(a, nxt.astype(sdt), float(r), d)
+                    action[t, n] = a; next_obs[t, n] = nxt; reward[t, n] = r; done[t, n] = d
+                    cur = first_obs() if d else nxt            # auto-reset: the returned obs is the next episode's first
+                    obs_after[t, n] = cur
+                    t += 1
+                if not complete:
+                    break
+                buf.add_trajectory(traj); trajs.append(traj)
+        # record the reference's draws
+        picks, cur_pick = [], {}
+        o_sample, o_randint, o_uniform = random.sample, np.random.randint, np.random.uniform
+
+        def w_sample(pop, k):
+            out = o_sample(pop, k)
+            cur_pick.clear(); cur_pick["ep"] = next(i for i, tr in enumerate(trajs) if tr is out[0]); cur_pick["n"] = 0
+            return out
+
+        def w_randint(*a, **kw):
+            v = o_randint(*a, **kw)
+            if cur_pick["n"] == 0:
+                cur_pick["st"] = int(v)
+            else:
+                cur_pick["sg"] = int(v)
+            cur_pick["n"] += 1
+            return v
+
+        def w_uniform(*a, **kw):
+            v = o_uniform(*a, **kw)
+            cur_pick["u"] = float(v)
+            return v
+        random.seed(60 + D); np.random.seed(60 + D)
+        rl_utils.random.sample, np.random.randint, np.random.uniform = w_sample, w_randint, w_uniform
+        try:
+            B, ratio, thr = 256, 0.8, 0.1
+            # run sample one draw at a time so that each pick can be captured
+            outs = dict(states=[], actions=[], next_states=[], rewards=[], dones=[])
+            for _ in range(B):
+                b = buf.sample(1, use_her=True, dis_threshold=thr, her_ratio=ratio)
+                her = cur_pick["u"] <= ratio
+                picks.append([cur_pick["ep"], cur_pick["st"], int(her), cur_pick.get("sg", 0) if her else 0])
+                cur_pick.pop("sg", None)
+                for k in outs:
+                    outs[k].append(b[k][0])
+        finally:
+            rl_utils.random.sample, np.random.randint, np.random.uniform = o_sample, o_randint, o_uniform
+        episodes = []
+        for n in range(N):
+            start = 0
+            for t in range(T):
+                if done[t, n]:
+                    episodes.append([n, start, t - start + 1]); start = t + 1
+        assert len(episodes) == len(trajs) and all(e[2] == tr.length for e, tr in zip(episodes, trajs))
+        np.savez(os.path.join(OUT, f"her_{task}_seed0.npz"), obs0=obs0, obs_after=obs_after, next_obs=next_obs, action=action,
+                 reward=reward, done=done, episodes=np.array(episodes, np.int32), picks=np.array(picks, np.int32),
+                 her_ratio=np.float32(ratio), dis_threshold=np.float32(thr),
+                 states=np.array(outs["states"], np.float64), next_states=np.array(outs["next_states"], np.float64),
+                 actions=np.array(outs["actions"], np.float32), rewards=np.array(outs["rewards"], np.float64),
+                 dones=np.array(outs["dones"], np.uint8))
+
+
 if __name__ == "__main__":
-    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth()
+    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples()
     print("fixtures written to", OUT)

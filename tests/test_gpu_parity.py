@@ -751,3 +751,88 @@ def test_set_policy_errors(envs):
     with pytest.raises(ArmEnvError, match="noise"):
         e.set_policy("random", noise_sigma=-1.0)
     e.close()
+
+
+# ------------------------------------------------------------------------------ trajectory store + HER sampler (8f.1)
+
+def _store_from_golden(g):
+    from armenv.replay import TrajectoryStore
+    st = TrajectoryStore(device=DEV, seed=5)
+    t = lambda k, dt=None: torch.from_numpy(g[k]).to(DEV)
+    out = dict(obs=t("obs_after"), terminal_obs=t("next_obs"), reward=t("reward"), done_u8=t("done"), actions=t("action"))
+    st.add_rollout(t("obs0"), out)
+    return st
+
+
+@pytest.mark.parametrize("task", ["reach", "push"])
+def test_her_sampler_matches_reference_golden(envs, task):
+    """G6 (outputs of the reference's ReplayBuffer_Trajectory_*.sample and the draws it made): the HIP sampler fed the
+    same draws reproduces every value."""
+    g = golden_npz(f"her_{task}_seed0.npz")
+    st = _store_from_golden(g)
+    assert st.size() == len(g["episodes"])
+    assert np.array_equal(_np(st.chunk["episodes"])[: st.size()], g["episodes"])
+    out = st.sample(len(g["picks"]), use_her=True, dis_threshold=float(g["dis_threshold"]), her_ratio=float(g["her_ratio"]),
+                    picks=g["picks"], return_picks=True)
+    assert np.array_equal(_np(out["picks"]), g["picks"])
+    assert np.array_equal(_np(out["states"]).astype(np.float64), g["states"])
+    assert np.array_equal(_np(out["next_states"]).astype(np.float64), g["next_states"])
+    assert np.array_equal(_np(out["actions"]), g["actions"]) and np.array_equal(_np(out["dones"]), g["dones"])
+    assert np.abs(_np(out["rewards"]).astype(np.float64) - g["rewards"]).max() < 1e-7
+
+
+def test_her_sampler_own_draws_are_valid_and_uniform(envs):
+    from oracle import her
+    g = golden_npz("her_reach_seed0.npz")
+    st = _store_from_golden(g)
+    B = 200000
+    out = st.sample(B, use_her=True, her_ratio=0.8, return_picks=True)
+    pk = _np(out["picks"]); eps = g["episodes"]
+    L = eps[pk[:, 0], 2]
+    assert (pk[:, 0] >= 0).all() and (pk[:, 0] < len(eps)).all() and (pk[:, 1] >= 0).all() and (pk[:, 1] < L).all()
+    h = pk[:, 2] == 1
+    assert ((pk[h, 3] >= pk[h, 1] + 1) & (pk[h, 3] <= L[h])).all()
+    assert abs(h.mean() - 0.8) < 0.01                                         # np.random.uniform() <= her_ratio
+    cnt = np.bincount(pk[:, 0], minlength=len(eps)) / B
+    assert np.abs(cnt - 1.0 / len(eps)).max() < 0.25 / len(eps)               # random.sample(buffer, 1): uniform over trajectories
+    # every value equals the restatement run on the kernel's own draws
+    ch = {k: g[k] for k in ("obs0", "obs_after", "next_obs", "action", "reward", "done")}
+    ref = her.sample_with_picks(ch, eps, pk[:5000], 0.1)
+    for k in ("states", "next_states", "actions", "dones"):
+        assert np.array_equal(_np(out[k])[:5000], ref[k]), k
+    assert np.abs(_np(out["rewards"])[:5000] - ref["rewards"]).max() < 1e-7
+    # no HER: plain transitions
+    out2 = st.sample(1000, use_her=False, return_picks=True)
+    assert int(out2["picks"][:, 2].sum()) == 0
+    # a second call draws a different batch (draw counter), the same store + seed + counter repeats
+    st2 = _store_from_golden(g)
+    a = st2.sample(64, return_picks=True)["picks"]; b = st2.sample(64, return_picks=True)["picks"]
+    assert not torch.equal(a, b)
+
+
+def test_rollout_into_store_end_to_end(envs):
+    """main.py:108-138 on the device: reset -> rollout (fused random policy) -> trajectory store -> HER batches."""
+    from armenv.replay import TrajectoryStore
+    n, T = 4096, 60
+    e = _mk(envs, n, seed=3, max_steps=12)                                   # 13-step episodes: ~4 complete per env
+    e.set_policy("random")
+    obs0 = e.reset().clone()
+    out = e.rollout(T, None, want_actions=True, want_terminal_obs=True)
+    st = TrajectoryStore(device=DEV, seed=1)
+    st.add_rollout(obs0, out)
+    n_done = int(out["done"].sum())
+    assert st.size() == n_done and n_done >= 4 * n
+    ep = st.chunk["episodes"][: st.size()]
+    assert int(ep[:, 2].max()) <= 13 and int(ep[:, 2].min()) >= 1
+    b = st.sample(65536, use_her=True, her_ratio=0.8, return_picks=True)
+    pk = b["picks"]; her = pk[:, 2] == 1
+    # relabelled goals are achieved eef positions, rewards follow the 0.1 threshold
+    d = (b["next_states"][:, :3] - b["next_states"][:, 3:6]).norm(dim=1)
+    assert bool(((b["rewards"][her] == 1.0) == (d[her] <= 0.1)).all())
+    assert bool((b["states"][:, 3:6] == b["next_states"][:, 3:6]).all())
+    # un-relabelled samples carry the env's own reward: -10 * distance or 0 on success (rl_reach_env.py:299-309)
+    keep = ~her & (b["dones"] == 0)
+    assert float((b["rewards"][keep] + 10.0 * d[keep]).abs().max()) < 1e-4
+    # consecutive states of a transition differ by one bounded arm move (dv * 0.7 per axis + IK residual)
+    assert float((b["next_states"][:, :3] - b["states"][:, :3]).abs().max()) < 0.02 * 0.7 + 2e-3
+    e.close()

@@ -265,3 +265,22 @@ def test_push_arm_pipeline_and_contact(O, kuka):
             gap = np.linalg.norm(np.maximum(np.abs(obs[0, :2] - c1[:2]) - 0.02, 0))
             assert gap >= 0.03 - 1e-3
     assert moved
+
+
+# ------------------------------------------------------------------------------ trajectory store + HER (next row 8f.1)
+
+@pytest.mark.parametrize("task", ["reach", "push"])
+def test_her_sampler_restatement_matches_reference(task):
+    """G6: the reference's own sampler outputs, with the draws it made (utils/rl_utils.py:108-199)."""
+    from oracle import her
+    g = golden_npz(f"her_{task}_seed0.npz")
+    ch = {k: g[k] for k in ("obs0", "obs_after", "next_obs", "action", "reward", "done")}
+    eps = her.index_episodes(g["done"])
+    assert np.array_equal(eps, g["episodes"])
+    assert (g["picks"][:, 2] == 1).sum() > 150 and (g["picks"][:, 2] == 0).sum() > 20
+    out = her.sample_with_picks(ch, eps, g["picks"], float(g["dis_threshold"]))
+    assert np.array_equal(out["states"].astype(np.float64), g["states"])
+    assert np.array_equal(out["next_states"].astype(np.float64), g["next_states"])
+    assert np.array_equal(out["actions"], g["actions"]) and np.array_equal(out["dones"], g["dones"])
+    assert np.abs(out["rewards"].astype(np.float64) - g["rewards"]).max() < 1e-7      # -0.1 is not exact in f32
+    assert 0.1 < g["dones"].mean() < 0.9
