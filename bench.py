@@ -88,9 +88,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(1, ndev))
     torch.cuda.set_device(dev)
-    init_process_group("nccl", dev)
+    # one rank per GPU over RCCL; if the node has fewer GPUs than ranks (debugging on a 1-GPU box) the ranks share
+    # GPUs and the logging collective falls back to gloo -- reported in config.parallelism
+    backend = "nccl" if world <= ndev else "gloo"
+    init_process_group(backend, dev if backend == "nccl" else None)
 
     n = args.envs_per_gpu
     Env = envs.BatchedReachEnv if args.task == "reach" else envs.BatchedPushEnv
@@ -161,7 +165,7 @@ def main():
     run(args.warmup)
     wall, gpu_ms, launches, dc = timed(args.steps)
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
@@ -211,8 +215,9 @@ def main():
                                     "N(0,0.392) pre-generated in HBM, step() throughput only, auto-reset on" % n),
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch,
-                       "parallelism": "env-sharded x%d, RCCL all-gather of episode returns every %d steps (logging only)"
-                                      % (world, args.gather_every) if world > 1 else "single GPU"},
+                       "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps (logging only)"
+                                      % (world, "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: debug)", args.gather_every)
+                                      if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo},

@@ -52,6 +52,13 @@ class ReturnGatherer:
 
     def launch(self, local_returns):
         """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs."""
+        if self.side is not None and self.world > 1 and dist.get_backend() != "nccl":
+            # debugging path (several ranks sharing one GPU cannot use RCCL): stage through the host with gloo
+            host = local_returns.detach().to("cpu", torch.float32)
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(parts, host)
+            self.out.copy_(torch.cat(parts))
+            return
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side):

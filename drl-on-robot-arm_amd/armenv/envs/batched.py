@@ -107,7 +107,8 @@ class BatchedArmEnv:
         """One env step for all N envs; no host synchronisation.  Returns (obs, reward, done, success)
         -- the same preallocated tensors every call (clone them to keep a history).  With
         want_terminal_obs the pre-reset observation is available as ``self.terminal_obs``."""
-        self._check_action(action)
+        if action is not None:          # None: the fused policy installed with set_policy() acts
+            self._check_action(action)
         if want_terminal_obs and self._terminal is None:
             self._terminal = torch.empty_like(self._obs)
         term = self._terminal if want_terminal_obs else None

@@ -1064,9 +1064,13 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                 uint8_t *success_dev, float *terminal_obs_dev, void *stream) {
   ENV_ENTER(env);
-  if (!action_dev) return fail(ARMENV_ESTATE, "armenv_step: action_dev is NULL and no fused policy is installed");
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_step: NULL output buffer");
   StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev};
+  if (!action_dev) {   // fused policy: a one-step rollout
+    if (env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
+      return fail(ARMENV_ESTATE, "armenv_step: action_dev is NULL and no fused policy is installed");
+    return env->eng->rollout(1, nullptr, io, nullptr, static_cast<hipStream_t>(stream));
+  }
   return env->eng->step(io, static_cast<hipStream_t>(stream));
 }
 

@@ -508,6 +508,17 @@ def test_rollout_random_policy_matches_oracle(envs, O, kuka):
     e.close(); e2.close()
 
 
+def test_step_with_fused_policy_equals_one_step_rollouts(envs):
+    a = _mk(envs, 256, seed=4); b = _mk(envs, 256, seed=4)
+    for e in (a, b):
+        e.set_policy("random"); e.reset()
+    out = a.rollout(9, None)
+    for t in range(9):
+        o, r, d, s = b.step(None)
+        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["done"][t], d)
+    a.close(); b.close()
+
+
 def test_rollout_argument_errors(envs):
     from armenv import ArmEnvError
     e = _mk(envs, 64)
