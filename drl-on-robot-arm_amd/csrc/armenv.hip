@@ -520,7 +520,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io
 // in-kernel by the fused exploration policy.  Because lanes never synchronise, a lane that needs extra IK updates
 // in one step does not hold the other envs back for the rest of the launch: per-step cost approaches the MEAN
 // update count instead of the per-launch MAX.
-template <class Lane, typename T>
+// POLICY is a compile-time copy of pol.kind: the external-action variant carries no actor / noise code, which keeps it
+// free of the register spills the fused-actor variant's 128 MFMA accumulators would otherwise force on it.
+template <class Lane, typename T, int POLICY>
 __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
                                                           const float *actions, StepIO io0, float *actions_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -529,13 +531,13 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   constexpr int kObs = Lane::kObs;
   Lane L;
   L.load(P, i);
-  uint32_t episode = (pol.kind != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
-  if (!actions && pol.kind == ARMENV_POLICY_ACTOR) L.refresh_obs(P);
+  uint32_t episode = (POLICY != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
+  if constexpr (POLICY == ARMENV_POLICY_ACTOR) L.refresh_obs(P);
   float an[3] = {0.f, 0.f, 0.f};
-  if (actions) { an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2]; }
+  if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2]; }
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
-    if (actions) {
+    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
       a[0] = (T)an[0]; a[1] = (T)an[1]; a[2] = (T)an[2];
       if (t + 1 < steps) {   // prefetch the next step's action; its latency hides under this step's IK
         const float *nx = actions + ((int64_t)(t + 1) * n + i) * 3;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
       }
     } else {
       float mu[3] = {0.f, 0.f, 0.f};
-      if (pol.kind == ARMENV_POLICY_ACTOR) {   // wave-uniform
+      if constexpr (POLICY == ARMENV_POLICY_ACTOR) {
         float s[kObs];
         L.policy_obs(s);
         actor_forward_wave<kObs>(pol.actor, s, mu);                      // take_action, TD3_mlp.py:82-97
@@ -568,12 +570,14 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
     io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
     if (actions_out) {
       float *ao = actions_out + ((int64_t)t * n + i) * 3;
-      if (actions) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
+      if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
       else { ao[0] = an[0]; ao[1] = an[1]; ao[2] = an[2]; }
     }
     const uint32_t before = L.n_done;
     L.env_step(P, i, a, io);
-    if (L.n_done != before && P.auto_reset) episode += 1u;
+    if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
+      if (L.n_done != before && P.auto_reset) episode += 1u;
+    }
   }
   L.store(P, i);
   if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)n * (unsigned long long)steps);
@@ -876,13 +880,20 @@ template <class C, typename T> struct Engine final : EngineBase {
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
+  template <class Lane, int POLICY>
+  void launch_rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
+    hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
+                       actions, io0, actions_out);
+  }
+  template <class Lane>
+  void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
+    if (actions) launch_rollout<Lane, ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
+    else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<Lane, ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
+    else launch_rollout<Lane, ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
+  }
   int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {
-    if (task == ARMENV_TASK_PUSH)
-      hipLaunchKernelGGL((env_rollout_kernel<PushLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
-                         actions, io0, actions_out);
-    else
-      hipLaunchKernelGGL((env_rollout_kernel<ReachLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
-                         actions, io0, actions_out);
+    if (task == ARMENV_TASK_PUSH) launch_rollout_policy<PushLane<C, T>>(steps, actions, io0, actions_out, s);
+    else launch_rollout_policy<ReachLane<C, T>>(steps, actions, io0, actions_out, s);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
@@ -952,6 +963,14 @@ extern "C" {
 #ifdef ARMENV_TIMELINE
 int armenv_dbg_set_timeline(unsigned long long *buf_dev) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf_dev, sizeof buf_dev);
+}
+int armenv_dbg_sections(unsigned long long out[8], int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(armenv::g_sections), 8 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(armenv::g_sections), z, sizeof z);
+  }
+  return rc;
 }
 #endif
 

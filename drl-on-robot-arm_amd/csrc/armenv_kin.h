@@ -144,11 +144,21 @@ AE_DEV T fast_rcp(T d) {
   return r;
 }
 
+// 1/sqrt(x): v_rsq + Newton steps (two in f64, one in f32); a few ulp, one short dependent chain instead of the
+// sqrt-then-divide pair (each a long quarter-rate sequence in f64)
+template <typename T>
+AE_DEV T fast_rsqrt(T x) {
+  T r = __builtin_amdgcn_rsq(x);
+  const T hx = T(0.5) * x;
+  r = Mth<T>::fma(Mth<T>::fma(-hx * r, r, T(0.5)), r, r);
+  if constexpr (sizeof(T) == 8) r = Mth<T>::fma(Mth<T>::fma(-hx * r, r, T(0.5)), r, r);
+  return r;
+}
+
 // btMatrix3x3::getRotation (Bullet src/LinearMath/btMatrix3x3.h): rotation matrix -> quaternion xyzw.
 // m(r,c) = W[3*c + r].
 template <typename T>
 AE_DEV void quat_from_frame(const T (&W)[9], T (&q)[4]) {
-  using M = Mth<T>;
   const T m00 = W[0], m10 = W[1], m20 = W[2], m01 = W[3], m11 = W[4], m21 = W[5], m02 = W[6], m12 = W[7], m22 = W[8];
   // Same case selection as getRotation (trace > 0, else the largest diagonal element), evaluated with selects
   // so that a wave whose lanes disagree on the case pays one sqrt and one divide, not four branches.
@@ -158,9 +168,8 @@ AE_DEV void quat_from_frame(const T (&W)[9], T (&q)[4]) {
   const bool cy = !cw && !cz && (m00 < m11);
   // cx otherwise
   const T t = cw ? (trace + T(1)) : cz ? (m22 - m00 - m11 + T(1)) : cy ? (m11 - m22 - m00 + T(1)) : (m00 - m11 - m22 + T(1));
-  const T r = M::sqrt(t);
-  const T big = r * T(0.5);
-  const T h = T(0.5) / r;
+  const T h = T(0.5) * fast_rsqrt<T>(t);   // 0.5 / sqrt(t)
+  const T big = t * h;                       // sqrt(t) * 0.5
   const T d21 = m21 - m12, d02 = m02 - m20, d10 = m10 - m01;
   const T s10 = m10 + m01, s20 = m20 + m02, s21 = m21 + m12;
   q[0] = cw ? d21 * h : cz ? s20 * h : cy ? s10 * h : big;
@@ -194,21 +203,19 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
   }
   const T wc = dw < T(-1) ? T(-1) : (dw > T(1) ? T(1) : dw);
   T angle = T(2) * M::acos(wc);
+  // axis = v / sqrt(1 - w^2), renormalised (btQuaternion::getAxis + btVector3::normalize): together v / |v|; the
+  // degenerate branch (1 - w^2 < 10 eps -> axis (1,0,0)) is a select so that the whole function is one basic block
+  // and its long dependent chain (acos, rsqrt) can be scheduled under the Jacobian / J J^T arithmetic
   const T s2 = M::fma(-dw, dw, T(1));
-  T a0, a1, a2;
-  if (s2 < T(10) * M::eps) {
-    a0 = T(1); a1 = T(0); a2 = T(0);
-  } else {
-    const T s = T(1) / M::sqrt(s2);
-    a0 = dx * s; a1 = dy * s; a2 = dz * s;
-  }
+  const T v2 = M::fma(dx, dx, M::fma(dy, dy, dz * dz));
+  const bool degenerate = (s2 < T(10) * M::eps) || !(v2 > T(0));
+  const T rv = fast_rsqrt<T>(degenerate ? T(1) : v2);
   if (angle_f32) angle = (T)(float)angle;
-  if (angle > M::pi) angle -= T(2) * M::pi;
+  angle = angle > M::pi ? angle - T(2) * M::pi : angle;
   if (angle_f32) angle = (T)(float)angle;
-  const T rn = T(1) / M::sqrt(M::fma(a0, a0, M::fma(a1, a1, a2 * a2)));   // btVector3::normalize: *= 1/length
-  e[0] = angle * (a0 * rn);
-  e[1] = angle * (a1 * rn);
-  e[2] = angle * (a2 * rn);
+  e[0] = degenerate ? angle : angle * (dx * rv);
+  e[1] = degenerate ? T(0) : angle * (dy * rv);
+  e[2] = degenerate ? T(0) : angle * (dz * rv);
 }
 
 // One damped-least-squares update in the dual 6x6 form  dtheta = J^T (J J^T + lambda I)^-1 e,
@@ -292,10 +299,10 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
     dth[i] = s;
     mx = M::fmax(mx, M::fabs(s));
   });
-  if (mx > P.max_dtheta) {
-    const T sc = P.max_dtheta / mx;
-    static_for<0, NJ>([&](auto II) { constexpr int i = II; dth[i] *= sc; });
-  }
+  // Jacobian::MaxAngleDLS scale-back as a select (no branch: keeps the caller's update in one basic block)
+  const bool over = mx > P.max_dtheta;
+  const T sc = P.max_dtheta * fast_rcp<T>(over ? mx : T(1));
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; dth[i] = over ? dth[i] * sc : dth[i]; });
 }
 
 // The arm move of one env step.  With FROM_ACTION the Cartesian target is built from the first FK:
@@ -304,19 +311,40 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 //   for (i = 0; i < maxIter && currentDiff > residual; ++i) { currentDiff = |p(q) - tgt|; q += dls(q); }
 // Each trip of the loop below does exactly one FK; the trip that decides to stop leaves S = FK(q_final),
 // which is the post-step FK of _reward() (:271).  Returns the number of updates applied.
+// Per-section cycle accounting for the instrumented build (make timeline): s_memtime stamps around FK, orientation
+// error, DLS update and rotation advance, summed per wave into g_sections by lane 0.
+#ifdef ARMENV_TIMELINE
+__device__ unsigned long long g_sections[8];
+#define SEC_T0() unsigned long long sec_t = clock64()
+#define SEC_ADD(k)                                                                         \
+  do {                                                                                     \
+    const unsigned long long now_ = clock64();                                             \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sections[k], now_ - sec_t);                  \
+    sec_t = now_;                                                                          \
+  } while (0)
+#else
+#define SEC_T0()
+#define SEC_ADD(k)
+#endif
+
 template <class C, typename T, bool FROM_ACTION>
 AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
                    const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr) {
   using M = Mth<T>;
-  T diff_prev = T(1e30);
+  // the residual test |p - tgt| > residual is evaluated on squares (no sqrt on the loop-carried critical path)
+  const T res2 = P.residual * P.residual;
+  T diff2_prev = T(1e60);
   int it = 0;
   T cq[NJ], sq[NJ];
+  SEC_T0();
   sincos_all<T>(q, cq, sq);
+  SEC_ADD(0);
   // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced
   // incrementally, otherwise cos/sin are recomputed from q
   const bool small_steps = P.max_dtheta <= T(0.7854);
   for (;; ++it) {
     fk<C, T>(ch, cq, sq, S);
+    SEC_ADD(1);
     if constexpr (FROM_ACTION) {
       if (it == 0) {
         if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
@@ -333,21 +361,25 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     e[0] = tgt[0] - S.p[0];
     e[1] = tgt[1] - S.p[1];
     e[2] = tgt[2] - S.p[2];
-    const T diff = M::sqrt(M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2])));
-    const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff_prev > P.residual) : !(diff > P.residual));
+    const T diff2 = M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2]));
+    const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff2_prev > res2) : !(diff2 > res2));
     if (stop) break;
     T qc[4], eo[3], dth[NJ];
+    SEC_ADD(2);
     quat_from_frame<T>(S.W, qc);
     orientation_error<T>(P.tq, qc, P.angle_f32, eo);
     e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
+    SEC_ADD(3);
     dls_update<T>(S, e, P, dth);
+    SEC_ADD(4);
     static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
     if (small_steps) {
       static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
     } else {
       sincos_all<T>(q, cq, sq);
     }
-    diff_prev = diff;
+    diff2_prev = diff2;
+    SEC_ADD(5);
   }
   if (P.clamp_limits) {
     static_for<0, NJ>([&](auto II) {

@@ -30,3 +30,16 @@ for k in range(3):
     key=xcc*100000+se*1000+sh*100+cu
     u,c=np.unique(key,return_counts=True); print("   distinct CUs used:",len(u)," waves/CU hist:",np.bincount(c))
     key2=key*10+simd; u2,c2=np.unique(key2,return_counts=True); print("   distinct SIMDs:",len(u2)," waves/SIMD hist:",np.bincount(c2))
+
+# per-section cycle shares of the IK (s_memtime deltas summed over waves): rollout of 50 steps
+lib.armenv_dbg_sections.argtypes=[C.POINTER(C.c_uint64*8), C.c_int]
+buf=(C.c_uint64*8)(); lib.armenv_dbg_sections(C.byref(buf),1)
+a=torch.stack([acts[k%8] for k in range(50)]).contiguous()
+e.rollout(50,a); torch.cuda.synchronize()
+lib.armenv_dbg_sections(C.byref(buf),1)
+v=np.array(list(buf),dtype=np.float64); names=['sincos_all','fk','target+residual','quat+orient_err','dls_update','q+=,rotate']
+tot=v[:6].sum()
+c=e.counters()
+print('sections (cycles per wave per step, share):')
+for nme,x in zip(names,v): print(f'   {nme:18s} {x/1024/50:9.0f}  {100*x/tot:5.1f}%')
+print('   total', tot/1024/50, 'cycles per wave-step')
