@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--task", default="reach", choices=["reach", "push"],
                     help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768)")
-    ap.add_argument("--policy", default="external", choices=["external", "random", "actor"],
+    ap.add_argument("--policy", default="external", choices=["external", "random", "actor", "actor_f16x3"],
                     help="external = pre-generated actions in HBM (configs[1], headline); random / actor = fused in-kernel "
                          "policy (actor = configs[2]: TD3 actor forward folded into the rollout kernel)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
@@ -108,7 +108,7 @@ def main():
         args.mode = "rollout"
         bound, sig = (0.7, 0.7 * 0.98) if args.task == "reach" else (0.4, 0.4 * 0.98)
         sd = None
-        if args.policy == "actor":      # weights of TD3_MLP(6,3,0.7) under torch.manual_seed(0): golden G3
+        if args.policy.startswith("actor"):      # weights of TD3_MLP(6,3,0.7) under torch.manual_seed(0): golden G3
             g = np.load(os.path.join(ROOT, "tests", "golden", "td3_actor_seed0.npz"))
             sd = {k: torch.from_numpy(g[k.replace(".", "_")]) for k in
                   ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
@@ -227,11 +227,16 @@ def main():
                               "frac": flops / (launch_us * 1e-6) / 1e12 / (F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3)},
             "episodes_finished": counters["episodes"], "nonfinite_states": counters["nonfinite"],
         }
-        if args.policy == "actor":
+        if args.policy.startswith("actor"):
             # 2 * (6*256 + 256*256 + 256*3) flop per env-step; layer 2 on the f32 MFMA
             af = 2 * (6 * 256 + 256 * 256 + 256 * 3) * n * steps_per_launch
-            line["roofline_mfma"] = {"bound": "mfma", "achieved": af / (launch_us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                                     "frac": af / (launch_us * 1e-6) / 1e12 / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+            if args.policy == "actor":
+                peak, dt, mult = 157.3, "f32 (v_mfma_f32_32x32x2_f32)", 1
+            else:   # three f16 MFMA passes per useful multiply-add; priced against the dense f16 MFMA peak
+                peak, dt, mult = 2500.0, "f32 emulated by 3 x f16 (v_mfma_f32_32x32x16_f16, hi/lo split)", 3
+            line["roofline_mfma"] = {"bound": "mfma", "achieved": mult * af / (launch_us * 1e-6) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                     "frac": mult * af / (launch_us * 1e-6) / 1e12 / peak, "dtype": dt,
+                                     "useful_tflops": af / (launch_us * 1e-6) / 1e12}
         if step_api:
             line["step_api"] = step_api
         if world == 1 and not args.no_cpu_baseline:

@@ -8,7 +8,7 @@ ABI_VERSION = 1
 TASK_REACH, TASK_PUSH = 0, 1
 ROBOT_KUKA, ROBOT_DIANA = 0, 1
 FK_AUTO, FK_GENERIC = 0, 1
-POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR = 0, 1, 2
+POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR, POLICY_ACTOR_F16X3 = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libarmenv.so")

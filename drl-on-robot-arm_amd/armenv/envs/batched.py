@@ -122,11 +122,13 @@ class BatchedArmEnv:
 
     def set_policy(self, kind="random", action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7, actor_state_dict=None):
         """Install the fused exploration policy of main.py:116-117 for `rollout(actions=None)`:
-        a = clip(actor(obs) + N(0, noise_sigma), +-noise_clip).  kind: "external" | "random" | "actor"."""
-        code = {"external": L.POLICY_EXTERNAL, "random": L.POLICY_RANDOM, "actor": L.POLICY_ACTOR}[kind]
+        a = clip(actor(obs) + N(0, noise_sigma), +-noise_clip).  kind: "external" | "random" | "actor" (exact f32) |
+        "actor_f16x3" (layer 2 on the f16 MFMA with hi/lo operand splitting, ~1e-6 from f32)."""
+        code = {"external": L.POLICY_EXTERNAL, "random": L.POLICY_RANDOM, "actor": L.POLICY_ACTOR,
+                "actor_f16x3": L.POLICY_ACTOR_F16X3}[kind]
         w = [None] * 6
         hidden = 0
-        if code == L.POLICY_ACTOR:
+        if code in (L.POLICY_ACTOR, L.POLICY_ACTOR_F16X3):
             keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
             w = [actor_state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in keys]
             hidden = int(w[0].shape[0])

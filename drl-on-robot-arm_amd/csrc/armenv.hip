@@ -149,24 +149,38 @@ struct PolicyParams {
   float sigma;       // action_bound * opt.gamma = 0.686 in run()
   float clip;        // action_bound = 0.7
   float bound;       // actor output scale
-  ActorParams actor; // ARMENV_POLICY_ACTOR only
+  ActorParams actor; // ARMENV_POLICY_ACTOR / _F16X3
+  ActorParamsH actor_h;  // ARMENV_POLICY_ACTOR_F16X3 only
 };
 
-// TD3_MLP.take_action (/root/reference/algo/TD3/TD3_mlp.py:82-97) for n states, n a multiple of 64.
-template <int IN>
-__global__ __launch_bounds__(256) void actor_kernel(ActorParams A, int64_t n, const float *states, float *actions) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 64
+// TD3_MLP.take_action (/root/reference/algo/TD3/TD3_mlp.py:82-97) for n states; MODE 0 exact f32, 1 f16x3.
+template <int IN, int MODE>
+__global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH H, int64_t n, const float *states, float *actions) {
+  __shared__ float4 w1_lds[MODE == 1 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  if constexpr (MODE == 1) {
+    actor_stage_w1(A.W1P, w1_lds);
+    __syncthreads();
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 256
   const int64_t ic = i < n ? i : n - 1;
   float s[IN], a[3];
   static_for<0, IN>([&](auto DI) { constexpr int d = DI; s[d] = states[ic * IN + d]; });
-  actor_forward_wave<IN>(A, s, a);
+  if constexpr (MODE == 1) actor_forward_wave_f16x3<IN>(A, H, w1_lds, s, a);
+  else actor_forward_wave<IN>(A, s, a);
   if (i < n) { actions[3 * i] = a[0]; actions[3 * i + 1] = a[1]; actions[3 * i + 2] = a[2]; }
 }
 
 // torch Linear layouts ([out][in]) -> the operand layouts of armenv_actor.h
 __global__ void actor_pack_kernel(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
-                                  int in_dim, float *W1P, float *W2P, float *B2W3) {
+                                  int in_dim, float *W1P, float *W2P, float *B2W3, _Float16 *W2H, _Float16 *W2L) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ACTOR_HID * ACTOR_HID) {   // f16 hi/lo split of W2 in the 32x32x16 A-operand order
+    const int j = t & 7, lane = (t >> 3) & 63, nt = (t >> 9) & 3, part = (t >> 11) & 1, ks = t >> 12;
+    const float x = W2[(32 * (4 * part + nt) + (lane & 31)) * ACTOR_HID + 16 * ks + 8 * (lane >> 5) + j];
+    const _Float16 hi = (_Float16)x;
+    W2H[t] = hi;
+    W2L[t] = (_Float16)(x - (float)hi);
+  }
   if (t < ACTOR_HID * 12) {   // [kk][row k = 2kk + r][12] == [k][12]
     const int k = t / 12, j = t % 12;
     W1P[t] = j < in_dim ? W1[k * in_dim + j] : (j == 11 ? b1[k] : 0.f);
@@ -525,6 +539,11 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io
 template <class Lane, typename T, int POLICY>
 __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
                                                           const float *actions, StepIO io0, float *actions_out) {
+  __shared__ float4 w1_lds[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // the kernel's only LDS use and only barrier: W1, once
+    actor_stage_w1(pol.actor.W1P, w1_lds);
+    __syncthreads();
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const int64_t n = P.n;
@@ -532,7 +551,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   Lane L;
   L.load(P, i);
   uint32_t episode = (POLICY != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
-  if constexpr (POLICY == ARMENV_POLICY_ACTOR) L.refresh_obs(P);
+  if constexpr (POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3) L.refresh_obs(P);
   float an[3] = {0.f, 0.f, 0.f};
   if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2]; }
   for (int32_t t = 0; t < steps; ++t) {
@@ -549,6 +568,10 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
         float s[kObs];
         L.policy_obs(s);
         actor_forward_wave<kObs>(pol.actor, s, mu);                      // take_action, TD3_mlp.py:82-97
+      } else if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {
+        float s[kObs];
+        L.policy_obs(s);
+        actor_forward_wave_f16x3<kObs>(pol.actor, pol.actor_h, w1_lds, s, mu);
       }
       float nz[3];
       // the episode index of the stream is the number of resets so far minus one (the running episode)
@@ -747,10 +770,15 @@ static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + b
 int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                           const float *b3, int in_dim, float bound, hipStream_t s) {
   const size_t n1 = ACTOR_HID * 12, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
-  if (!actor_buf && hipMalloc(reinterpret_cast<void **>(&actor_buf), (n1 + n2 + n3) * sizeof(float)) != hipSuccess)
+  // f32 tables, then the two f16 tables (n2 halfs each = n2 floats together)
+  if (!actor_buf && hipMalloc(reinterpret_cast<void **>(&actor_buf), (n1 + n2 + n3 + n2) * sizeof(float)) != hipSuccess)
     return fail(ARMENV_ENOMEM, "armenv_set_policy: hipMalloc failed");
   float *W1P = actor_buf, *W2P = actor_buf + n1, *B2W3 = actor_buf + n1 + n2;
-  hipLaunchKernelGGL(actor_pack_kernel, dim3((unsigned)(n2 / 256)), dim3(256), 0, s, W1, b1, W2, b2, W3, in_dim, W1P, W2P, B2W3);
+  _Float16 *W2H = reinterpret_cast<_Float16 *>(actor_buf + n1 + n2 + n3), *W2L = W2H + n2;
+  hipLaunchKernelGGL(actor_pack_kernel, dim3((unsigned)(n2 / 256)), dim3(256), 0, s, W1, b1, W2, b2, W3, in_dim, W1P, W2P, B2W3,
+                     W2H, W2L);
+  pol.actor_h.W2H = reinterpret_cast<const half8 *>(W2H);
+  pol.actor_h.W2L = reinterpret_cast<const half8 *>(W2L);
   HIP_TRY(hipGetLastError());
   float hb3[3];
   HIP_TRY(hipMemcpyAsync(hb3, b3, sizeof hb3, hipMemcpyDeviceToHost, s));
@@ -767,8 +795,14 @@ int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, con
 int EngineBase::actor_forward(int64_t n, const float *states, float *actions, hipStream_t s) {
   if (!pol.actor.W2P) return fail(ARMENV_ESTATE, "armenv_actor_forward: no actor installed (armenv_set_policy)");
   const unsigned grid = (unsigned)((n + 255) / 256);
-  if (pol.actor.in_dim == 6) hipLaunchKernelGGL((actor_kernel<6>), dim3(grid), dim3(256), 0, s, pol.actor, n, states, actions);
-  else hipLaunchKernelGGL((actor_kernel<9>), dim3(grid), dim3(256), 0, s, pol.actor, n, states, actions);
+  const bool fast = pol.kind == ARMENV_POLICY_ACTOR_F16X3;
+  if (pol.actor.in_dim == 6) {
+    if (fast) hipLaunchKernelGGL((actor_kernel<6, 1>), dim3(grid), dim3(256), 0, s, pol.actor, pol.actor_h, n, states, actions);
+    else hipLaunchKernelGGL((actor_kernel<6, 0>), dim3(grid), dim3(256), 0, s, pol.actor, pol.actor_h, n, states, actions);
+  } else {
+    if (fast) hipLaunchKernelGGL((actor_kernel<9, 1>), dim3(grid), dim3(256), 0, s, pol.actor, pol.actor_h, n, states, actions);
+    else hipLaunchKernelGGL((actor_kernel<9, 0>), dim3(grid), dim3(256), 0, s, pol.actor, pol.actor_h, n, states, actions);
+  }
   HIP_TRY(hipGetLastError());
   return ARMENV_OK;
 }
@@ -889,6 +923,7 @@ template <class C, typename T> struct Engine final : EngineBase {
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     if (actions) launch_rollout<Lane, ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<Lane, ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
+    else if (pol.kind == ARMENV_POLICY_ACTOR_F16X3) launch_rollout<Lane, ARMENV_POLICY_ACTOR_F16X3>(steps, actions, io0, actions_out, s);
     else launch_rollout<Lane, ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
   }
   int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {
@@ -1140,11 +1175,11 @@ int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const fl
                       const float *b2_dev, const float *W3_dev, const float *b3_dev, int32_t hidden_dim, float action_bound,
                       float noise_sigma, float noise_clip, void *stream) {
   ENV_ENTER(env);
-  if (policy != ARMENV_POLICY_EXTERNAL && policy != ARMENV_POLICY_RANDOM && policy != ARMENV_POLICY_ACTOR)
+  if (policy < ARMENV_POLICY_EXTERNAL || policy > ARMENV_POLICY_ACTOR_F16X3)
     return fail(ARMENV_EINVAL, "armenv_set_policy: unknown policy %d", policy);
   if (policy != ARMENV_POLICY_EXTERNAL && !(noise_sigma >= 0.f && noise_clip > 0.f))
     return fail(ARMENV_EINVAL, "armenv_set_policy: need noise_sigma >= 0 and noise_clip > 0");
-  if (policy == ARMENV_POLICY_ACTOR) {
+  if (policy == ARMENV_POLICY_ACTOR || policy == ARMENV_POLICY_ACTOR_F16X3) {
     if (!W1_dev || !b1_dev || !W2_dev || !b2_dev || !W3_dev || !b3_dev) return fail(ARMENV_EINVAL, "armenv_set_policy: NULL weight pointer");
     if (hidden_dim != ACTOR_HID)
       return fail(ARMENV_EINVAL, "armenv_set_policy: hidden_dim %d; the fused actor is built for %d (config.py:56)", hidden_dim, ACTOR_HID);

@@ -133,4 +133,153 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float (&s)[IN], float
   });
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fast variant: layer 2 on the f16 MFMA (v_mfma_f32_32x32x16_f16, 16x the f32 MFMA rate) with both operands split
+// x = hi + lo, hi = f16(x), lo = f16(x - hi), and three passes  hi*hi + hi*lo + lo*hi  accumulated in f32.  f16 products
+// are exact in f32, so only the lo*lo term (2^-22 relative) and f32 accumulation order separate the result from the
+// exact-f32 path above: within the 1e-5 actor tolerance of the reference's vectors (tests).  Measured: 45 us for 65 536
+// envs standalone (196 TF useful = 590 TF of f16 MFMA; a streamed-operand f16 MFMA probe reaches ~1000 TF, fixed
+// operands 1570 TF), 52 us per fused env step against 113 us for the exact-f32 actor.
+// Same transposed decomposition; per k-step of 16 a lane supplies 8 consecutive k of its env column, so layer 1 is
+// evaluated 8 rows at a time with W1 (12 KB) staged ONCE per workgroup in LDS (the only LDS use and the only barrier
+// of the kernel, before the step loop).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#ifndef ACTOR_F16_NT
+#define ACTOR_F16_NT 4
+#endif
+
+struct ActorParamsH {
+  const half8 *W2H;    // [16 ks][8 tile][64 lane]: W2[32 tile + (lane&31)][16 ks + 8 (lane>>5) + j], j = 0..7 -- hi
+  const half8 *W2L;    //   same, lo
+};
+
+constexpr int ACTOR_W1_LDS_FLOATS = ACTOR_HID * 12;
+
+// copy W1P (global, [256][12] f32) into LDS; every thread of the block must call this once, then __syncthreads()
+AE_DEV void actor_stage_w1(const float *W1P, float4 *lds) {
+  for (int i = threadIdx.x; i < ACTOR_W1_LDS_FLOATS / 4; i += blockDim.x) lds[i] = reinterpret_cast<const float4 *>(W1P)[i];
+}
+
+template <int IN>
+AE_DEV void actor_forward_wave_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, const float (&s)[IN],
+                                     float (&out)[3]) {
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5;
+  float sA[IN], sB[IN];
+  static_for<0, IN>([&](auto DI) {
+    constexpr int d = DI;
+    const float other = __shfl_xor(s[d], 32);
+    sA[d] = half ? other : s[d];
+    sB[d] = half ? s[d] : other;
+  });
+  float p[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  constexpr int NT = ACTOR_F16_NT;            // neuron tiles per pass: 8 = single pass (256 accumulators), 4 = two passes
+  constexpr int NPASS = 8 / NT;
+#pragma unroll 1
+  for (int part = 0; part < NPASS; ++part) {
+    f32x16 acc[NT][2];
+    static_for<0, NT>([&](auto NI) {
+      constexpr int nt = NI;
+      static_for<0, 16>([&](auto RI) { constexpr int r = RI; acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f; });
+    });
+    half8 ah[NT], al[NT], nh[NT], nl[NT];
+    auto load_a = [&](int ks, half8 (&h)[NT], half8 (&l)[NT]) {
+      const int kc = ks < 16 ? ks : 15;
+      // table order is [ks][tile 0..7][lane]; pass `part` covers tiles NT*part .. NT*part + NT-1
+      const int base = (kc * 8 + NT * part) * 64 + lane;
+      static_for<0, NT>([&](auto NI) { constexpr int nt = NI; h[nt] = H.W2H[base + nt * 64]; l[nt] = H.W2L[base + nt * 64]; });
+    };
+    // B operands: h1 of the lane's two env columns for k = 16 ks + 8 half + j (j = 0..7), split into f16 hi / lo.
+    // Row j of the step is built in three pieces so that the pieces can be placed between MFMAs (below).
+    auto row_load = [&](int ks, int j, float4 &ra, float4 &rb, float4 &rc) {
+      const int kc = ks < 16 ? ks : 15;
+      const float4 *row = w1_lds + (16 * kc + 8 * half + j) * 3;
+      ra = row[0]; rb = row[1]; rc = row[2];
+    };
+    auto row_dot = [&](const float4 &ra, const float4 &rb, const float4 &rc, const float (&sv)[IN]) {
+      const float w[9] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc.x};
+      float h = rc.w;
+      static_for<0, IN>([&](auto DI) { constexpr int d = DI; h = fmaf(w[d], sv[d], h); });
+      return fmaxf(h, 0.f);
+    };
+    half8 bh[2], bl[2], bh_n[2], bl_n[2];
+    load_a(0, ah, al);
+    static_for<0, 8>([&](auto JI) {
+      constexpr int j = JI;
+      float4 ra, rb, rc;
+      row_load(0, j, ra, rb, rc);
+      const float hA = row_dot(ra, rb, rc, sA), hB = row_dot(ra, rb, rc, sB);
+      const _Float16 ha = (_Float16)hA, hb = (_Float16)hB;
+      bh[0][j] = ha; bl[0][j] = (_Float16)(hA - (float)ha);
+      bh[1][j] = hb; bl[1][j] = (_Float16)(hB - (float)hb);
+    });
+#pragma unroll 1
+    for (int ks = 0; ks < 16; ++ks) {
+      load_a(ks + 1, nh, nl);                               // A operands of the next k-step, in flight under the MFMAs
+      // Software pipeline, pinned by sched_barrier(0): the 6*NT MFMAs of k-step ks are issued one at a time with a
+      // slice of the layer-1 VALU / LDS work for k-step ks+1 behind each, so the VALU runs while the matrix pipe is
+      // busy (an in-order wave cannot overlap the two phases otherwise; left alone hipcc emits them back to back).
+      float4 ra, rb, rc, na, nb, nc;
+      row_load(ks + 1, 0, ra, rb, rc);
+      static_for<0, 8>([&](auto JI) {
+        constexpr int j = JI;
+        constexpr int m0 = 3 * j;                            // MFMA slots of this row: m0, m0+1, m0+2 (of 6*NT)
+        auto mfma = [&](auto MI) {
+          constexpr int m = MI;
+          if constexpr (m < 6 * NT) {
+            // order: pass (hi*hi, hi*lo, lo*hi) outermost, so consecutive MFMAs never share an accumulator -- three
+            // back-to-back MFMAs on one accumulator each wait out the full dependent latency (measured 103 instead
+            // of 32 cycles per MFMA)
+            constexpr int k3 = m / (2 * NT), nt = (m % (2 * NT)) / 2, t = m % 2;
+            acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al[nt] : ah[nt], k3 == 1 ? bl[t] : bh[t], acc[nt][t], 0, 0, 0);
+          }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(std::integral_constant<int, m0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const float hA = row_dot(ra, rb, rc, sA);
+        const _Float16 ha = (_Float16)hA;
+        bh_n[0][j] = ha; bl_n[0][j] = (_Float16)(hA - (float)ha);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(std::integral_constant<int, m0 + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j < 7) row_load(ks + 1, j + 1, na, nb, nc);
+        const float hB = row_dot(ra, rb, rc, sB);
+        const _Float16 hb = (_Float16)hB;
+        bh_n[1][j] = hb; bl_n[1][j] = (_Float16)(hB - (float)hb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(std::integral_constant<int, m0 + 2>{});
+        ra = na; rb = nb; rc = nc;
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<24, 6 * NT>([&](auto MI) {                  // NT = 8: the remaining MFMAs (none for NT = 4)
+        constexpr int m = MI;
+        constexpr int k3 = m / (2 * NT), nt = (m % (2 * NT)) / 2, t = m % 2;
+        acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al[nt] : ah[nt], k3 == 1 ? bl[t] : bh[t], acc[nt][t], 0, 0, 0);
+      });
+      static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah[nt] = nh[nt]; al[nt] = nl[nt]; });
+      bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
+    }
+    static_for<0, NT>([&](auto NI) {
+      constexpr int nt = NI;
+      static_for<0, 16>([&](auto RI) {
+        constexpr int r = RI;
+        const int n = 32 * (NT * part + nt) + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float4 c = A.B2W3[n];
+        const float h0 = fmaxf(acc[nt][0][r] + c.x, 0.f);
+        const float h1 = fmaxf(acc[nt][1][r] + c.x, 0.f);
+        p[0][0] = fmaf(c.y, h0, p[0][0]); p[0][1] = fmaf(c.z, h0, p[0][1]); p[0][2] = fmaf(c.w, h0, p[0][2]);
+        p[1][0] = fmaf(c.y, h1, p[1][0]); p[1][1] = fmaf(c.z, h1, p[1][1]); p[1][2] = fmaf(c.w, h1, p[1][2]);
+      });
+    });
+  }
+  static_for<0, 3>([&](auto OI) {
+    constexpr int o = OI;
+    const float t0 = p[0][o] + __shfl_xor(p[0][o], 32);
+    const float t1 = p[1][o] + __shfl_xor(p[1][o], 32);
+    const float z = (half ? t1 : t0) + A.b3[o];
+    out[o] = tanhf(z) * A.bound;
+  });
+}
+
 }  // namespace armenv

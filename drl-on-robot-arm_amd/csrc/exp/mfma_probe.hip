@@ -80,7 +80,55 @@ template <int NACC> void run_mem(const char *name, int blocks, bool zeros) {
   printf("%-34s blocks %4d: %.3f ms  %.1f TF  shader clock %.2f GHz  %.0f shader cycles/MFMA\n", name, blocks, ms,
          mf * 4096 / (ms * 1e-3) / 1e12, ghz, (double)hc[0] / ((double)iters * NACC));
 }
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+template <int NACC, int MODE>
+__global__ __launch_bounds__(256) void probe_h(float *out, const half8 *tab, int iters) {
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const int lane = threadIdx.x & 63;
+  half8 a[4], b[2];
+  for (int i = 0; i < 4; ++i) a[i] = tab[i * 64 + lane];
+  for (int i = 0; i < 2; ++i) b[i] = tab[(4 + i) * 64 + lane];
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 1) {   // stream A operands from memory
+      for (int i = 0; i < 4; ++i) a[i] = tab[((it & 15) * 8 + i) * 64 + lane];
+    }
+    if (MODE == 2) {   // perturb B with VALU
+      for (int i = 0; i < 2; ++i) b[i][it & 7] = (_Float16)((float)b[i][it & 7] * 0.999f);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[i & 1], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC, int MODE> void run_h(const char *name, int blocks, bool zeros) {
+  float *out; hipMalloc(&out, sizeof(float) * blocks * 256);
+  half8 *tab; hipMalloc(&tab, 16 * 16 * 8 * 64);
+  _Float16 *h = new _Float16[16 * 8 * 64 * 8];
+  unsigned x = 777;
+  for (int i = 0; i < 16 * 8 * 64 * 8; ++i) { x = x * 1664525u + 1013904223u; h[i] = zeros ? (_Float16)0.f : (_Float16)(((x >> 8) * (1.f / 8388608.f) - 1.f) * 0.1f); }
+  hipMemcpy(tab, h, 16 * 8 * 64 * 8 * 2, hipMemcpyHostToDevice);
+  const int iters = 4096;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  probe_h<NACC, MODE><<<blocks, 256>>>(out, tab, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  probe_h<NACC, MODE><<<blocks, 256>>>(out, tab, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double mf = (double)blocks * 4 * iters * NACC;
+  printf("f16 32x32x16 %-30s blocks %4d: %.3f ms  %.0f TF  %.0f ns-cycles@2.4/MFMA/SIMD\n", name, blocks, ms, mf * 32768 / (ms * 1e-3) / 1e12,
+         ms * 1e-3 * 2.4e9 / ((double)iters * NACC) / ((blocks * 4) / 1024.0 > 1 ? (blocks * 4) / 1024.0 : 1));
+}
 int main() {
+  run_h<8, 0>("fixed operands, random data", 256, false);
+  run_h<8, 0>("fixed operands, zero data", 256, true);
+  run_h<8, 1>("A streamed, random", 256, false);
+  run_h<8, 2>("B perturbed by VALU", 256, false);
+  run_h<8, 0>("fixed, 2 waves/SIMD", 512, false);
+
   run_mem<8>("mem operands, random data", 256, false);
   run_mem<8>("mem operands, zero data", 256, true);
   run_mem<8>("mem operands, random, 2 waves/SIMD", 512, false);

@@ -49,7 +49,12 @@ enum {
 enum { ARMENV_TASK_REACH = 0, ARMENV_TASK_PUSH = 1 };
 enum { ARMENV_ROBOT_KUKA = 0, ARMENV_ROBOT_DIANA = 1 };
 enum { ARMENV_FK_AUTO = 0, ARMENV_FK_GENERIC = 1 };
-enum { ARMENV_POLICY_EXTERNAL = 0, ARMENV_POLICY_RANDOM = 1, ARMENV_POLICY_ACTOR = 2 };
+enum {
+  ARMENV_POLICY_EXTERNAL = 0,
+  ARMENV_POLICY_RANDOM = 1,
+  ARMENV_POLICY_ACTOR = 2,        /* TD3 actor, exact f32 (layer 2 on the f32-input MFMA) */
+  ARMENV_POLICY_ACTOR_F16X3 = 3   /* same actor, layer 2 on the f16 MFMA with 3-pass hi/lo operand splitting (~1e-6) */
+};
 
 typedef struct ArmEnv ArmEnv;
 

@@ -705,6 +705,36 @@ def test_actor_forward_matches_reference_golden(envs, O):
     e.close()
 
 
+def test_actor_f16x3_within_tolerance_of_reference(envs, O):
+    """Fast actor variant (f16 MFMA, hi/lo operand split, three passes): still within the 1e-5 actor tolerance of the
+    reference's golden vectors; and usable as the fused rollout policy."""
+    g, sd = _golden_actor()
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    e = _mk(envs, 256, seed=31, max_steps=20)
+    e.set_policy("actor_f16x3", action_bound=float(g["action_bound"]), noise_sigma=0.1, noise_clip=0.7, actor_state_dict=tsd)
+    for n in (1024, 777, 1):
+        a = _np(e.actor_forward(torch.from_numpy(g["states"][:n])))
+        assert np.abs(a - g["actions"][:n]).max() < 1e-5
+    rng = np.random.default_rng(81)
+    big = {"fc1.weight": rng.normal(0, 0.8, (256, 6)), "fc1.bias": rng.normal(0, 0.3, 256),
+           "fc2.weight": rng.normal(0, 0.09, (256, 256)) * np.linspace(0.5, 1.5, 256)[None, :], "fc2.bias": rng.normal(0, 0.2, 256),
+           "fc3.weight": rng.normal(0, 0.12, (3, 256)), "fc3.bias": rng.normal(0, 0.1, 3)}
+    big = {k: v.astype(np.float32) for k, v in big.items()}
+    st = rng.uniform(-1, 1, (640, 6)).astype(np.float32)
+    e2 = _mk(envs, 64)
+    e2.set_policy("actor_f16x3", action_bound=0.7, actor_state_dict={k: torch.from_numpy(v) for k, v in big.items()})
+    assert np.abs(_np(e2.actor_forward(torch.from_numpy(st))) - O.actor_forward(big, st, 0.7)).max() < 1e-5
+    e2.close()
+    # as the fused policy: same trajectory as the exact-f32 actor to within the step tolerance
+    ref = _mk(envs, 256, seed=31, max_steps=20)
+    ref.set_policy("actor", action_bound=0.7, noise_sigma=0.1, noise_clip=0.7, actor_state_dict=tsd)
+    e.reset(); ref.reset()
+    oa = e.rollout(30, None, want_actions=True); ob = ref.rollout(30, None, want_actions=True)
+    assert float((oa["actions"] - ob["actions"]).abs().max()) < 2e-5
+    assert torch.equal(oa["done"], ob["done"]) and float((oa["obs"] - ob["obs"]).abs().max()) < 1e-5
+    e.close(); ref.close()
+
+
 def test_actor_forward_asymmetric_weights(envs, O):
     """Transpose-detecting check of the MFMA operand/accumulator maps: random, non-symmetric weights with a
     distinct scale per layer, and biases that make about half the units fire."""

@@ -1,11 +1,14 @@
 import sys, time; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/drl-on-robot-arm_amd')
 import numpy as np, torch
+from armenv import _lib as L
+import os
+if len(sys.argv)>2: L.LIB_PATH=sys.argv[2]
 from armenv import envs
 g=np.load('/root/repo/tests/golden/td3_actor_seed0.npz')
 sd={k: torch.from_numpy(g[k.replace('.','_')]) for k in ("fc1.weight","fc1.bias","fc2.weight","fc2.bias","fc3.weight","fc3.bias")}
 for prec in (64,32):
     e=envs.BatchedReachEnv(65536, device='cuda:0', precision=prec)
-    e.set_policy('actor', actor_state_dict=sd)
+    e.set_policy(sys.argv[1] if len(sys.argv)>1 else 'actor', actor_state_dict=sd)
     for n in (65536, 131072, 262144):
         s=torch.rand(n,6,device='cuda:0')
         for _ in range(3): e.actor_forward(s)
