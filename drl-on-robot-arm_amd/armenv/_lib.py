@@ -44,7 +44,8 @@ class ArmEnvConfig(C.Structure):
 
 class ArmEnvHerArgs(C.Structure):
     _fields_ = [
-        ("T", C.c_int64), ("N", C.c_int64), ("obs_dim", C.c_int32), ("use_her", C.c_int32),
+        ("T", C.c_int64), ("N", C.c_int64), ("ring_base", C.c_int64), ("ring_cap", C.c_int64),
+        ("obs_dim", C.c_int32), ("use_her", C.c_int32),
         ("obs0_dev", C.c_void_p), ("obs_after_dev", C.c_void_p), ("next_obs_dev", C.c_void_p), ("action_dev", C.c_void_p),
         ("reward_dev", C.c_void_p), ("done_dev", C.c_void_p), ("episodes_dev", C.c_void_p), ("num_episodes_dev", C.c_void_p),
         ("batch", C.c_int64), ("picks_dev", C.c_void_p), ("seed", C.c_uint64), ("draw", C.c_uint64),
@@ -73,8 +74,8 @@ SYMBOLS = {
     "armenv_counters": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8), _P]),
     "armenv_set_policy": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
     "armenv_actor_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
-    "armenv_count_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P]),
-    "armenv_write_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P, _P, _P]),
+    "armenv_count_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P]),
+    "armenv_write_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P, _P, _P]),
     "armenv_her_sample": (C.c_int, [C.c_int32, C.POINTER(ArmEnvHerArgs), _P]),
     "armenv_num_envs": (C.c_int64, [_P]),
     "armenv_obs_dim": (C.c_int32, [_P]),

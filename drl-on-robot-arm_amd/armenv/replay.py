@@ -14,41 +14,75 @@ def _p(t):
 
 
 class TrajectoryStore:
-    """One rollout chunk of N envs x T steps.  ``size()`` = number of complete episodes (what the reference calls
-    trajectories); ``sample(batch_size, use_her, dis_threshold, her_ratio)`` returns a dict of device tensors with the
-    reference's keys."""
+    """A time-major ring of the last ``capacity_steps`` env steps of N envs (the reference's deque keeps the last
+    `capacity` trajectories, rl_utils.py:109-113).  ``size()`` = number of complete episodes currently in the window;
+    ``sample(batch_size, use_her, dis_threshold, her_ratio)`` returns device tensors under the reference's keys."""
 
-    def __init__(self, device="cuda:0", seed=0):
+    def __init__(self, device="cuda:0", seed=0, capacity_steps=None):
         self.device = torch.device(device)
         self._lib = L.load()
         self.seed = int(seed)
         self._draw = 0
+        self.capacity = capacity_steps
         self.chunk = None
+        self._ring = None
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def add_rollout(self, obs0, out, actions=None, starts_at_reset=True):
-        """obs0: observation [N, D] before the rollout's first step (what reset()/the previous step returned);
-        out: the dict returned by ``env.rollout(..., want_terminal_obs=True)`` (needs obs, terminal_obs, reward, done_u8
-        and actions -- pass ``actions`` when the policy was external)."""
+        """Append a rollout chunk.  obs0: observation [N, D] before the chunk's first step (only used when the window
+        starts at a reset); out: the dict returned by ``env.rollout(..., want_terminal_obs=True)`` (obs, terminal_obs,
+        reward, done_u8, and actions unless `actions` is given).  Without ``capacity_steps`` the store holds exactly
+        this chunk (zero-copy); with it, chunks accumulate in a ring and the oldest steps fall out."""
         acts = actions if actions is not None else out["actions"]
-        obs_after, next_obs = out["obs"], out["terminal_obs"]
-        T, N, D = obs_after.shape
-        done = out["done_u8"]
+        src = dict(obs_after=out["obs"], next_obs=out["terminal_obs"], action=acts, reward=out["reward"], done=out["done_u8"])
+        Tc, N, D = src["obs_after"].shape
+        if self.capacity is None:
+            self._ring = dict(cap=Tc, base=0, T=Tc, N=N, D=D, obs0=obs0.contiguous(), at_reset=bool(starts_at_reset),
+                              **{k: v.contiguous() for k, v in src.items()})
+        else:
+            r = self._ring
+            if r is None:
+                cap = int(self.capacity)
+                if cap < Tc:
+                    raise ValueError("capacity_steps smaller than one rollout chunk")
+                r = dict(cap=cap, base=0, T=0, N=N, D=D, obs0=obs0.clone(), at_reset=bool(starts_at_reset))
+                for k, v in src.items():
+                    r[k] = torch.empty((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+                self._ring = r
+            cap = r["cap"]
+            drop = max(0, r["T"] + Tc - cap)                   # oldest steps that fall out of the window
+            if drop:
+                r["base"] = (r["base"] + drop) % cap
+                r["T"] -= drop
+                r["at_reset"] = False                         # the window now starts mid-episode
+            w = (r["base"] + r["T"]) % cap                     # physical row of the first new step
+            first = min(Tc, cap - w)
+            for k, v in src.items():
+                r[k][w:w + first].copy_(v[:first])
+                if first < Tc:
+                    r[k][: Tc - first].copy_(v[first:])
+            r["T"] += Tc
+        self._index()
+
+    def _index(self):
+        r = self._ring
         dev = self.device.index or 0
+        T, N = r["T"], r["N"]
         counts = torch.empty(N, dtype=torch.int32, device=self.device)
-        L.check(self._lib.armenv_count_episodes(dev, T, N, _p(done), int(bool(starts_at_reset)), _p(counts), self._stream()))
+        L.check(self._lib.armenv_count_episodes(dev, T, N, r["base"], r["cap"], _p(r["done"]), int(r["at_reset"]), _p(counts),
+                                                self._stream()))
         offsets = torch.cumsum(counts, 0, dtype=torch.int64)
-        episodes = torch.empty((T * N, 3), dtype=torch.int32, device=self.device)   # upper bound: one episode per step
-        L.check(self._lib.armenv_write_episodes(dev, T, N, _p(done), int(bool(starts_at_reset)), _p(counts), _p(offsets),
-                                                _p(episodes), self._stream()))
-        self.chunk = dict(T=T, N=N, D=D, obs0=obs0.contiguous(), obs_after=obs_after, next_obs=next_obs, action=acts.contiguous(),
-                          reward=out["reward"], done=done, episodes=episodes, num_episodes=offsets[-1:].contiguous(),
-                          counts=counts, offsets=offsets)
+        if r.get("episodes") is None or r["episodes"].shape[0] < T * N:
+            r["episodes"] = torch.empty((r["cap"] * N, 3), dtype=torch.int32, device=self.device)   # bound: one per step
+        L.check(self._lib.armenv_write_episodes(dev, T, N, r["base"], r["cap"], _p(r["done"]), int(r["at_reset"]), _p(counts),
+                                                _p(offsets), _p(r["episodes"]), self._stream()))
+        r["num_episodes"] = offsets[-1:].contiguous()
+        self.chunk = r
 
     def size(self):
-        """number of complete episodes (host sync)"""
+        """number of complete episodes in the window (host sync)"""
         return 0 if self.chunk is None else int(self.chunk["num_episodes"].item())
 
     def sample(self, batch_size, use_her=True, dis_threshold=0.1, her_ratio=0.8, picks=None, return_picks=False):
@@ -57,7 +91,7 @@ class TrajectoryStore:
             raise RuntimeError("TrajectoryStore.sample: no rollout stored")
         B, D, dev = int(batch_size), ch["D"], self.device
         a = L.ArmEnvHerArgs()
-        a.T, a.N, a.obs_dim, a.use_her = ch["T"], ch["N"], D, int(bool(use_her))
+        a.T, a.N, a.ring_base, a.ring_cap, a.obs_dim, a.use_her = ch["T"], ch["N"], ch["base"], ch["cap"], D, int(bool(use_her))
         a.obs0_dev, a.obs_after_dev, a.next_obs_dev = ch["obs0"].data_ptr(), ch["obs_after"].data_ptr(), ch["next_obs"].data_ptr()
         a.action_dev, a.reward_dev, a.done_dev = ch["action"].data_ptr(), ch["reward"].data_ptr(), ch["done"].data_ptr()
         a.episodes_dev, a.num_episodes_dev = ch["episodes"].data_ptr(), ch["num_episodes"].data_ptr()

@@ -1,0 +1,96 @@
+"""Batched TD3 learner on PyTorch-ROCm tensors: the counterpart of
+/root/reference/algo/TD3/TD3_mlp.py:33-161 + net_mlp.py:29-71 that consumes device-resident HER batches
+(armenv.replay.TrajectoryStore.sample) without a host round trip and hands its actor to the env engine for fused
+rollouts (BatchedArmEnv.set_policy).  Stock torch ops: the learner is integration, not a kernel."""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Actor(nn.Module):
+    """a = bound * tanh(fc3(relu(fc2(relu(fc1(s))))))   (net_mlp.py:29-40; parameter names fc1/fc2/fc3 so that a
+    reference state_dict loads unchanged)"""
+
+    def __init__(self, state_dim, hidden_dim, action_dim, action_bound):
+        super().__init__()
+        self.fc1, self.fc2, self.fc3 = nn.Linear(state_dim, hidden_dim), nn.Linear(hidden_dim, hidden_dim), nn.Linear(hidden_dim, action_dim)
+        self.action_bound = action_bound
+
+    def forward(self, s):
+        return torch.tanh(self.fc3(F.relu(self.fc2(F.relu(self.fc1(s)))))) * self.action_bound
+
+
+class TwinCritic(nn.Module):
+    """two Q heads over cat(state, action) in one module (net_mlp.py:43-71; fc1-3 = Q1, fc4-6 = Q2)"""
+
+    def __init__(self, state_dim, hidden_dim, action_dim):
+        super().__init__()
+        d = state_dim + action_dim
+        self.fc1, self.fc2, self.fc3 = nn.Linear(d, hidden_dim), nn.Linear(hidden_dim, hidden_dim), nn.Linear(hidden_dim, 1)
+        self.fc4, self.fc5, self.fc6 = nn.Linear(d, hidden_dim), nn.Linear(hidden_dim, hidden_dim), nn.Linear(hidden_dim, 1)
+
+    def q1(self, s, a):
+        x = torch.cat([s, a], dim=1)
+        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+
+    def forward(self, s, a):
+        x = torch.cat([s, a], dim=1)
+        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x))))), self.fc6(F.relu(self.fc5(F.relu(self.fc4(x)))))
+
+
+class TD3:
+    """Hyper-parameters default to config.py:55-73 (hidden 256, lr 1e-3, tau 0.005, gamma 0.98, policy noise 0.2,
+    clip 0.5, delayed actor update every 3 critic updates)."""
+
+    def __init__(self, state_dim, action_dim, action_bound, hidden_dim=256, actor_lr=1e-3, critic_lr=1e-3, tau=0.005,
+                 gamma=0.98, policy_noise=0.2, noise_clip=0.5, policy_freq=3, device="cuda:0"):
+        self.device = torch.device(device)
+        self.actor = Actor(state_dim, hidden_dim, action_dim, action_bound).to(self.device)       # creation order as
+        self.critic = TwinCritic(state_dim, hidden_dim, action_dim).to(self.device)               # TD3_mlp.py:61-64
+        self.target_actor = Actor(state_dim, hidden_dim, action_dim, action_bound).to(self.device)
+        self.target_critic = TwinCritic(state_dim, hidden_dim, action_dim).to(self.device)
+        self.target_critic.load_state_dict(self.critic.state_dict())
+        self.target_actor.load_state_dict(self.actor.state_dict())
+        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=actor_lr)
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=critic_lr)
+        self.tau, self.gamma, self.action_bound = tau, gamma, action_bound
+        self.policy_noise, self.noise_clip, self.policy_freq = policy_noise, noise_clip, policy_freq
+        self.total_it = 0
+
+    @torch.no_grad()
+    def _soft_update(self, net, target):
+        for pt, p in zip(target.parameters(), net.parameters()):
+            pt.mul_(1.0 - self.tau).add_(p, alpha=self.tau)
+
+    def train(self, batch):
+        """One TD3 update from a dict of device tensors: states [B,D], actions [B,3], next_states [B,D], rewards [B],
+        dones [B] (any dtype).  Returns the critic loss as a 0-dim tensor (no host sync).  TD3_mlp.py:114-161."""
+        s = batch["states"].to(self.device, torch.float32)
+        a = batch["actions"].to(self.device, torch.float32)
+        r = batch["rewards"].to(self.device, torch.float32).view(-1, 1)
+        s2 = batch["next_states"].to(self.device, torch.float32)
+        d = batch["dones"].to(self.device, torch.float32).view(-1, 1)
+        self.total_it += 1
+        with torch.no_grad():
+            noise = (torch.randn_like(a) * self.policy_noise).clamp(-self.noise_clip, self.noise_clip)
+            a2 = (self.target_actor(s2) + noise).clamp(-self.action_bound, self.action_bound)
+            tq1, tq2 = self.target_critic(s2, a2)
+            target_q = r + (1 - d) * self.gamma * torch.min(tq1, tq2)
+        q1, q2 = self.critic(s, a)
+        critic_loss = F.mse_loss(q1, target_q) + F.mse_loss(q2, target_q)
+        self.critic_opt.zero_grad()
+        critic_loss.backward()
+        self.critic_opt.step()
+        if self.total_it % self.policy_freq == 0:
+            actor_loss = -self.critic.q1(s, self.actor(s)).mean()
+            self.actor_opt.zero_grad()
+            actor_loss.backward()
+            self.actor_opt.step()
+            self._soft_update(self.actor, self.target_actor)
+            self._soft_update(self.critic, self.target_critic)
+        return critic_loss.detach()
+
+    def actor_state_dict(self):
+        return {k: v.detach() for k, v in self.actor.state_dict().items()}

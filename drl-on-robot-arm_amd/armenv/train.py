@@ -1,0 +1,77 @@
+"""On-device training loop: the reference's ``run()`` (/root/reference/main.py:77-162) with its four stages kept on the
+GPU -- fused-actor rollouts (armenv_rollout), trajectory store + HER batches (armenv_her_sample), TD3 updates (torch),
+success accounting (armenv_counters).  One iteration = `rollout_steps` env steps of `num_envs` envs followed by
+`updates` TD3 steps; the reference does 40 updates of 256 samples after every (<= 501-step) episode of its single env.
+
+    python -m armenv.train --iterations 200
+"""
+import argparse
+import json
+import time
+
+import torch
+
+from . import envs
+from .replay import TrajectoryStore
+from .td3 import TD3
+
+
+def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
+                device="cuda:0", actor_kind="actor_f16x3", expl_sigma=0.7 * 0.98, log_every=10, log=print,
+                window_steps=1536, minimal_episodes=5, max_steps=500):
+    torch.manual_seed(seed)
+    action_bound = 0.7                                            # main.py:87
+    env = envs.BatchedReachEnv(num_envs, device=device, seed=seed, max_steps=max_steps)
+    agent = TD3(6, 3, action_bound, device=device)
+    store = TrajectoryStore(device=device, seed=seed, capacity_steps=window_steps)   # last `window_steps` steps of every env
+    ready = False
+    obs = env.reset()
+    history = []
+    c_prev = env.counters()
+    t0 = time.perf_counter()
+    bufs = {}
+    for it in range(iterations):
+        # take_action + exploration noise + step, fused (main.py:114-124)
+        env.set_policy(actor_kind, action_bound=action_bound, noise_sigma=expl_sigma, noise_clip=action_bound,
+                       actor_state_dict=agent.actor_state_dict())
+        obs0 = obs.clone()
+        out = env.rollout(rollout_steps, None, out=bufs, want_actions=True, want_terminal_obs=True)
+        obs = out["obs"][-1]
+        store.add_rollout(obs0, out, starts_at_reset=(it == 0))    # traj.store_step / add_trajectory (main.py:128-129)
+        if not ready:                                             # replay_buffer.size() >= minimal_episodes, main.py:135
+            ready = store.size() >= minimal_episodes
+        if ready:
+            for _ in range(updates):                              # main.py:136-138
+                agent.train(store.sample(batch_size, use_her=True, her_ratio=her_ratio))
+        if (it + 1) % log_every == 0:
+            c = env.counters()
+            ep = c["episodes"] - c_prev["episodes"]
+            rate = (c["successes"] - c_prev["successes"]) / max(1, ep)
+            c_prev = c
+            rec = dict(iteration=it + 1, env_steps=c["env_steps"], episodes=c["episodes"], success_rate=rate,
+                       wall_s=time.perf_counter() - t0)
+            history.append(rec)
+            log(json.dumps(rec))
+    env.close()
+    return agent, history
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-envs", type=int, default=1024)
+    ap.add_argument("--iterations", type=int, default=200)
+    ap.add_argument("--rollout-steps", type=int, default=32)
+    ap.add_argument("--updates", type=int, default=48)
+    ap.add_argument("--batch-size", type=int, default=2048)
+    ap.add_argument("--actor", default="actor_f16x3", choices=["actor", "actor_f16x3"])
+    ap.add_argument("--sigma", type=float, default=0.7 * 0.98)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--window-steps", type=int, default=1536)
+    ap.add_argument("--max-steps", type=int, default=500, help="opt.max_steps_one_episode")
+    a = ap.parse_args()
+    train_reach(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
+                expl_sigma=a.sigma, window_steps=a.window_steps, max_steps=a.max_steps)
+
+
+if __name__ == "__main__":
+    main()

@@ -1220,23 +1220,25 @@ int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *
   DeviceGuard guard_(device);                                                          \
   if (!guard_.ok) return fail(ARMENV_ENODEV, "%s: hipSetDevice(%d) failed", __func__, (int)(device))
 
-int armenv_count_episodes(int32_t device, int64_t T, int64_t N, const uint8_t *done_dev, int32_t starts_at_reset,
-                          int32_t *counts_dev, void *stream) {
+int armenv_count_episodes(int32_t device, int64_t T, int64_t N, int64_t ring_base, int64_t ring_cap, const uint8_t *done_dev,
+                          int32_t starts_at_reset, int32_t *counts_dev, void *stream) {
   DEV_ENTER(device);
-  if (T < 0 || N < 1 || !done_dev || !counts_dev) return fail(ARMENV_EINVAL, "armenv_count_episodes: bad arguments");
+  if (T < 0 || N < 1 || ring_cap < T || ring_cap < 1 || ring_base < 0 || !done_dev || !counts_dev)
+    return fail(ARMENV_EINVAL, "armenv_count_episodes: bad arguments");
   hipLaunchKernelGGL(index_episodes_kernel, dim3(grid_for(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), T, N,
-                     done_dev, starts_at_reset, counts_dev, (const int64_t *)nullptr, (int32_t *)nullptr);
+                     ring_base, ring_cap, done_dev, starts_at_reset, counts_dev, (const int64_t *)nullptr, (int32_t *)nullptr);
   HIP_TRY(hipGetLastError());
   return ARMENV_OK;
 }
 
-int armenv_write_episodes(int32_t device, int64_t T, int64_t N, const uint8_t *done_dev, int32_t starts_at_reset,
-                          const int32_t *counts_dev, const int64_t *offsets_dev, int32_t *episodes_dev, void *stream) {
+int armenv_write_episodes(int32_t device, int64_t T, int64_t N, int64_t ring_base, int64_t ring_cap, const uint8_t *done_dev,
+                          int32_t starts_at_reset, const int32_t *counts_dev, const int64_t *offsets_dev,
+                          int32_t *episodes_dev, void *stream) {
   DEV_ENTER(device);
-  if (T < 0 || N < 1 || !done_dev || !counts_dev || !offsets_dev || !episodes_dev)
+  if (T < 0 || N < 1 || ring_cap < T || ring_cap < 1 || ring_base < 0 || !done_dev || !counts_dev || !offsets_dev || !episodes_dev)
     return fail(ARMENV_EINVAL, "armenv_write_episodes: bad arguments");
   hipLaunchKernelGGL(index_episodes_kernel, dim3(grid_for(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), T, N,
-                     done_dev, starts_at_reset, const_cast<int32_t *>(counts_dev), offsets_dev, episodes_dev);
+                     ring_base, ring_cap, done_dev, starts_at_reset, const_cast<int32_t *>(counts_dev), offsets_dev, episodes_dev);
   HIP_TRY(hipGetLastError());
   return ARMENV_OK;
 }
@@ -1245,7 +1247,8 @@ int armenv_her_sample(int32_t device, const ArmEnvHerArgs *a, void *stream) {
   DEV_ENTER(device);
   if (!a) return fail(ARMENV_EINVAL, "armenv_her_sample: args is NULL");
   if (a->obs_dim != 6 && a->obs_dim != 9) return fail(ARMENV_EINVAL, "armenv_her_sample: obs_dim must be 6 or 9");
-  if (a->batch < 0 || a->T < 1 || a->N < 1) return fail(ARMENV_EINVAL, "armenv_her_sample: bad sizes");
+  if (a->batch < 0 || a->T < 1 || a->N < 1 || a->ring_cap < a->T || a->ring_base < 0)
+    return fail(ARMENV_EINVAL, "armenv_her_sample: bad sizes");
   if (!a->obs0_dev || !a->obs_after_dev || !a->next_obs_dev || !a->action_dev || !a->reward_dev || !a->done_dev ||
       !a->episodes_dev || !a->num_episodes_dev || !a->states_dev || !a->actions_dev || !a->next_states_dev ||
       !a->rewards_dev || !a->dones_dev)
@@ -1253,7 +1256,7 @@ int armenv_her_sample(int32_t device, const ArmEnvHerArgs *a, void *stream) {
   if (!(a->her_ratio >= 0.f && a->her_ratio <= 1.f)) return fail(ARMENV_EINVAL, "armenv_her_sample: her_ratio outside [0,1]");
   if (a->batch == 0) return ARMENV_OK;
   HerArgs h;
-  h.T = a->T; h.N = a->N; h.D = a->obs_dim;
+  h.T = a->T; h.N = a->N; h.ring_base = a->ring_base; h.ring_cap = a->ring_cap; h.D = a->obs_dim;
   h.obs0 = a->obs0_dev; h.obs_after = a->obs_after_dev; h.next_obs = a->next_obs_dev; h.action = a->action_dev;
   h.reward = a->reward_dev; h.done = a->done_dev; h.episodes = a->episodes_dev; h.num_episodes = a->num_episodes_dev;
   h.B = a->batch; h.picks_in = a->picks_dev; h.seed = a->seed; h.draw = a->draw; h.use_her = a->use_her;

@@ -20,7 +20,9 @@ namespace armenv {
 
 // pass 1: number of complete episodes per env column; pass 2 (write != nullptr): emit (env, t_start, length).
 // `starts_at_reset`: the chunk began right after a reset of every env, so the first episode's start is inside it.
-__global__ __launch_bounds__(256) void index_episodes_kernel(int64_t T, int64_t N, const uint8_t *done, int32_t starts_at_reset,
+// The buffers may be a ring: logical step t lives in physical row (ring_base + t) % ring_cap (ring_cap >= T).
+__global__ __launch_bounds__(256) void index_episodes_kernel(int64_t T, int64_t N, int64_t ring_base, int64_t ring_cap,
+                                                            const uint8_t *done, int32_t starts_at_reset,
                                                             int32_t *counts, const int64_t *offsets, int32_t *episodes) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void index_episodes_kernel(int64_t T, int64_t 
   int64_t start = starts_at_reset ? 0 : -1;
   int64_t w = episodes ? (offsets[n] - (int64_t)counts[n]) : 0;   // offsets = inclusive cumsum of counts
   for (int64_t t = 0; t < T; ++t) {
-    if (done[t * N + n]) {
+    if (done[((ring_base + t) % ring_cap) * N + n]) {
       if (start >= 0) {
         if (episodes) {
           int32_t *e = episodes + 3 * w;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void index_episodes_kernel(int64_t T, int64_t 
 }
 
 struct HerArgs {
-  int64_t T, N;
+  int64_t T, N, ring_base, ring_cap;
   int32_t D;                 // 6 reach, 9 push
   const float *obs0, *obs_after, *next_obs, *action, *reward;
   const uint8_t *done;
@@ -69,7 +71,14 @@ __global__ __launch_bounds__(256) void her_sample_kernel(HerArgs A) {
   if (A.picks_in) {
     ep = A.picks_in[4 * b]; st = A.picks_in[4 * b + 1]; her = A.picks_in[4 * b + 2]; sg = A.picks_in[4 * b + 3];
   } else {
-    if (E <= 0) return;
+    if (E <= 0) {   // nothing to sample from: a defined, inert batch
+      for (int k = 0; k < D; ++k) { A.states[b * D + k] = 0.f; A.next_states[b * D + k] = 0.f; }
+      A.actions[3 * b] = A.actions[3 * b + 1] = A.actions[3 * b + 2] = 0.f;
+      A.rewards[b] = 0.f;
+      A.dones[b] = 1;
+      if (A.picks_out) { A.picks_out[4 * b] = -1; A.picks_out[4 * b + 1] = A.picks_out[4 * b + 2] = A.picks_out[4 * b + 3] = 0; }
+      return;
+    }
     double u0, u1, u2, u3;
     philox_pair(A.seed, (uint64_t)b, (uint32_t)A.draw, 0u, u0, u1);
     philox_pair(A.seed, (uint64_t)b, (uint32_t)A.draw, 1u, u2, u3);
@@ -81,11 +90,12 @@ __global__ __launch_bounds__(256) void her_sample_kernel(HerArgs A) {
   }
   const int32_t *e = A.episodes + 3 * ep;
   const int64_t n = e[0], t0 = e[1];
-  const int64_t t = t0 + st;                                // chunk time of the transition
+  auto row = [&](int64_t lt) { return (A.ring_base + lt) % A.ring_cap; };   // logical step -> physical row
+  const int64_t t = row(t0 + st);                           // physical row of the transition
   auto state_ptr = [&](int64_t j) -> const float * {        // traj.states[j]
-    const int64_t tt = t0 + j;                              // states[j] is the observation before chunk step tt
-    if (j == 0) return tt == 0 ? A.obs0 + n * D : A.obs_after + ((tt - 1) * A.N + n) * D;
-    return A.next_obs + ((tt - 1) * A.N + n) * D;
+    const int64_t tt = t0 + j;                              // states[j] is the observation before logical step tt
+    if (j == 0) return tt == 0 ? A.obs0 + n * D : A.obs_after + (row(tt - 1) * A.N + n) * D;
+    return A.next_obs + (row(tt - 1) * A.N + n) * D;
   };
   const float *s = state_ptr(st), *s2 = state_ptr(st + 1);
   float sv[D], nv[D];

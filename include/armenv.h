@@ -214,14 +214,17 @@ int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float 
 /* Episode index, two passes around a caller-side inclusive prefix sum (e.g. torch.cumsum) of counts:
  *   armenv_count_episodes -> counts_dev i32 [N];   offsets = inclusive cumsum(counts) as i64 [N];
  *   armenv_write_episodes -> episodes_dev i32 [E][3] = (env, t_start, length), E = offsets[N-1].
- * starts_at_reset != 0: every env was reset right before step 0 of the chunk. */
-int armenv_count_episodes(int32_t device, int64_t T, int64_t N, const uint8_t *done_dev, int32_t starts_at_reset,
-                          int32_t *counts_dev, void *stream);
-int armenv_write_episodes(int32_t device, int64_t T, int64_t N, const uint8_t *done_dev, int32_t starts_at_reset,
-                          const int32_t *counts_dev, const int64_t *offsets_dev, int32_t *episodes_dev, void *stream);
+ * starts_at_reset != 0: every env was reset right before step 0 of the chunk.
+ * The [T] axis may be a ring of ring_cap >= T physical rows: logical step t (0 = oldest kept) lives in physical row
+ * (ring_base + t) % ring_cap; a plain chunk is ring_base = 0, ring_cap = T. */
+int armenv_count_episodes(int32_t device, int64_t T, int64_t N, int64_t ring_base, int64_t ring_cap, const uint8_t *done_dev,
+                          int32_t starts_at_reset, int32_t *counts_dev, void *stream);
+int armenv_write_episodes(int32_t device, int64_t T, int64_t N, int64_t ring_base, int64_t ring_cap, const uint8_t *done_dev,
+                          int32_t starts_at_reset, const int32_t *counts_dev, const int64_t *offsets_dev,
+                          int32_t *episodes_dev, void *stream);
 
 typedef struct ArmEnvHerArgs {
-  int64_t T, N;
+  int64_t T, N, ring_base, ring_cap;
   int32_t obs_dim;            /* 6: reach relabel rule (rl_utils.py:140-141); 9: push rule (:187-188) */
   int32_t use_her;
   const float *obs0_dev, *obs_after_dev, *next_obs_dev, *action_dev, *reward_dev;

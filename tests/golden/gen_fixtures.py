@@ -17,6 +17,8 @@ reference's importable Python (config, algo.TD3) -- never reference source text.
                                envs/rl_reach_env.py:299-309 (strict '>' and '<')
   G6 her_{reach,push}_seed0.npz  ReplayBuffer_Trajectory_{reach,push}.sample outputs + the draws it made
                                (utils/rl_utils.py:108-199), produced by importing the reference
+  G8 td3_train_seed0.npz       six TD3_MLP.train() updates of the reference: losses + final parameters
+                               (algo/TD3/TD3_mlp.py:114-161), produced by importing the reference
   G7 push_reward_truth.json    (cube, target, d_last, step_counter) -> (reward, done, is_success) of
                                envs/rl_push_env.py:387-432 with its float32 / float64 mix
 """
@@ -245,6 +247,34 @@ def g6_her_samples():
                  dones=np.array(outs["dones"], np.uint8))
 
 
+def g8_td3_train():
+    """G8: six TD3_MLP.train() updates of the reference (algo/TD3/TD3_mlp.py:114-161) from torch.manual_seed(0)
+    initialisation on fixed batches: critic losses and the final actor / critic / target parameters."""
+    sys.path.insert(0, REF)
+    import torch
+    from algo.TD3.TD3_mlp import TD3_MLP
+    torch.manual_seed(0)
+    agent = TD3_MLP(6, 3, 0.7, device=torch.device("cpu"))
+    rng = np.random.default_rng(8)
+    B = 64
+    batches = []
+    for _ in range(6):
+        st = rng.uniform(0.2, 0.6, (B, 6)).astype(np.float32)
+        ns = st.copy(); ns[:, :3] += rng.normal(0, 0.01, (B, 3)).astype(np.float32)
+        batches.append(dict(states=st, actions=rng.uniform(-0.7, 0.7, (B, 3)).astype(np.float32), next_states=ns,
+                            rewards=rng.choice([-0.1, 1.0], B).astype(np.float32), dones=rng.integers(0, 2, B).astype(np.uint8)))
+    torch.manual_seed(123)          # target-policy smoothing noise stream
+    losses = [float(agent.train({k: v.tolist() if k in ("rewards", "dones") else v for k, v in b.items()})) for b in batches]
+    out = {"losses": np.array(losses)}
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            out[f"b{i}_{k}"] = v
+    for name, net in (("actor", agent.actor), ("critic", agent.critic), ("target_actor", agent.target_actor), ("target_critic", agent.target_critic)):
+        for k, v in net.state_dict().items():
+            out[f"{name}__{k.replace('.', '_')}"] = v.detach().numpy().copy()
+    np.savez(os.path.join(OUT, "td3_train_seed0.npz"), **out)
+
+
 if __name__ == "__main__":
-    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples()
+    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train()
     print("fixtures written to", OUT)

@@ -877,3 +877,50 @@ def test_rollout_into_store_end_to_end(envs):
     # consecutive states of a transition differ by one bounded arm move (dv * 0.7 per axis + IK residual)
     assert float((b["next_states"][:, :3] - b["states"][:, :3]).abs().max()) < 0.02 * 0.7 + 2e-3
     e.close()
+
+
+def test_trajectory_ring_matches_linear_window(envs):
+    """Chunks accumulated in a ring (capacity smaller than the total) give the same episode index and the same samples
+    as the restatement run on the equivalent linear window."""
+    from armenv.replay import TrajectoryStore
+    from oracle import her
+    n, Tc, cap = 192, 25, 80
+    e = _mk(envs, n, seed=6, max_steps=17)                       # 18-step episodes
+    e.set_policy("random")
+    obs = e.reset()
+    st = TrajectoryStore(device=DEV, seed=2, capacity_steps=cap)
+    keep = []
+    for c in range(6):                                           # 150 steps through an 80-step ring (wraps twice)
+        obs0 = obs.clone()
+        out = e.rollout(Tc, None, want_actions=True, want_terminal_obs=True)
+        obs = out["obs"][-1].clone()
+        st.add_rollout(obs0, out, starts_at_reset=(c == 0))
+        keep.append({k: _np(out[k]).copy() for k in ("obs", "terminal_obs", "actions", "reward", "done_u8")})
+        cat = lambda k: np.concatenate([x[k] for x in keep])
+        tot = len(keep) * Tc
+        lo = max(0, tot - cap) if tot > cap else 0
+        # the ring drops whole overflow: window = last min(tot, cap) steps
+        T = min(tot, cap)
+        lo = tot - T
+        ch = dict(obs0=_np(obs0) * 0, obs_after=cat("obs")[lo:], next_obs=cat("terminal_obs")[lo:], action=cat("actions")[lo:],
+                  reward=cat("reward")[lo:], done=cat("done_u8")[lo:])
+        if lo == 0:
+            ch["obs0"] = _np(st.chunk["obs0"])
+        eps = her.index_episodes(ch["done"], starts_at_reset=(lo == 0))
+        assert st.chunk["T"] == T and st.size() == len(eps)
+        assert np.array_equal(_np(st.chunk["episodes"])[: len(eps)], eps)
+        b = st.sample(4096, use_her=True, return_picks=True)
+        ref = her.sample_with_picks(ch, eps, _np(b["picks"]), 0.1)
+        for k in ("states", "next_states", "actions", "dones"):
+            assert np.array_equal(_np(b[k]), ref[k]), (c, k)
+        assert np.abs(_np(b["rewards"]) - ref["rewards"]).max() < 1e-7
+    assert st.size() > n
+    # an empty window yields an inert, defined batch
+    empty = TrajectoryStore(device=DEV, seed=2, capacity_steps=40)
+    e2 = _mk(envs, 64, seed=1)
+    e2.set_policy("random"); o0 = e2.reset().clone()
+    empty.add_rollout(o0, e2.rollout(10, None, want_actions=True, want_terminal_obs=True))
+    assert empty.size() == 0
+    z = empty.sample(32, return_picks=True)
+    assert int(z["picks"][:, 0].max()) == -1 and float(z["states"].abs().max()) == 0.0 and bool((z["dones"] == 1).all())
+    e.close(); e2.close()

@@ -133,3 +133,24 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
                 txt = open(os.path.join(dp, fn)).read()
                 assert "oracle" not in txt.lower(), os.path.join(dp, fn)
+
+
+def test_td3_learner_matches_reference_golden():
+    """G8: the reference's TD3_MLP.train (algo/TD3/TD3_mlp.py:114-161), six updates from torch.manual_seed(0) on fixed
+    batches (two delayed actor updates + soft target updates included): same losses and parameters on CPU."""
+    import torch
+    from conftest import golden_npz
+    from armenv.td3 import TD3
+    g = golden_npz("td3_train_seed0.npz")
+    torch.manual_seed(0)
+    agent = TD3(6, 3, 0.7, device="cpu")
+    torch.manual_seed(123)
+    for i, want in enumerate(g["losses"]):
+        b = {k: torch.from_numpy(g[f"b{i}_{k}"]) for k in ("states", "actions", "next_states", "rewards", "dones")}
+        loss = float(agent.train(b))
+        assert abs(loss - want) < 1e-5 * max(1.0, abs(want)), (i, loss, want)
+    for name, net in (("actor", agent.actor), ("critic", agent.critic), ("target_actor", agent.target_actor), ("target_critic", agent.target_critic)):
+        for k, v in net.state_dict().items():
+            ref = g[f"{name}__{k.replace('.', '_')}"]
+            assert np.abs(v.numpy() - ref).max() < 1e-5, (name, k)
+    assert agent.total_it == 6
