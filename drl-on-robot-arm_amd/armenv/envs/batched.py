@@ -100,6 +100,9 @@ class BatchedArmEnv:
             L.check(self._lib.armenv_reset(self._h, _ptr(m), _ptr(self._obs), self._stream()))
         else:
             g = goal.to(device=self.device, dtype=torch.float32).contiguous()
+            want = (self.num_envs, 3 if self.task == L.TASK_REACH else 6)     # push: [cube xyz, target xyz]
+            if tuple(g.shape) != want:
+                raise ValueError(f"goal must have shape {want}")
             L.check(self._lib.armenv_reset_with_goal(self._h, _ptr(m), _ptr(g), _ptr(self._obs), self._stream()))
         return self._obs
 
