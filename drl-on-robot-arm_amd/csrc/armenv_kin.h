@@ -136,9 +136,14 @@ AE_DEV void rotate_small(T &c, T &s, T d) {
 }
 
 // reciprocal: v_rcp + two Newton steps (f64) / one (f32); used where a few-ulp quotient is enough (LDL^T pivots)
+AE_DEV double hw_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+AE_DEV float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+AE_DEV double hw_rsq(double x) { return __builtin_amdgcn_rsq(x); }
+AE_DEV float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 template <typename T>
 AE_DEV T fast_rcp(T d) {
-  T r = __builtin_amdgcn_rcp(d);
+  T r = hw_rcp(d);
   r = Mth<T>::fma(Mth<T>::fma(-d, r, T(1)), r, r);
   if constexpr (sizeof(T) == 8) r = Mth<T>::fma(Mth<T>::fma(-d, r, T(1)), r, r);
   return r;
@@ -148,7 +153,7 @@ AE_DEV T fast_rcp(T d) {
 // sqrt-then-divide pair (each a long quarter-rate sequence in f64)
 template <typename T>
 AE_DEV T fast_rsqrt(T x) {
-  T r = __builtin_amdgcn_rsq(x);
+  T r = hw_rsq(x);
   const T hx = T(0.5) * x;
   r = Mth<T>::fma(Mth<T>::fma(-hx * r, r, T(0.5)), r, r);
   if constexpr (sizeof(T) == 8) r = Mth<T>::fma(Mth<T>::fma(-hx * r, r, T(0.5)), r, r);
