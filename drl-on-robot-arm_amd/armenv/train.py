@@ -56,8 +56,48 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
     return agent, history
 
 
+def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
+               device="cuda:0", actor_kind="actor_f16x3", log_every=10, log=print, window_steps=1536, minimal_episodes=5,
+               max_steps=500):
+    """``train_push_with_TD3`` (/root/reference/main.py:449-515) on the device: state_dim 9, action_bound 0.4 (:455-457),
+    unclipped exploration noise N(0, 0.4 * 0.98) (:484), push HER relabel rule (utils/rl_utils.py:171-188).  The cube
+    follows the build's simplified push-out model, so learning curves are not comparable with the reference's."""
+    torch.manual_seed(seed)
+    action_bound = 0.4
+    env = envs.BatchedPushEnv(num_envs, device=device, seed=seed, max_steps=max_steps)
+    agent = TD3(9, 3, action_bound, device=device)
+    store = TrajectoryStore(device=device, seed=seed, capacity_steps=window_steps)
+    obs = env.reset()
+    history, ready, bufs = [], False, {}
+    c_prev = env.counters()
+    t0 = time.perf_counter()
+    for it in range(iterations):
+        env.set_policy(actor_kind, action_bound=action_bound, noise_sigma=action_bound * 0.98, noise_clip=1e9,
+                       actor_state_dict=agent.actor_state_dict())
+        obs0 = obs.clone()
+        out = env.rollout(rollout_steps, None, out=bufs, want_actions=True, want_terminal_obs=True)
+        obs = out["obs"][-1]
+        store.add_rollout(obs0, out, starts_at_reset=(it == 0))
+        if not ready:
+            ready = store.size() >= minimal_episodes
+        if ready:
+            for _ in range(updates):
+                agent.train(store.sample(batch_size, use_her=True, her_ratio=her_ratio))
+        if (it + 1) % log_every == 0:
+            c = env.counters()
+            ep = c["episodes"] - c_prev["episodes"]
+            rec = dict(iteration=it + 1, env_steps=c["env_steps"], episodes=c["episodes"],
+                       success_rate=(c["successes"] - c_prev["successes"]) / max(1, ep), wall_s=time.perf_counter() - t0)
+            c_prev = c
+            history.append(rec)
+            log(json.dumps(rec))
+    env.close()
+    return agent, history
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="reach", choices=["reach", "push"])
     ap.add_argument("--num-envs", type=int, default=1024)
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--rollout-steps", type=int, default=32)
@@ -69,6 +109,10 @@ def main():
     ap.add_argument("--window-steps", type=int, default=1536)
     ap.add_argument("--max-steps", type=int, default=500, help="opt.max_steps_one_episode")
     a = ap.parse_args()
+    if a.task == "push":
+        train_push(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
+                   window_steps=a.window_steps, max_steps=a.max_steps)
+        return
     train_reach(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
                 expl_sigma=a.sigma, window_steps=a.window_steps, max_steps=a.max_steps)
 
