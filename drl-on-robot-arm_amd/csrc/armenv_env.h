@@ -1,0 +1,661 @@
+// armenv_env.h -- device side of the env engine: per-env state layout (EnvParams), the per-lane env bodies (ReachLane,
+// PushLane), and the kernels built from them: reset, one-step, T-step rollout with optional fused policy, FK / IK
+// entry kernels, state exchange, actor entry + weight packing.  Host side and C ABI: armenv.hip.
+#pragma once
+#include "../../include/armenv.h"
+#include "armenv_kin.h"
+#include "armenv_actor.h"
+
+using namespace armenv;
+
+
+template <typename T> struct EnvParams {
+  // state
+  T *q;
+  T *ep_return;
+  T *last_return;
+  float *goal;
+  int32_t *step;
+  uint32_t *episode;
+  int32_t *last_len;
+  uint8_t *last_success;
+  unsigned long long *counters;
+  T *aux;  // push only: [7][N] = cube xyz, target xyz, d_last
+  int64_t n;
+  // task constants
+  T dv;
+  T reach_dis;
+  int32_t max_steps;
+  int32_t auto_reset;
+  T box_lo[3];
+  T box_hi[3];
+  double goal_lo[3];
+  double goal_hi[3];
+  T q_init[NJ];
+  T p_init[3];  // FK(q_init), computed on the device at create time
+  uint64_t seed;
+  uint64_t env_id0;
+  // push task (rl_push_env.py): simplified pusher model + reward constants
+  T push_success_dis, push_cube_half, push_eef_radius;
+  double push_rest_z, push_place_min, push_place_max;
+  IKParams<T> ik;
+  ChainDev<T> chain;
+};
+
+struct StepIO {
+  const float *action;
+  float *obs;
+  float *reward;
+  uint8_t *done;
+  uint8_t *success;
+  float *terminal_obs;
+};
+
+// goal ~ U(box): a + (b - a) * u per axis as random.uniform does (rl_reach_env.py:180-182), then the
+// f32 cast of :213-215.  Always f64 arithmetic so that both precisions draw identical goals.
+template <typename T>
+AE_DEV void sample_goal(const EnvParams<T> &P, int64_t i, uint32_t episode, float (&g)[3]) {
+  double u0, u1, u2, u3;
+  philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 0u, u0, u1);
+  philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 1u, u2, u3);
+  g[0] = (float)(P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u0);
+  g[1] = (float)(P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u1);
+  g[2] = (float)(P.goal_lo[2] + (P.goal_hi[2] - P.goal_lo[2]) * u2);
+}
+
+template <typename T>
+AE_DEV void store_obs6(float *obs, int64_t i, const T (&p)[3], const float (&g)[3]) {
+  float2 *o = reinterpret_cast<float2 *>(obs + 6 * i);  // 24 B rows: 8-byte aligned
+  o[0] = make_float2((float)p[0], (float)p[1]);
+  o[1] = make_float2((float)p[2], g[0]);
+  o[2] = make_float2(g[1], g[2]);
+}
+
+template <typename T>
+AE_DEV void store_obs9(float *obs, int64_t i, const T (&p)[3], const T (&c)[3], const T (&t)[3]) {
+  float *o = obs + 9 * i;
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; o[k] = (float)p[k]; o[3 + k] = (float)c[k]; o[6 + k] = (float)t[k]; });
+}
+
+// FK(q_init) once per handle, with the same device code the step uses.
+template <class C, typename T>
+__global__ void init_consts_kernel(EnvParams<T> P, T *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  T q[NJ];
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = P.q_init[i]; });
+  FKState<T> S;
+  T cq[NJ], sq[NJ];
+  sincos_all<T>(q, cq, sq);
+  fk<C, T>(P.chain, cq, sq, S);
+  out[0] = S.p[0]; out[1] = S.p[1]; out[2] = S.p[2];
+}
+
+// RLReachEnv.reset (rl_reach_env.py:132-217) for masked envs.
+template <typename T>
+__global__ __launch_bounds__(256) void reach_reset_kernel(EnvParams<T> P, const uint8_t *mask, const float *goal_in,
+                                                          float *obs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (mask && !mask[i]) return;
+  float g[3];
+  if (goal_in) {
+    g[0] = goal_in[3 * i]; g[1] = goal_in[3 * i + 1]; g[2] = goal_in[3 * i + 2];
+  } else {
+    const uint32_t ep = P.episode[i];
+    sample_goal(P, i, ep, g);
+    P.episode[i] = ep + 1u;
+  }
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.q_init[j]; });
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = g[k]; });
+  P.step[i] = 0;
+  P.ep_return[i] = T(0);
+  if (obs) store_obs6<T>(obs, i, P.p_init, g);
+}
+
+// Optional per-wave timeline (make timeline; csrc/exp/run_timeline.py): wall-clock stamps at kernel entry, after
+// the state loads, after the IK loop and at exit, plus IK update count and placement.  Off in the product build.
+#ifdef ARMENV_TIMELINE
+__device__ unsigned long long *g_timeline;
+#define TL_STAMP(name) const unsigned long long name = wall_clock64()
+#else
+#define TL_STAMP(name)
+#endif
+
+// Fused exploration policy of the rollout loop (/root/reference/main.py:116-117):
+//   a = clip(actor(obs) + N(0, sigma), +-clip);  kind RANDOM = zero actor.
+struct PolicyParams {
+  int32_t kind;      // ARMENV_POLICY_*
+  float sigma;       // action_bound * opt.gamma = 0.686 in run()
+  float clip;        // action_bound = 0.7
+  float bound;       // actor output scale
+  ActorParams actor; // ARMENV_POLICY_ACTOR / _F16X3
+  ActorParamsH actor_h;  // ARMENV_POLICY_ACTOR_F16X3 only
+};
+
+// TD3_MLP.take_action (/root/reference/algo/TD3/TD3_mlp.py:82-97) for n states; MODE 0 exact f32, 1 f16x3.
+template <int IN, int MODE>
+__global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH H, int64_t n, const float *states, float *actions) {
+  __shared__ float4 w1_lds[MODE == 1 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  if constexpr (MODE == 1) {
+    actor_stage_w1(A.W1P, w1_lds);
+    __syncthreads();
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 256
+  const int64_t ic = i < n ? i : n - 1;
+  float s[IN], a[3];
+  static_for<0, IN>([&](auto DI) { constexpr int d = DI; s[d] = states[ic * IN + d]; });
+  if constexpr (MODE == 1) actor_forward_wave_f16x3<IN>(A, H, w1_lds, s, a);
+  else actor_forward_wave<IN>(A, s, a);
+  if (i < n) { actions[3 * i] = a[0]; actions[3 * i + 1] = a[1]; actions[3 * i + 2] = a[2]; }
+}
+
+// torch Linear layouts ([out][in]) -> the operand layouts of armenv_actor.h
+__global__ void actor_pack_kernel(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                                  int in_dim, float *W1P, float *W2P, float *B2W3, _Float16 *W2H, _Float16 *W2L) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ACTOR_HID * ACTOR_HID) {   // f16 hi/lo split of W2 in the 32x32x16 A-operand order
+    const int j = t & 7, lane = (t >> 3) & 63, nt = (t >> 9) & 3, part = (t >> 11) & 1, ks = t >> 12;
+    const float x = W2[(32 * (4 * part + nt) + (lane & 31)) * ACTOR_HID + 16 * ks + 8 * (lane >> 5) + j];
+    const _Float16 hi = (_Float16)x;
+    W2H[t] = hi;
+    W2L[t] = (_Float16)(x - (float)hi);
+  }
+  if (t < ACTOR_HID * 12) {   // [kk][row k = 2kk + r][12] == [k][12]
+    const int k = t / 12, j = t % 12;
+    W1P[t] = j < in_dim ? W1[k * in_dim + j] : (j == 11 ? b1[k] : 0.f);
+  }
+  if (t < ACTOR_HID * ACTOR_HID) {
+    const int c = t & 3, l32 = (t >> 2) & 31, part = (t >> 7) & 1, k = t >> 8;
+    W2P[t] = W2[(32 * (4 * part + c) + l32) * ACTOR_HID + k];
+  }
+  if (t < ACTOR_HID * 4) {
+    const int n = t >> 2, c = t & 3;
+    B2W3[t] = c == 0 ? b2[n] : W3[(c - 1) * ACTOR_HID + n];
+  }
+}
+
+// Three N(0,1) draws for (env, episode, step): Philox block 0x80000000|step of the env's stream (reset draws use
+// blocks < 2^31), Box-Muller in f32 on u = (w + 1) * 2^-32 in (0, 1].
+AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step, float (&nz)[3]) {
+  uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), episode, 0x80000000u | step};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)c[0] + 1.0f) * k, u1 = (float)c[1] * k, u2 = ((float)c[2] + 1.0f) * k, u3 = (float)c[3] * k;
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  nz[0] = r0 * c0; nz[1] = r0 * s0; nz[2] = r1 * c1;
+  (void)s1;
+}
+
+// Per-lane state of one reach env and the body of one env step.  The single-step kernel and the T-step rollout
+// kernel both run this code, so a rollout is bit-identical to T step launches.
+template <class C, typename T> struct ReachLane {
+  using M = Mth<T>;
+  static constexpr int kObs = 6;
+  T q[NJ];
+  float g[3];
+  int32_t step;
+  T ep_ret;
+  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;   // flushed to the handle's counters once per launch
+
+  AE_DEV void load(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * n + i]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; g[k] = P.goal[(int64_t)k * n + i]; });
+    step = P.step[i];
+    ep_ret = P.ep_return[i];
+  }
+
+  AE_DEV void store(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
+    P.step[i] = step;
+    P.ep_return[i] = ep_ret;
+    if (n_done) atomicAdd(&P.counters[0], (unsigned long long)n_done);
+    if (n_succ) atomicAdd(&P.counters[1], (unsigned long long)n_succ);
+    if (n_bad) atomicAdd(&P.counters[3], (unsigned long long)n_bad);
+    // one add per wave for the IK-update total (wave reduction first)
+    if (__ballot(1) == ~0ull) {
+      unsigned u = n_upd;
+      for (int o = 32; o; o >>= 1) u += __shfl_xor(u, o);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[4], (unsigned long long)u);
+    } else if (n_upd) {   // ragged last wave
+      atomicAdd(&P.counters[4], (unsigned long long)n_upd);
+    }
+  }
+
+  // RLReachEnv.step + _reward (rl_reach_env.py:219-319) with action a; writes row i of the caller's buffers.
+  // Returns the number of IK updates.
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io) {
+    const int64_t n = P.n;
+    FKState<T> S;
+    T tgt[3];
+    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
+
+    n_upd += (uint32_t)updates;
+    step += 1;                                                                    // :264
+    const T dx = S.p[0] - (T)g[0], dy = S.p[1] - (T)g[1], dz = S.p[2] - (T)g[2];
+    const T dist = M::sqrt(M::fma(dx, dx, M::fma(dy, dy, dz * dz)));              // :281
+    T reward;
+    bool done, succ;
+    if (step > P.max_steps) { reward = -dist * T(10); done = true; succ = false; }          // :299-301
+    else if (dist < P.reach_dis) { reward = T(0); done = true; succ = true; }               // :303-306
+    else { reward = -dist * T(10); done = false; succ = false; }                            // :307-309
+    ep_ret += reward;
+
+    bool finite = true;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
+    if (!finite) n_bad += 1;
+
+    io.reward[i] = (float)reward;
+    io.done[i] = done ? 1 : 0;
+    io.success[i] = succ ? 1 : 0;
+    if (io.terminal_obs) store_obs6<T>(io.terminal_obs, i, S.p, g);
+
+    if (done) {
+      P.last_return[i] = ep_ret;
+      P.last_len[i] = step;
+      P.last_success[i] = succ ? 1 : 0;
+      n_done += 1;
+      if (succ) n_succ += 1;
+    }
+    if (done && P.auto_reset) {
+      const uint32_t ep = P.episode[i];
+      sample_goal(P, i, ep, g);
+      P.episode[i] = ep + 1u;
+      static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
+      step = 0;
+      ep_ret = T(0);
+      store_obs6<T>(io.obs, i, P.p_init, g);
+      cur_obs[0] = (float)P.p_init[0]; cur_obs[1] = (float)P.p_init[1]; cur_obs[2] = (float)P.p_init[2];
+    } else {
+      store_obs6<T>(io.obs, i, S.p, g);                                           // :319
+      cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    }
+    return updates;
+  }
+
+  float cur_obs[3];   // eef part of the observation the policy sees next (goal part is g)
+  // eef of the current state, for the first policy call of a launch (later ones reuse the step's exit FK)
+  AE_DEV void refresh_obs(const EnvParams<T> &P) {
+    FKState<T> S;
+    T cq[NJ], sq[NJ];
+    sincos_all<T>(q, cq, sq);
+    fk<C, T>(P.chain, cq, sq, S);
+    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+  }
+  AE_DEV void policy_obs(float (&s)[6]) const {
+    s[0] = cur_obs[0]; s[1] = cur_obs[1]; s[2] = cur_obs[2]; s[3] = g[0]; s[4] = g[1]; s[5] = g[2];
+  }
+};
+
+// ---- push task (/root/reference/envs/rl_push_env.py) ---------------------------------------------------------------
+// Placement of cube and target: rejection sampling, <= 1000 tries, six draws per try (:195-214); f64 always.
+template <typename T>
+AE_DEV void push_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&cube)[3], T (&target)[3]) {
+  double cx = 0, cy = 0, tx = 0, ty = 0;
+  for (uint32_t t = 0; t < 1000u; ++t) {
+    double u0, u1, u2, u3, u4, u5;
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 0u, u0, u1);
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 1u, u2, u3);
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 2u, u4, u5);
+    cx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u0;
+    cy = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u1;
+    tx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u3;
+    ty = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u4;
+    const double dx = cx - tx, dy = cy - ty;
+    const double d = ::sqrt(::fma(dx, dx, dy * dy));   // both rest at the same z
+    if (d >= P.push_place_min && d <= P.push_place_max) break;
+    (void)u2; (void)u5;
+  }
+  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = (T)P.push_rest_z;
+  target[0] = (T)tx; target[1] = (T)ty; target[2] = (T)P.push_rest_z;
+}
+
+template <class C, typename T> struct PushLane {
+  using M = Mth<T>;
+  static constexpr int kObs = 9;
+  T q[NJ];
+  T cube[3], target[3], d_last;
+  int32_t step;
+  T ep_ret;
+  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;
+  float cur_obs[3];
+  AE_DEV void refresh_obs(const EnvParams<T> &P) {
+    FKState<T> S;
+    T cq[NJ], sq[NJ];
+    sincos_all<T>(q, cq, sq);
+    fk<C, T>(P.chain, cq, sq, S);
+    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+  }
+  AE_DEV void policy_obs(float (&s)[9]) const {
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; s[k] = cur_obs[k]; s[3 + k] = (float)cube[k]; s[6 + k] = (float)target[k]; });
+  }
+
+  AE_DEV T dist_ct() const {
+    const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
+    return M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
+  }
+
+  AE_DEV void load(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * n + i]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = P.aux[(int64_t)k * n + i]; target[k] = P.aux[(int64_t)(3 + k) * n + i]; });
+    d_last = P.aux[(int64_t)6 * n + i];
+    step = P.step[i];
+    ep_ret = P.ep_return[i];
+  }
+
+  AE_DEV void store(const EnvParams<T> &P, int64_t i) {
+    const int64_t n = P.n;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
+    P.aux[(int64_t)6 * n + i] = d_last;
+    P.step[i] = step;
+    P.ep_return[i] = ep_ret;
+    if (n_done) atomicAdd(&P.counters[0], (unsigned long long)n_done);
+    if (n_succ) atomicAdd(&P.counters[1], (unsigned long long)n_succ);
+    if (n_bad) atomicAdd(&P.counters[3], (unsigned long long)n_bad);
+    if (n_upd) atomicAdd(&P.counters[4], (unsigned long long)n_upd);
+  }
+
+  // stepSimulation (:349), simplified: sphere (tool, radius r at the eef) vs axis-aligned box (cube, half-size h)
+  // overlap test; on overlap the cube is displaced horizontally -- along the contact normal by the penetration
+  // depth when the tool centre is outside the footprint, ahead of the tool along its travel p0 -> p when inside.
+  AE_DEV void contact(const EnvParams<T> &P, const T (&p0)[3], const T (&p)[3]) {
+    const T h = P.push_cube_half, r = P.push_eef_radius;
+    if (M::fabs(p[2] - cube[2]) >= h + r) return;
+    const T lx = cube[0] - h, hx = cube[0] + h, ly = cube[1] - h, hy = cube[1] + h;
+    const T qx = p[0] < lx ? lx : (p[0] > hx ? hx : p[0]);
+    const T qy = p[1] < ly ? ly : (p[1] > hy ? hy : p[1]);
+    const T gx = p[0] - qx, gy = p[1] - qy;
+    const T gap = M::sqrt(M::fma(gx, gx, gy * gy));
+    if (gap >= r) return;
+    if (gap > T(1e-9)) {
+      const T depth = r - gap;
+      cube[0] -= depth * (gx / gap);
+      cube[1] -= depth * (gy / gap);
+    } else {
+      T mx = p[0] - p0[0], my = p[1] - p0[1];
+      const T mn = M::sqrt(M::fma(mx, mx, my * my));
+      if (mn < T(1e-3)) return;   // < 1 mm of horizontal travel: the tool presses down on the cube, no sweep
+      mx /= mn; my /= mn;
+      const T s = (r + h) - M::fma(cube[0] - p[0], mx, (cube[1] - p[1]) * my);
+      if (s > T(0)) { cube[0] = M::fma(s, mx, cube[0]); cube[1] = M::fma(s, my, cube[1]); }
+    }
+  }
+
+  // RLPushEnv.step + _reward (rl_push_env.py:310-440)
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io) {
+    FKState<T> S;
+    T tgt[3];
+    T p0[3];
+    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
+    n_upd += (uint32_t)updates;
+    contact(P, p0, S.p);                                                          // :349
+    step += 1;                                                                    // :355
+    const T d_cur = dist_ct();                                                    // :388
+    T test = d_cur - d_last;                                                      // :390-392
+    if (M::fabs(test) < T(1e-5)) test = T(0.01);                                  // :393-394
+    d_last = d_cur;                                                               // :396-397
+    const float fx = (float)cube[0] - (float)target[0], fy = (float)cube[1] - (float)target[1],
+                fz = (float)cube[2] - (float)target[2];                           // :378-384 float32 states
+    const float dt32 = sqrtf(fmaf(fx, fx, fmaf(fy, fy, fz * fz)));                 // :400
+    T reward;
+    bool done;
+    if (step > P.max_steps) { reward = (T)(-dt32 * 50.0f); done = true; }                       // :418-420
+    else if ((double)dt32 < (double)P.push_success_dis) { reward = T(100); done = true; }       // :422-424
+    else { reward = -test * T(100); done = false; }                                             // :427-428
+    const bool succ = d_cur < P.push_success_dis;                                               // :430-432
+    ep_ret += reward;
+
+    bool finite = true;
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
+    if (!finite) n_bad += 1;
+
+    io.reward[i] = (float)reward;
+    io.done[i] = done ? 1 : 0;
+    io.success[i] = succ ? 1 : 0;
+    if (io.terminal_obs) store_obs9<T>(io.terminal_obs, i, S.p, cube, target);
+    if (done) {
+      P.last_return[i] = ep_ret;
+      P.last_len[i] = step;
+      P.last_success[i] = succ ? 1 : 0;
+      n_done += 1;
+      if (succ) n_succ += 1;
+    }
+    if (done && P.auto_reset) {
+      const uint32_t ep = P.episode[i];
+      push_sample(P, i, ep, cube, target);
+      P.episode[i] = ep + 1u;
+      d_last = dist_ct();                                                         // :243-245
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
+      step = 0;
+      ep_ret = T(0);
+      store_obs9<T>(io.obs, i, P.p_init, cube, target);
+      cur_obs[0] = (float)P.p_init[0]; cur_obs[1] = (float)P.p_init[1]; cur_obs[2] = (float)P.p_init[2];
+    } else {
+      store_obs9<T>(io.obs, i, S.p, cube, target);                               // :308
+      cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    }
+    return updates;
+  }
+};
+
+// RLPushEnv.reset (rl_push_env.py:145-256) for masked envs; goal_in f32 [N][6] = cube xyz, target xyz.
+template <typename T>
+__global__ __launch_bounds__(256) void push_reset_kernel(EnvParams<T> P, const uint8_t *mask, const float *goal_in, float *obs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (mask && !mask[i]) return;
+  const int64_t n = P.n;
+  T cube[3], target[3];
+  if (goal_in) {
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = (T)goal_in[6 * i + k]; target[k] = (T)goal_in[6 * i + 3 + k]; });
+  } else {
+    const uint32_t ep = P.episode[i];
+    push_sample(P, i, ep, cube, target);
+    P.episode[i] = ep + 1u;
+  }
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.q_init[j]; });
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
+  const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
+  P.aux[(int64_t)6 * n + i] = Mth<T>::sqrt(Mth<T>::fma(x, x, Mth<T>::fma(y, y, z * z)));
+  P.step[i] = 0;
+  P.ep_return[i] = T(0);
+  if (obs) store_obs9<T>(obs, i, P.p_init, cube, target);
+}
+
+// One env step per launch: load state -> FK -> target = clip(p + dv a) -> DLS IK loop -> FK -> (push: contact) ->
+// reward / done -> obs pack -> episode accounting -> optional in-place reset -> store state.
+// Lane = ReachLane (rl_reach_env.py:219-319) or PushLane (rl_push_env.py:310-440).
+template <class Lane, typename T>
+__global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io) {
+  TL_STAMP(tl0);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  Lane L;
+  L.load(P, i);
+  T a[3];
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; a[k] = (T)io.action[3 * i + k]; });
+#ifdef ARMENV_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  TL_STAMP(tl1);
+  const int updates = L.env_step(P, i, a, io);
+  (void)updates;
+  TL_STAMP(tl2);
+  L.store(P, i);
+  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)P.n);
+#ifdef ARMENV_TIMELINE
+  {
+    TL_STAMP(tl3);
+    int mx = updates;
+    for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    const unsigned long long dn = __ballot(L.n_done != 0);
+    if ((threadIdx.x & 63) == 0 && g_timeline) {
+      unsigned long long *r = g_timeline + 8 * (i >> 6);
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      r[0] = tl0; r[1] = tl1; r[2] = tl2; r[3] = tl3; r[4] = mx; r[5] = __popcll(dn); r[6] = xcc; r[7] = hw;
+    }
+  }
+#endif
+}
+
+// The rollout inner loop of /root/reference/main.py:108-128 for `steps` consecutive env steps in ONE launch: the env
+// state stays in registers, every step's outputs go to row t of [steps][N][...] buffers, and the action of step t
+// is either read from actions[t] (external policy, identical to `steps` calls of env_step_kernel) or produced
+// in-kernel by the fused exploration policy.  Because lanes never synchronise, a lane that needs extra IK updates
+// in one step does not hold the other envs back for the rest of the launch: per-step cost approaches the MEAN
+// update count instead of the per-launch MAX.
+// POLICY is a compile-time copy of pol.kind: the external-action variant carries no actor / noise code, which keeps it
+// free of the register spills the fused-actor variant's 128 MFMA accumulators would otherwise force on it.
+template <class Lane, typename T, int POLICY>
+__global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
+                                                          const float *actions, StepIO io0, float *actions_out) {
+  __shared__ float4 w1_lds[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // the kernel's only LDS use and only barrier: W1, once
+    actor_stage_w1(pol.actor.W1P, w1_lds);
+    __syncthreads();
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const int64_t n = P.n;
+  constexpr int kObs = Lane::kObs;
+  Lane L;
+  L.load(P, i);
+  uint32_t episode = (POLICY != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
+  if constexpr (POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3) L.refresh_obs(P);
+  float an[3] = {0.f, 0.f, 0.f};
+  if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2]; }
+  for (int32_t t = 0; t < steps; ++t) {
+    T a[3];
+    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+      a[0] = (T)an[0]; a[1] = (T)an[1]; a[2] = (T)an[2];
+      if (t + 1 < steps) {   // prefetch the next step's action; its latency hides under this step's IK
+        const float *nx = actions + ((int64_t)(t + 1) * n + i) * 3;
+        an[0] = nx[0]; an[1] = nx[1]; an[2] = nx[2];
+      }
+    } else {
+      float mu[3] = {0.f, 0.f, 0.f};
+      if constexpr (POLICY == ARMENV_POLICY_ACTOR) {
+        float s[kObs];
+        L.policy_obs(s);
+        actor_forward_wave<kObs>(pol.actor, s, mu);                      // take_action, TD3_mlp.py:82-97
+      } else if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {
+        float s[kObs];
+        L.policy_obs(s);
+        actor_forward_wave_f16x3<kObs>(pol.actor, pol.actor_h, w1_lds, s, mu);
+      }
+      float nz[3];
+      // the episode index of the stream is the number of resets so far minus one (the running episode)
+      policy_noise(P.seed, P.env_id0 + (uint64_t)i, episode - 1u, (uint32_t)L.step, nz);
+      static_for<0, 3>([&](auto KI) {
+        constexpr int k = KI;
+        float v = fmaf(nz[k], pol.sigma, mu[k]);                          // + N(0, sigma), main.py:116
+        v = fminf(fmaxf(v, -pol.clip), pol.clip);                         // .clip(-bound, bound), main.py:117
+        a[k] = (T)v;
+        an[k] = v;
+      });
+    }
+    StepIO io;
+    io.action = nullptr;
+    io.obs = io0.obs + (int64_t)t * n * kObs;
+    io.reward = io0.reward + (int64_t)t * n;
+    io.done = io0.done + (int64_t)t * n;
+    io.success = io0.success + (int64_t)t * n;
+    io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
+    if (actions_out) {
+      float *ao = actions_out + ((int64_t)t * n + i) * 3;
+      if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
+      else { ao[0] = an[0]; ao[1] = an[1]; ao[2] = an[2]; }
+    }
+    const uint32_t before = L.n_done;
+    L.env_step(P, i, a, io);
+    if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
+      if (L.n_done != before && P.auto_reset) episode += 1u;
+    }
+  }
+  L.store(P, i);
+  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)n * (unsigned long long)steps);
+}
+
+// p.getLinkState(body, 6)[4], [5]
+template <class C, typename T>
+__global__ __launch_bounds__(256) void fk_kernel(EnvParams<T> P, int64_t n, const double *q_in, double *pos, double *quat) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T q[NJ];
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = (T)q_in[7 * i + j]; });
+  FKState<T> S;
+  T cq[NJ], sq[NJ];
+  sincos_all<T>(q, cq, sq);
+  fk<C, T>(P.chain, cq, sq, S);
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; pos[3 * i + k] = (double)S.p[k]; });
+  if (quat) {
+    T qc[4];
+    quat_from_frame<T>(S.W, qc);
+    static_for<0, 4>([&](auto KI) { constexpr int k = KI; quat[4 * i + k] = (double)qc[k]; });
+  }
+}
+
+// p.calculateInverseKinematics(body, 6, pos, orn, jointDamping)
+template <class C, typename T>
+__global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, const double *q_in, const double *tgt_in,
+                                                 double *q_out, int32_t *iters) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T q[NJ], tgt[3], a[3] = {T(0), T(0), T(0)};
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = (T)q_in[7 * i + j]; });
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; tgt[k] = (T)tgt_in[3 * i + k]; });
+  FKState<T> S;
+  const int it = ik_move<C, T, false>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q_out[7 * i + j] = (double)q[j]; });
+  if (iters) iters[i] = it;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *q, float *goal, int32_t *step,
+                                                        uint32_t *episode, double *ep_return, double *aux) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (aux && P.aux) {
+    static_for<0, 7>([&](auto KI) { constexpr int k = KI; aux[8 * i + k] = (double)P.aux[(int64_t)k * P.n + i]; });
+    aux[8 * i + 7] = 0.0;
+  }
+  if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[7 * i + j] = (double)P.q[(int64_t)j * P.n + i]; });
+  if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; goal[3 * i + k] = P.goal[(int64_t)k * P.n + i]; });
+  if (step) step[i] = P.step[i];
+  if (episode) episode[i] = P.episode[i];
+  if (ep_return) ep_return[i] = (double)P.ep_return[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void set_state_kernel(EnvParams<T> P, const double *q, const float *goal,
+                                                        const int32_t *step, const uint32_t *episode,
+                                                        const double *ep_return, const double *aux) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (aux && P.aux) static_for<0, 7>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * P.n + i] = (T)aux[8 * i + k]; });
+  if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = (T)q[7 * i + j]; });
+  if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = goal[3 * i + k]; });
+  if (step) P.step[i] = step[i];
+  if (episode) P.episode[i] = episode[i];
+  if (ep_return) P.ep_return[i] = (T)ep_return[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void episode_stats_kernel(EnvParams<T> P, double *last_return, int32_t *last_len,
+                                                            uint8_t *last_success) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  if (last_return) last_return[i] = (double)P.last_return[i];
+  if (last_len) last_len[i] = P.last_len[i];
+  if (last_success) last_success[i] = P.last_success[i];
+}
+
