@@ -924,3 +924,55 @@ def test_trajectory_ring_matches_linear_window(envs):
     z = empty.sample(32, return_picks=True)
     assert int(z["picks"][:, 0].max()) == -1 and float(z["states"].abs().max()) == 0.0 and bool((z["dones"] == 1).all())
     e.close(); e2.close()
+
+
+# ------------------------------------------------------------------------------ stream / graph behaviour (boundary)
+
+def test_step_is_capturable_in_a_hip_graph(envs):
+    """armenv_step only enqueues a kernel on the caller's stream (no allocation, no sync), so a policy + step loop
+    can be captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed."""
+    n = 4096
+    torch.manual_seed(0)
+    W = (torch.randn(6, 3, device=DEV) * 0.5)
+    policy = lambda o: torch.tanh(o @ W) * 0.7
+    eager = _mk(envs, n, seed=12); graphed = _mk(envs, n, seed=12)
+    obs_e = eager.reset().clone()
+    ref = []
+    for _ in range(6):
+        o, r, d, s = eager.step(policy(obs_e).contiguous())
+        obs_e = o.clone(); ref.append((o.clone(), r.clone(), d.clone()))
+    obs_g = graphed.reset()                                   # the env's persistent obs tensor: graph input and output
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):                              # warm-up on the capture stream
+        act = policy(obs_g).contiguous()
+    torch.cuda.current_stream(DEV).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        act = policy(graphed._obs).contiguous()
+        o, r, d, s = graphed.step(act)
+    # capture does not execute: state still at reset
+    for t in range(6):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o, ref[t][0]) and torch.equal(r, ref[t][1]) and torch.equal(d, ref[t][2]), t
+    assert graphed.counters()["env_steps"] == 6 * n
+    eager.close(); graphed.close()
+
+
+def test_two_handles_on_two_streams_are_independent(envs):
+    n = 8192
+    a = _mk(envs, n, seed=1); b = _mk(envs, n, seed=2)
+    s1, s2 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    act = torch.zeros(n, 3, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        a.reset(); oa = [a.step(act)[0].clone() for _ in range(5)]
+    with torch.cuda.stream(s2):
+        b.reset(); ob = [b.step(act)[0].clone() for _ in range(5)]
+    torch.cuda.synchronize()
+    c = _mk(envs, n, seed=1); c.reset()
+    oc = [c.step(act)[0].clone() for _ in range(5)]
+    assert all(torch.equal(x, y) for x, y in zip(oa, oc)) and not torch.equal(oa[-1][:, 3:], ob[-1][:, 3:])
+    a.close(); b.close(); c.close()
