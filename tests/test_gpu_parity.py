@@ -976,3 +976,15 @@ def test_two_handles_on_two_streams_are_independent(envs):
     oc = [c.step(act)[0].clone() for _ in range(5)]
     assert all(torch.equal(x, y) for x, y in zip(oa, oc)) and not torch.equal(oa[-1][:, 3:], ob[-1][:, 3:])
     a.close(); b.close(); c.close()
+
+
+def test_training_loop_smoke(envs):
+    """armenv.train (main.py:77-162 on the device) runs end to end: rollouts with the fused actor, ring store, HER
+    batches, TD3 updates; a few iterations only (learning curves: profiles/r01_train_*.jsonl)."""
+    from armenv.train import train_reach
+    logs = []
+    agent, hist = train_reach(num_envs=256, iterations=12, rollout_steps=16, updates=4, batch_size=256, window_steps=64,
+                              max_steps=20, log_every=4, log=logs.append)
+    assert len(hist) == 3 and hist[-1]["env_steps"] == 256 * 16 * 12 and hist[-1]["episodes"] >= 256 * 8
+    assert agent.total_it > 0
+    assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
