@@ -103,9 +103,49 @@ AE_DEV void fk(const ChainDev<T> &ch, const T (&cq)[NJ], const T (&sq)[NJ], FKSt
   });
 }
 
+// fdlibm __kernel_sin / __kernel_cos on [-pi/4, pi/4] (< 1 ulp)
+template <typename T>
+AE_DEV void sincos_kernel(T r, T &s, T &c) {
+  using M = Mth<T>;
+  const T z = r * r;
+  T ps = T(1.58969099521155010221e-10);
+  ps = M::fma(ps, z, T(-2.50507602534068634195e-08));
+  ps = M::fma(ps, z, T(2.75573137070700676789e-06));
+  ps = M::fma(ps, z, T(-1.98412698298579493134e-04));
+  ps = M::fma(ps, z, T(8.33333333332248946124e-03));
+  ps = M::fma(ps, z, T(-1.66666666666666324348e-01));
+  s = M::fma(r * z, ps, r);
+  T pc = T(-1.13596475577881948265e-11);
+  pc = M::fma(pc, z, T(2.08757232129817482790e-09));
+  pc = M::fma(pc, z, T(-2.75573143513906633035e-07));
+  pc = M::fma(pc, z, T(2.48015872894767294178e-05));
+  pc = M::fma(pc, z, T(-1.38888888888741095749e-03));
+  pc = M::fma(pc, z, T(4.16666666666666019037e-02));
+  c = M::fma(z * z, pc, M::fma(T(-0.5), z, T(1)));
+}
+
+// sin and cos of a joint angle: three-term Cody-Waite reduction by pi/2 (exact products for |x| up to ~1e5, far beyond
+// any joint angle) + the kernels above + quadrant fix-up: half the instructions of the library sincos, whose
+// Payne-Hanek path for huge arguments is dead weight here.  Non-finite or absurdly large inputs fall back to the library.
+AE_DEV void sincos_joint(double x, double &s, double &c) {
+  if (!(::fabs(x) < 1.0e5)) { ::sincos(x, &s, &c); return; }
+  const double k = ::rint(x * 6.36619772367581382433e-01);
+  double r = ::fma(-k, 1.57079632673412561417e+00, x);
+  r = ::fma(-k, 6.07710050630396597660e-11, r);
+  r = ::fma(-k, 2.02226624871116645580e-21, r);
+  r = ::fma(-k, 8.47842766036889956997e-32, r);
+  double sr, cr;
+  sincos_kernel<double>(r, sr, cr);
+  const int n = (int)k & 3;
+  const double s1 = (n & 1) ? cr : sr, c1 = (n & 1) ? sr : cr;
+  s = (n & 2) ? -s1 : s1;
+  c = ((n + 1) & 2) ? -c1 : c1;
+}
+AE_DEV void sincos_joint(float x, float &s, float &c) { ::sincosf(x, &s, &c); }
+
 template <typename T>
 AE_DEV void sincos_all(const T (&q)[NJ], T (&cq)[NJ], T (&sq)[NJ]) {
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; Mth<T>::sincos(q[j], sq[j], cq[j]); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; sincos_joint(q[j], sq[j], cq[j]); });
 }
 
 // (c,s) <- (cos(q+d), sin(q+d)) from (cos q, sin q) for |d| <= pi/4 (the DLS scale-back bounds every update by
@@ -114,21 +154,8 @@ AE_DEV void sincos_all(const T (&q)[NJ], T (&cq)[NJ], T (&sq)[NJ]) {
 template <typename T>
 AE_DEV void rotate_small(T &c, T &s, T d) {
   using M = Mth<T>;
-  const T z = d * d;
-  T ps = T(1.58969099521155010221e-10);
-  ps = M::fma(ps, z, T(-2.50507602534068634195e-08));
-  ps = M::fma(ps, z, T(2.75573137070700676789e-06));
-  ps = M::fma(ps, z, T(-1.98412698298579493134e-04));
-  ps = M::fma(ps, z, T(8.33333333332248946124e-03));
-  ps = M::fma(ps, z, T(-1.66666666666666324348e-01));
-  const T sd = M::fma(d * z, ps, d);
-  T pc = T(-1.13596475577881948265e-11);
-  pc = M::fma(pc, z, T(2.08757232129817482790e-09));
-  pc = M::fma(pc, z, T(-2.75573143513906633035e-07));
-  pc = M::fma(pc, z, T(2.48015872894767294178e-05));
-  pc = M::fma(pc, z, T(-1.38888888888741095749e-03));
-  pc = M::fma(pc, z, T(4.16666666666666019037e-02));
-  const T cd = M::fma(z * z, pc, M::fma(T(-0.5), z, T(1)));
+  T sd, cd;
+  sincos_kernel<T>(d, sd, cd);
   const T cn = M::fma(c, cd, -(s * sd));
   const T sn = M::fma(s, cd, c * sd);
   c = cn;
