@@ -59,8 +59,14 @@ def cpu_baseline(precision, seconds=12.0):
         dt = time.perf_counter() - t0
         if (dt >= seconds and k >= 3) or k >= 2000:
             break
+    try:                      # the metric's own "PyBullet CPU path", only if it exists here
+        import pybullet  # noqa: F401
+        pyb = "installed (not timed by this script)"
+    except Exception as e:    # expected: the wheel is not in the image and there is no network
+        pyb = "unavailable: %s" % e
     return {"value": n * k / dt, "unit": "env-steps/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"{k} steps x {n} envs of the same reach workload in {dt:.1f}s, C oracle fp64, OpenMP"}
+            "sample": f"{k} steps x {n} envs of the same reach workload in {dt:.1f}s, C oracle fp64, OpenMP",
+            "pybullet": pyb}
 
 
 def main():
