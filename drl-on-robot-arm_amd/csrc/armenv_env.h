@@ -228,11 +228,16 @@ template <class C, typename T> struct ReachLane {
 
   // RLReachEnv.step + _reward (rl_reach_env.py:219-319) with action a; writes row i of the caller's buffers.
   // Returns the number of IK updates.
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io) {
+  // `prefetched` (nullable): registers a caller loaded before this step (the rollout's next action).  They are
+  // consumed here, right after the IK and BEFORE this step's stores are issued: the s_waitcnt the consumption needs
+  // then covers only that old load; placed at the next step's top it would also wait for this step's stores
+  // (vmcnt is in-order) -- measured 15 % of the wave's cycles.
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, const float (*prefetched)[3] = nullptr) {
     const int64_t n = P.n;
     FKState<T> S;
     T tgt[3];
     const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
+    if (prefetched) asm volatile("" ::"v"((*prefetched)[0]), "v"((*prefetched)[1]), "v"((*prefetched)[2]));
 
     n_upd += (uint32_t)updates;
     step += 1;                                                                    // :264
@@ -389,11 +394,12 @@ template <class C, typename T> struct PushLane {
   }
 
   // RLPushEnv.step + _reward (rl_push_env.py:310-440)
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io) {
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, const float (*prefetched)[3] = nullptr) {
     FKState<T> S;
     T tgt[3];
     T p0[3];
     const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
+    if (prefetched) asm volatile("" ::"v"((*prefetched)[0]), "v"((*prefetched)[1]), "v"((*prefetched)[2]));
     n_upd += (uint32_t)updates;
     contact(P, p0, S.p);                                                          // :349
     step += 1;                                                                    // :355
@@ -532,7 +538,13 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   uint32_t episode = (POLICY != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
   if constexpr (POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3) L.refresh_obs(P);
   float an[3] = {0.f, 0.f, 0.f};
-  if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2]; }
+  if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+    an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2];
+    // settle this load before the loop: otherwise the loop header inherits a pending load on these registers from the
+    // entry edge and hipcc puts an in-order vmcnt wait at the top of EVERY step, which also waits for the previous
+    // step's stores
+    asm volatile("" ::"v"(an[0]), "v"(an[1]), "v"(an[2]));
+  }
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
     if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
@@ -576,7 +588,8 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
       else { ao[0] = an[0]; ao[1] = an[1]; ao[2] = an[2]; }
     }
     const uint32_t before = L.n_done;
-    L.env_step(P, i, a, io);
+    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) L.env_step(P, i, a, io, &an);
+    else L.env_step(P, i, a, io);
     if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
       if (L.n_done != before && P.auto_reset) episode += 1u;
     }
