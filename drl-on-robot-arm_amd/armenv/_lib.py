@@ -72,6 +72,7 @@ SYMBOLS = {
     "armenv_set_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "armenv_episode_stats": (C.c_int, [_P, _P, _P, _P, _P]),
     "armenv_counters": (C.c_int, [_P, C.POINTER(C.c_uint64 * 8), _P]),
+    "armenv_summary": (C.c_int, [_P, _P, _P]),
     "armenv_set_policy": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
     "armenv_actor_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "armenv_count_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P]),

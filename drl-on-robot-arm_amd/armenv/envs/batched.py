@@ -239,6 +239,15 @@ class BatchedArmEnv:
         L.check(self._lib.armenv_episode_stats(self._h, _ptr(ret), _ptr(ln), _ptr(su), self._stream()))
         return ret, ln, su
 
+    def summary(self):
+        """Device-side logging summary, no host sync: dict of 0-dim tensors (mean / max distance to goal, mean return,
+        length and success rate of the envs' last finished episodes)."""
+        out = torch.empty(8, dtype=torch.float64, device=self.device)
+        L.check(self._lib.armenv_summary(self._h, _ptr(out), self._stream()))
+        n = out[5]
+        return dict(mean_distance=out[0] / n, max_distance=out[1], mean_last_return=out[2] / n, mean_last_len=out[3] / n,
+                    last_success_rate=out[4] / n, raw=out)
+
     def counters(self):
         out = (C.c_uint64 * 8)()
         L.check(self._lib.armenv_counters(self._h, C.byref(out), self._stream()))

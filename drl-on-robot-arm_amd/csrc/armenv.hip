@@ -103,6 +103,7 @@ struct EngineBase {
                         const double *ep_return, const double *aux, hipStream_t s) = 0;
   virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
   virtual int counters(uint64_t out[8], hipStream_t s) = 0;
+  virtual int summary(double *out_dev, hipStream_t s) = 0;
   virtual const char *name() const = 0;
 };
 
@@ -308,6 +309,12 @@ template <class C, typename T> struct Engine final : EngineBase {
     HIP_TRY(hipStreamSynchronize(s));
     return ARMENV_OK;
   }
+  int summary(double *out_dev, hipStream_t s) override {
+    HIP_TRY(hipMemsetAsync(out_dev, 0, 8 * sizeof(double), s));
+    hipLaunchKernelGGL((env_summary_kernel<C, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, task, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
   const char *name() const override { return kname.c_str(); }
 };
 
@@ -510,6 +517,12 @@ int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream) {
   ENV_ENTER(env);
   if (!out) return fail(ARMENV_EINVAL, "armenv_counters: out is NULL");
   return env->eng->counters(out, static_cast<hipStream_t>(stream));
+}
+
+int armenv_summary(ArmEnv *env, double *out_dev, void *stream) {
+  ENV_ENTER(env);
+  if (!out_dev) return fail(ARMENV_EINVAL, "armenv_summary: out_dev is NULL");
+  return env->eng->summary(out_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const float *b1_dev, const float *W2_dev,

@@ -632,6 +632,47 @@ __global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, cons
   if (iters) iters[i] = it;
 }
 
+// Logging summary without a host round trip: per-lane reach distance |FK(q) - goal| (reach) or cube-target distance
+// (push) and the last finished episode's return / length / success, reduced across the wavefront with lane shuffles
+// and accumulated with one atomic per wave into out[8] =
+//   [sum distance, max distance (as f64 bits via atomicMax on the non-negative pattern), sum last_return, sum last_len,
+//    sum last_success, envs counted, 0, 0].
+template <class C, typename T>
+__global__ __launch_bounds__(256) void env_summary_kernel(EnvParams<T> P, int32_t task, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < P.n;
+  const int64_t ic = live ? i : P.n - 1;
+  double dist;
+  if (task == ARMENV_TASK_PUSH) {
+    const T x = P.aux[0 * P.n + ic] - P.aux[3 * P.n + ic], y = P.aux[1 * P.n + ic] - P.aux[4 * P.n + ic],
+            z = P.aux[2 * P.n + ic] - P.aux[5 * P.n + ic];
+    dist = (double)Mth<T>::sqrt(Mth<T>::fma(x, x, Mth<T>::fma(y, y, z * z)));
+  } else {
+    T q[NJ], cq[NJ], sq[NJ];
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * P.n + ic]; });
+    sincos_all<T>(q, cq, sq);
+    FKState<T> S;
+    fk<C, T>(P.chain, cq, sq, S);
+    const T x = S.p[0] - (T)P.goal[0 * P.n + ic], y = S.p[1] - (T)P.goal[1 * P.n + ic], z = S.p[2] - (T)P.goal[2 * P.n + ic];
+    dist = (double)Mth<T>::sqrt(Mth<T>::fma(x, x, Mth<T>::fma(y, y, z * z)));
+  }
+  double v[5] = {live ? dist : 0.0, live ? (double)P.last_return[ic] : 0.0, live ? (double)P.last_len[ic] : 0.0,
+                 live ? (double)P.last_success[ic] : 0.0, live ? 1.0 : 0.0};
+  double mx = live ? dist : 0.0;
+  for (int o = 32; o; o >>= 1) {
+    static_for<0, 5>([&](auto KI) { constexpr int k = KI; v[k] += __shfl_xor(v[k], o); });
+    mx = fmax(mx, __shfl_xor(mx, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], v[0]);
+    atomicMax(reinterpret_cast<unsigned long long *>(&out[1]), (unsigned long long)__double_as_longlong(mx));
+    atomicAdd(&out[2], v[1]);
+    atomicAdd(&out[3], v[2]);
+    atomicAdd(&out[4], v[3]);
+    atomicAdd(&out[5], v[4]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *q, float *goal, int32_t *step,
                                                         uint32_t *episode, double *ep_return, double *aux) {

@@ -189,6 +189,12 @@ int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len
  * out[2] env-steps executed, out[3] non-finite joint states seen, out[4] IK (DLS) updates applied, out[5..7] 0. */
 int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream);
 
+/* Logging summary computed on the device (no host sync; what main.py:130-160 prints/plots from one env): out_dev f64 [8] =
+ * [sum over envs of the current distance to the goal (reach: |FK(q) - goal|, push: |cube - target|), max of it, sum of
+ * the last finished episodes' returns, sum of their lengths, sum of their success flags, number of envs, 0, 0].
+ * Wavefront shuffles reduce each wave's 64 envs; one atomic per wave and quantity reaches HBM. */
+int armenv_summary(ArmEnv *env, double *out_dev, void *stream);
+
 /* Installs the TD3 actor (PolicyNet, /root/reference/algo/TD3/net_mlp.py:29-40; take_action
  * algo/TD3/TD3_mlp.py:82-97) for fused stepping: a = action_bound * tanh(W3 relu(W2 relu(W1 s + b1) + b2) + b3),
  * then the rollout loop's exploration a = clip(a + N(0, noise_sigma), +-noise_clip) (main.py:116-117).

@@ -988,3 +988,26 @@ def test_training_loop_smoke(envs):
     assert len(hist) == 3 and hist[-1]["env_steps"] == 256 * 16 * 12 and hist[-1]["episodes"] >= 256 * 8
     assert agent.total_it > 0
     assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
+
+
+def test_device_summary_matches_host_reduction(envs, O, kuka):
+    n = 4096 + 17                                              # ragged last wave
+    e = _mk(envs, n, seed=14, max_steps=9)
+    e.set_policy("random"); e.reset()
+    e.rollout(25, None)
+    s = e.summary()
+    st = e.get_state()
+    p, _ = O.fk(kuka, _np(st["q"]))
+    d = np.linalg.norm(p - _np(st["goal"]).astype(np.float64), axis=1)
+    ret, ln, su = e.episode_stats()
+    assert abs(float(s["mean_distance"]) - d.mean()) < 1e-9 and abs(float(s["max_distance"]) - d.max()) < 1e-9
+    assert abs(float(s["mean_last_return"]) - _np(ret).mean()) < 1e-9
+    assert abs(float(s["mean_last_len"]) - _np(ln).mean()) < 1e-9 and float(s["raw"][5]) == n
+    assert abs(float(s["last_success_rate"]) - _np(su).mean()) < 1e-12
+    e.close()
+    pe = envs.BatchedPushEnv(1024, device=DEV, seed=3)
+    pe.reset()
+    aux = _np(pe.get_state()["aux"])
+    sp = pe.summary()
+    assert abs(float(sp["mean_distance"]) - np.linalg.norm(aux[:, :3] - aux[:, 3:6], axis=1).mean()) < 1e-12
+    pe.close()
