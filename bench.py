@@ -210,15 +210,20 @@ def main():
                 traffic = None
         updates = dc["ik_updates"] / max(1, dc["env_steps"])
         flops = (updates * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n * steps_per_launch
+        pol_txt = {"external": "random policy %s pre-generated in HBM, step() throughput only",
+                   "random": "random policy %s generated in-kernel (Philox)",
+                   "actor": "TD3 actor forward (exact f32 MFMA) + exploration noise %s fused into the step kernel",
+                   "actor_f16x3": "TD3 actor forward (f16 MFMA, 3-pass hi/lo split) + exploration noise %s fused into the step kernel"}
+        noise = "clip(N(0,0.686),+-0.7)" if args.task == "reach" else "N(0,0.392)"
+        workload = ("rl_reach_env %d parallel envs per GPU, %s, KUKA iiwa chain, auto-reset on" if args.task == "reach" else
+                    "rl_push_env %d parallel envs per GPU (arm FK/IK + cube contact/overlap test), %s, auto-reset on") % (
+                        n, pol_txt[args.policy] % noise)
         line = {
             "metric": "env-steps/sec at N parallel envs (rl_%s_env)" % args.task,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
-            "config": {"workload": ("rl_reach_env %d parallel envs per GPU, random policy clip(N(0,0.686),+-0.7) pre-generated "
-                                    "in HBM, step() throughput only, KUKA iiwa chain, auto-reset on" % n) if args.task == "reach" else
-                                   ("rl_push_env %d parallel envs per GPU (arm FK/IK + cube contact/overlap test), random policy "
-                                    "N(0,0.392) pre-generated in HBM, step() throughput only, auto-reset on" % n),
+            "config": {"workload": workload,
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch,
                        "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps (logging only)"
