@@ -78,8 +78,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--gather-every", type=int, default=100, help="steps between episode-return all-gathers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--task", default="reach", choices=["reach", "push"],
-                    help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768)")
+    ap.add_argument("--task", default="reach", choices=["reach", "push", "pick"],
+                    help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768); "
+                         "pick = the next-row env (SURVEY.md section 8f.4)")
     ap.add_argument("--policy", default="external", choices=["external", "random", "actor", "actor_f16x3"],
                     help="external = pre-generated actions in HBM (configs[1], headline); random / actor = fused in-kernel "
                          "policy (actor = configs[2]: TD3 actor forward folded into the rollout kernel)")
@@ -103,7 +104,7 @@ def main():
     init_process_group(backend, dev if backend == "nccl" else None)
 
     n = args.envs_per_gpu
-    Env = envs.BatchedReachEnv if args.task == "reach" else envs.BatchedPushEnv
+    Env = {"reach": envs.BatchedReachEnv, "push": envs.BatchedPushEnv, "pick": envs.BatchedPickEnv}[args.task]
     env = Env(n, device=dev, seed=0, env_id_offset=rank * n, precision=args.precision)
     gen = torch.Generator(device=dev); gen.manual_seed(1000 + rank)
     if args.task == "reach":      # run() exploration with a zero actor, main.py:116-117
@@ -196,9 +197,9 @@ def main():
         io_b, st_b = IO_BYTES, STATE_BYTES[args.precision]
         if args.policy != "external":
             io_b -= 12                      # no action read
-        if args.task == "push":   # obs 36 B instead of 24; state: cube/target/d_last (7 reals) r+w instead of goal
+        if args.task != "reach":  # obs 36 B instead of 24; state: cube/target/d_last (7 reals; pick 11) r+w instead of goal
             io_b += 12
-            st_b += 2 * 7 * (args.precision // 8) - 12
+            st_b += 2 * (7 if args.task == "push" else 11) * (args.precision // 8) - 12
         algo = (io_b * steps_per_launch + st_b) * n   # bytes one launch moves, algorithmically
         achieved = algo / (launch_us * 1e-6) / 1e9
         traffic = None
@@ -215,9 +216,10 @@ def main():
                    "actor": "TD3 actor forward (exact f32 MFMA) + exploration noise %s fused into the step kernel",
                    "actor_f16x3": "TD3 actor forward (f16 MFMA, 3-pass hi/lo split) + exploration noise %s fused into the step kernel"}
         noise = "clip(N(0,0.686),+-0.7)" if args.task == "reach" else "N(0,0.392)"
-        workload = ("rl_reach_env %d parallel envs per GPU, %s, KUKA iiwa chain, auto-reset on" if args.task == "reach" else
-                    "rl_push_env %d parallel envs per GPU (arm FK/IK + cube contact/overlap test), %s, auto-reset on") % (
-                        n, pol_txt[args.policy] % noise)
+        workload = {"reach": "rl_reach_env %d parallel envs per GPU, %s, KUKA iiwa chain, auto-reset on",
+                    "push": "rl_push_env %d parallel envs per GPU (arm FK/IK + cube contact/overlap test), %s, auto-reset on",
+                    "pick": "rl_pick_env %d parallel envs per GPU (arm FK/IK + gripper trigger / hold model), %s, auto-reset on",
+                    }[args.task] % (n, pol_txt[args.policy] % noise)
         line = {
             "metric": "env-steps/sec at N parallel envs (rl_%s_env)" % args.task,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -5,7 +5,7 @@ import os
 
 NJ = 7
 ABI_VERSION = 1
-TASK_REACH, TASK_PUSH = 0, 1
+TASK_REACH, TASK_PUSH, TASK_PICK = 0, 1, 2
 ROBOT_KUKA, ROBOT_DIANA = 0, 1
 FK_AUTO, FK_GENERIC = 0, 1
 POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR, POLICY_ACTOR_F16X3 = 0, 1, 2, 3
@@ -38,6 +38,8 @@ class ArmEnvConfig(C.Structure):
         ("ik_max_iters", C.c_int32), ("ik_exit_mode", C.c_int32), ("ik_angle_f32", C.c_int32), ("reserved0", C.c_int32),
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
+        ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
+        ("pick_reserved", C.c_double),
         ("chain", ArmEnvChain),
     ]
 
@@ -80,6 +82,7 @@ SYMBOLS = {
     "armenv_her_sample": (C.c_int, [C.c_int32, C.POINTER(ArmEnvHerArgs), _P]),
     "armenv_num_envs": (C.c_int64, [_P]),
     "armenv_obs_dim": (C.c_int32, [_P]),
+    "armenv_aux_dim": (C.c_int32, [_P]),
     "armenv_action_dim": (C.c_int32, [_P]),
     "armenv_kernel_name": (C.c_char_p, [_P]),
     "armenv_last_error": (C.c_char_p, []),

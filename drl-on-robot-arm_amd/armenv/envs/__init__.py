@@ -2,6 +2,7 @@
 ``getattr(envs, opt.env)`` (/root/reference/main.py:83) resolves here too."""
 from .rl_reach_env import RLReachEnv
 from .rl_push_env import RLPushEnv
-from .batched import BatchedArmEnv, BatchedReachEnv, BatchedPushEnv
+from .rl_pick_env import RLPickEnv
+from .batched import BatchedArmEnv, BatchedReachEnv, BatchedPushEnv, BatchedPickEnv
 
-__all__ = ["RLReachEnv", "RLPushEnv", "BatchedArmEnv", "BatchedReachEnv", "BatchedPushEnv"]
+__all__ = ["RLReachEnv", "RLPushEnv", "RLPickEnv", "BatchedArmEnv", "BatchedReachEnv", "BatchedPushEnv", "BatchedPickEnv"]

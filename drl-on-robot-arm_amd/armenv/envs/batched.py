@@ -24,6 +24,7 @@ class BatchedArmEnv:
 
     task = L.TASK_REACH
     obs_dim = 6
+    aux_dim = 0
 
     def __init__(self, num_envs, device="cuda:0", seed=0, auto_reset=True, precision=64, robot="kuka",
                  chain: Chain = None, env_id_offset=0, fk_path=L.FK_AUTO, **overrides):
@@ -100,7 +101,7 @@ class BatchedArmEnv:
             L.check(self._lib.armenv_reset(self._h, _ptr(m), _ptr(self._obs), self._stream()))
         else:
             g = goal.to(device=self.device, dtype=torch.float32).contiguous()
-            want = (self.num_envs, 3 if self.task == L.TASK_REACH else 6)     # push: [cube xyz, target xyz]
+            want = (self.num_envs, 3 if self.task == L.TASK_REACH else 6)     # push / pick: [cube xyz, target xyz]
             if tuple(g.shape) != want:
                 raise ValueError(f"goal must have shape {want}")
             L.check(self._lib.armenv_reset_with_goal(self._h, _ptr(m), _ptr(g), _ptr(self._obs), self._stream()))
@@ -198,15 +199,16 @@ class BatchedArmEnv:
 
     # ------------------------------------------------------------------ state exchange / stats
     def get_state(self):
-        """Reach: q, goal, step, episode, ep_return.  Push: aux [N,8] (cube xyz, target xyz, d_last, 0) replaces goal."""
+        """Reach: q, goal, step, episode, ep_return.  Push: aux [N,8] (cube xyz, target xyz, d_last, 0) replaces goal;
+        pick: aux [N,12] (cube xyz, target xyz, d_last, gripper 0/1/2, hold offset xyz, 0)."""
         n, dev = self.num_envs, self.device
-        push = self.task == L.TASK_PUSH
+        push = self.task != L.TASK_REACH
         st = dict(q=torch.empty((n, 7), dtype=torch.float64, device=dev),
                   step=torch.empty(n, dtype=torch.int32, device=dev),
                   episode=torch.empty(n, dtype=torch.int32, device=dev),   # u32 bits
                   ep_return=torch.empty(n, dtype=torch.float64, device=dev))
         if push:
-            st["aux"] = torch.empty((n, 8), dtype=torch.float64, device=dev)
+            st["aux"] = torch.empty((n, self.aux_dim), dtype=torch.float64, device=dev)
         else:
             st["goal"] = torch.empty((n, 3), dtype=torch.float32, device=dev)
         L.check(self._lib.armenv_get_state(self._h, _ptr(st["q"]), _ptr(st.get("goal")), _ptr(st["step"]),
@@ -225,7 +227,7 @@ class BatchedArmEnv:
         n = self.num_envs
         q_, g_, s_, e_, r_, a_ = (prep(q, torch.float64, (n, 7)), prep(goal, torch.float32, (n, 3)),
                                   prep(step, torch.int32, (n,)), prep(episode, torch.int32, (n,)),
-                                  prep(ep_return, torch.float64, (n,)), prep(aux, torch.float64, (n, 8)))
+                                  prep(ep_return, torch.float64, (n,)), prep(aux, torch.float64, (n, self.aux_dim)))
         L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), _ptr(a_),
                                            self._stream()))
         torch.cuda.current_stream(dev).synchronize()   # temporaries above must outlive the copy
@@ -272,7 +274,24 @@ class BatchedPushEnv(BatchedArmEnv):
     reward / done / success follow rl_push_env.py:368-445.  obs f32 [N, 9] = [eef, cube, target]."""
     task = L.TASK_PUSH
     obs_dim = 9
+    aux_dim = 8
 
     def __init__(self, num_envs, **kw):
         super().__init__(num_envs, **kw)
         self.observation_space = Box(low=[0.2, -0.3, 0.0], high=[0.7, 0.3, 0.55])       # rl_push_env.py:101-104
+
+
+class BatchedPickEnv(BatchedArmEnv):
+    """N x RLPickEnv (/root/reference/envs/rl_pick_env.py): arm pipeline exact (dv 0.08, start position rounded through
+    float32, z in [0, 0.55 + 0.257], IK result applied to joints 0..5 only, :310-351); placement :190-208; reward / done /
+    success :358-445.  The gripper (closed by p.getClosestPoints within 6 mm, :412-416) and the cube follow the build's
+    own tip-sphere model instead of Bullet's finger contact dynamics: aux[:, 7] is 0 open,
+    1 closed, 2 closed and holding the cube.  obs f32 [N, 9] = [eef (link-7 frame), cube, target]."""
+    task = L.TASK_PICK
+    obs_dim = 9
+    aux_dim = 12
+
+    def __init__(self, num_envs, **kw):
+        super().__init__(num_envs, **kw)
+        gl = float(self.cfg.pick_gripper_length)
+        self.observation_space = Box(low=[0.2, -0.3, 0.0 + gl], high=[0.7, 0.3, 0.55 + gl])    # rl_pick_env.py:94-97

@@ -1,33 +1,12 @@
-// armenv.hip -- host side of libarmenv.so: the C ABI of include/armenv.h, handle life-cycle, chain classification,
-// kernel dispatch (precision x chain x task x policy).  Device side: armenv_env.h (+ armenv_kin.h, armenv_actor.h,
-// armenv_replay.h).
-//
-// Data layout in HBM (N envs, T = f64 or f32 by ArmEnvConfig.precision), struct-of-arrays with the env index fastest
-// so that a wave's 64 lanes touch 64 consecutive elements of every array:
-//   q[7][N] T | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
-//   last_len[N] i32 | last_success[N] u8 | counters[8] u64 | push: aux[7][N] T
-// Caller-facing buffers keep the reference's array-of-struct shapes (action [N][3], obs [N][6|9]); a wave still
-// reads/writes one contiguous span of them.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <new>
-#include <string>
-
-#include "armenv_env.h"
+// armenv.hip -- the C ABI of include/armenv.h: handle life-cycle, argument checks, dispatch to the engine of the
+// handle's (task, precision) (armenv_engine.h / armenv_task.hip), the fused actor's weight packing and entry kernel,
+// and the trajectory-store kernels (armenv_replay.h).
+#include "armenv_engine.h"
 #include "armenv_replay.h"
-
-// ------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
 
-static int fail(int code, const char *fmt, ...) {
+int armenv_fail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -36,78 +15,6 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                            \
-  do {                                                                                           \
-    hipError_t e_ = (expr);                                                                      \
-    if (e_ != hipSuccess) return fail(ARMENV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = false;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
-  }
-  ~DeviceGuard() {
-    int cur = -1;
-    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-  }
-};
-
-static void rpy_to_mat(const double rpy[3], double R[9]) {  // row-major, Rz(yaw) Ry(pitch) Rx(roll)
-  const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]);
-  const double cp = std::cos(rpy[1]), sp = std::sin(rpy[1]);
-  const double cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
-  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
-  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
-  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
-}
-
-template <class C> static bool chain_matches(const ArmEnvChain &ch) {
-  for (int k = 0; k < 3; ++k)
-    if (ch.base_xyz[k] != 0.0 || ch.base_rpy[k] != 0.0) return false;
-  for (int j = 0; j < NJ; ++j) {
-    double R[9];
-    rpy_to_mat(ch.origin_rpy[j], R);
-    for (int c = 0; c < 3; ++c) {
-      if (std::fabs(ch.origin_xyz[j][c] - C::xyz[j][c]) > 1e-12) return false;
-      for (int r = 0; r < 3; ++r) {
-        const double want = (r == C::perm[j][c]) ? (double)C::sgn[j][c] : 0.0;
-        if (std::fabs(R[3 * r + c] - want) > 1e-9) return false;
-      }
-    }
-  }
-  return true;
-}
-
-struct EngineBase {
-  virtual ~EngineBase() {
-    if (actor_buf) (void)hipFree(actor_buf);
-  }
-  virtual int init(const ArmEnvConfig &cfg) = 0;
-  virtual int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) = 0;
-  virtual int step(const StepIO &io, hipStream_t s) = 0;
-  virtual int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) = 0;
-  PolicyParams pol{};
-  float *actor_buf = nullptr;   // packed W1P | W2P | B2W3 on the handle's device
-  int set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
-                int in_dim, float bound, hipStream_t s);
-  int actor_forward(int64_t n, const float *states, float *actions, hipStream_t s);
-  virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
-  virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
-  virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
-                        hipStream_t s) = 0;
-  virtual int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
-                        const double *ep_return, const double *aux, hipStream_t s) = 0;
-  virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
-  virtual int counters(uint64_t out[8], hipStream_t s) = 0;
-  virtual int summary(double *out_dev, hipStream_t s) = 0;
-  virtual const char *name() const = 0;
-};
-
-static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                           const float *b3, int in_dim, float bound, hipStream_t s) {
@@ -149,186 +56,22 @@ int EngineBase::actor_forward(int64_t n, const float *states, float *actions, hi
   return ARMENV_OK;
 }
 
-template <class C, typename T> struct Engine final : EngineBase {
-  EnvParams<T> P{};
-  void *pool = nullptr;
-  int block = 256;
-  int task = ARMENV_TASK_REACH;
-  std::string kname;
-
-  ~Engine() override {
-    if (pool) (void)hipFree(pool);
-  }
-
-  int init(const ArmEnvConfig &cfg) override {
-    const int64_t n = cfg.num_envs;
-    P.n = n;
-    // carve one allocation, 256-byte aligned sections
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
-    const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
-    const size_t o_ls = take(n), o_cnt = take(8 * 8), o_tmp = take(sizeof(T) * 4);
-    task = cfg.task;
-    const size_t o_aux = take(task == ARMENV_TASK_PUSH ? sizeof(T) * 7 * n : 0);
-    if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
-    HIP_TRY(hipMemset(pool, 0, off));
-    char *b = static_cast<char *>(pool);
-    P.q = reinterpret_cast<T *>(b + o_q);
-    P.ep_return = reinterpret_cast<T *>(b + o_er);
-    P.last_return = reinterpret_cast<T *>(b + o_lr);
-    P.goal = reinterpret_cast<float *>(b + o_goal);
-    P.step = reinterpret_cast<int32_t *>(b + o_step);
-    P.episode = reinterpret_cast<uint32_t *>(b + o_ep);
-    P.last_len = reinterpret_cast<int32_t *>(b + o_ll);
-    P.last_success = reinterpret_cast<uint8_t *>(b + o_ls);
-    P.counters = reinterpret_cast<unsigned long long *>(b + o_cnt);
-    T *tmp = reinterpret_cast<T *>(b + o_tmp);
-    P.aux = task == ARMENV_TASK_PUSH ? reinterpret_cast<T *>(b + o_aux) : nullptr;
-    P.push_success_dis = (T)cfg.push_success_dis;
-    P.push_cube_half = (T)cfg.push_cube_half;
-    P.push_eef_radius = (T)cfg.push_eef_radius;
-    P.push_rest_z = cfg.push_rest_z;
-    P.push_place_min = cfg.push_place_min;
-    P.push_place_max = cfg.push_place_max;
-
-    P.dv = (T)cfg.dv;
-    P.reach_dis = (T)cfg.reach_dis;
-    P.max_steps = cfg.max_steps;
-    P.auto_reset = cfg.auto_reset;
-    P.seed = cfg.seed;
-    P.env_id0 = cfg.env_id_offset;
-    for (int k = 0; k < 3; ++k) {
-      P.box_lo[k] = (T)cfg.box_lo[k]; P.box_hi[k] = (T)cfg.box_hi[k];
-      P.goal_lo[k] = cfg.goal_lo[k]; P.goal_hi[k] = cfg.goal_hi[k];
-    }
-    for (int j = 0; j < NJ; ++j) {
-      P.q_init[j] = (T)cfg.q_init[j];
-      P.ik.lim_lo[j] = (T)cfg.chain.limit_lo[j];
-      P.ik.lim_hi[j] = (T)cfg.chain.limit_hi[j];
-    }
-    for (int k = 0; k < 4; ++k) P.ik.tq[k] = (T)cfg.target_quat[k];
-    P.ik.lambda = (T)cfg.ik_lambda;
-    P.ik.residual = (T)cfg.ik_residual;
-    P.ik.max_dtheta = (T)cfg.ik_max_dtheta;
-    P.ik.max_iters = cfg.ik_max_iters;
-    P.ik.exit_mode = cfg.ik_exit_mode;
-    P.ik.angle_f32 = cfg.ik_angle_f32;
-    P.ik.clamp_limits = cfg.clamp_joint_limits;
-    for (int j = 0; j < NJ; ++j) {
-      double R[9];
-      rpy_to_mat(cfg.chain.origin_rpy[j], R);
-      for (int k = 0; k < 9; ++k) P.chain.R[j][k] = (T)R[k];
-      for (int k = 0; k < 3; ++k) P.chain.xyz[j][k] = (T)cfg.chain.origin_xyz[j][k];
-    }
-    {
-      double R[9];
-      rpy_to_mat(cfg.chain.base_rpy, R);
-      for (int k = 0; k < 9; ++k) P.chain.base_R[k] = (T)R[k];
-      for (int k = 0; k < 3; ++k) P.chain.base_p[k] = (T)cfg.chain.base_xyz[k];
-    }
-    hipLaunchKernelGGL((init_consts_kernel<C, T>), dim3(1), dim3(64), 0, 0, P, tmp);
-    HIP_TRY(hipGetLastError());
-    T host_p[3];
-    HIP_TRY(hipMemcpy(host_p, tmp, sizeof host_p, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 3; ++k) P.p_init[k] = host_p[k];
-    if (const char *bs = getenv("ARMENV_BLOCK")) {
-      const int v = atoi(bs);
-      if (v == 64 || v == 128 || v == 256) block = v;
-    }
-    kname = std::string(task == ARMENV_TASK_PUSH ? "push_step<" : "reach_step<") + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
-    return ARMENV_OK;
-  }
-
-  int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) override {
-    if (task == ARMENV_TASK_PUSH)
-      hipLaunchKernelGGL((push_reset_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, mask, goal, obs);
-    else
-      hipLaunchKernelGGL((reach_reset_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, mask, goal, obs);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  int step(const StepIO &io, hipStream_t s) override {
-    if (task == ARMENV_TASK_PUSH)
-      hipLaunchKernelGGL((env_step_kernel<PushLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
-    else
-      hipLaunchKernelGGL((env_step_kernel<ReachLane<C, T>, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  template <class Lane, int POLICY>
-  void launch_rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
-    hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
-                       actions, io0, actions_out);
-  }
-  template <class Lane>
-  void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
-    if (actions) launch_rollout<Lane, ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
-    else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<Lane, ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
-    else if (pol.kind == ARMENV_POLICY_ACTOR_F16X3) launch_rollout<Lane, ARMENV_POLICY_ACTOR_F16X3>(steps, actions, io0, actions_out, s);
-    else launch_rollout<Lane, ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
-  }
-  int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {
-    if (task == ARMENV_TASK_PUSH) launch_rollout_policy<PushLane<C, T>>(steps, actions, io0, actions_out, s);
-    else launch_rollout_policy<ReachLane<C, T>>(steps, actions, io0, actions_out, s);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) override {
-    hipLaunchKernelGGL((fk_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, pos, quat);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) override {
-    hipLaunchKernelGGL((ik_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, tgt, q_out, iters);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
-                hipStream_t s) override {
-    hipLaunchKernelGGL((get_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
-                       ep_return, aux);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
-                const double *ep_return, const double *aux, hipStream_t s) override {
-    hipLaunchKernelGGL((set_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
-                       ep_return, aux);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) override {
-    hipLaunchKernelGGL((episode_stats_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, last_return,
-                       last_len, last_success);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  int counters(uint64_t out[8], hipStream_t s) override {
-    HIP_TRY(hipMemcpyAsync(out, P.counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return ARMENV_OK;
-  }
-  int summary(double *out_dev, hipStream_t s) override {
-    HIP_TRY(hipMemsetAsync(out_dev, 0, 8 * sizeof(double), s));
-    hipLaunchKernelGGL((env_summary_kernel<C, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, task, out_dev);
-    HIP_TRY(hipGetLastError());
-    return ARMENV_OK;
-  }
-  const char *name() const override { return kname.c_str(); }
-};
-
 struct ArmEnv {
   ArmEnvConfig cfg;
   std::unique_ptr<EngineBase> eng;
 };
 
-template <typename T> static EngineBase *make_engine(const ArmEnvConfig &cfg) {
-  if (cfg.fk_path == ARMENV_FK_AUTO) {
-    if (chain_matches<KukaChain>(cfg.chain)) return new (std::nothrow) Engine<KukaChain, T>();
-    if (chain_matches<DianaChain>(cfg.chain)) return new (std::nothrow) Engine<DianaChain, T>();
+static EngineBase *make_engine(const ArmEnvConfig &cfg) {
+#ifdef ARMENV_TIMELINE   // the instrumented build (make timeline) carries the f64 reach engine only
+  return cfg.task == ARMENV_TASK_REACH && cfg.precision == 64 ? armenv_make_engine_reach_f64(cfg) : nullptr;
+#endif
+  const bool d = cfg.precision == 64;
+  switch (cfg.task) {
+    case ARMENV_TASK_REACH: return d ? armenv_make_engine_reach_f64(cfg) : armenv_make_engine_reach_f32(cfg);
+    case ARMENV_TASK_PUSH: return d ? armenv_make_engine_push_f64(cfg) : armenv_make_engine_push_f32(cfg);
+    case ARMENV_TASK_PICK: return d ? armenv_make_engine_pick_f64(cfg) : armenv_make_engine_pick_f32(cfg);
   }
-  return new (std::nothrow) Engine<GenericChain, T>();
+  return nullptr;
 }
 
 static void fill_chain(ArmEnvChain *out, const double (*xyz)[3], const double (*rpy)[3], const double *lo,
@@ -343,19 +86,6 @@ static void fill_chain(ArmEnvChain *out, const double (*xyz)[3], const double (*
 
 extern "C" {
 
-#ifdef ARMENV_TIMELINE
-int armenv_dbg_set_timeline(unsigned long long *buf_dev) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf_dev, sizeof buf_dev);
-}
-int armenv_dbg_sections(unsigned long long out[8], int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(armenv::g_sections), 8 * sizeof(unsigned long long));
-  if (reset) {
-    unsigned long long z[8] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(armenv::g_sections), z, sizeof z);
-  }
-  return rc;
-}
-#endif
 
 int32_t armenv_abi_version(void) { return ARMENV_ABI_VERSION; }
 const char *armenv_last_error(void) { return g_err.c_str(); }
@@ -370,7 +100,7 @@ int armenv_builtin_chain(int32_t robot, ArmEnvChain *out) {
 
 int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   if (!c) return fail(ARMENV_EINVAL, "armenv_default_config: cfg is NULL");
-  if (task != ARMENV_TASK_REACH && task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "unknown task %d", task);
+  if (task < ARMENV_TASK_REACH || task > ARMENV_TASK_PICK) return fail(ARMENV_EINVAL, "unknown task %d", task);
   std::memset(c, 0, sizeof *c);
   c->abi_version = ARMENV_ABI_VERSION;
   c->device = 0;
@@ -387,7 +117,8 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->clamp_joint_limits = 0;
   const double lo[3] = {0.2, -0.3, 0.0}, hi[3] = {0.7, 0.3, 0.55};
   for (int k = 0; k < 3; ++k) { c->box_lo[k] = lo[k]; c->box_hi[k] = hi[k]; c->goal_lo[k] = lo[k]; c->goal_hi[k] = hi[k]; }
-  if (task == ARMENV_TASK_PUSH) c->box_hi[2] = 0.1;
+  if (task == ARMENV_TASK_PUSH) c->box_hi[2] = 0.1;                 // rl_push_env.py:314
+  if (task == ARMENV_TASK_PICK) c->box_hi[2] = 0.55 + 0.257;       // rl_pick_env.py:313
   // p.getQuaternionFromEuler([0, -pi, pi/2]) (Bullet setEulerZYX)
   {
     const double pi = 3.14159265358979323846;
@@ -412,6 +143,9 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->push_rest_z = 0.01;
   c->push_place_min = 0.22;
   c->push_place_max = 0.25;
+  c->pick_gripper_length = 0.257;   // rl_pick_env.py:79
+  c->pick_trigger_dis = 0.006;      // rl_pick_env.py:412
+  c->pick_jaw_half = 0.02;
   return armenv_builtin_chain(ARMENV_ROBOT_KUKA, &c->chain);
 }
 
@@ -422,7 +156,7 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
     return fail(ARMENV_EINVAL, "armenv_create: abi_version %d, library is %d", cfg->abi_version, ARMENV_ABI_VERSION);
   if (cfg->num_envs < 1) return fail(ARMENV_EINVAL, "armenv_create: num_envs must be >= 1");
   if (cfg->precision != 64 && cfg->precision != 32) return fail(ARMENV_EINVAL, "armenv_create: precision must be 32 or 64");
-  if (cfg->task != ARMENV_TASK_REACH && cfg->task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_create: unknown task %d", cfg->task);
+  if (cfg->task < ARMENV_TASK_REACH || cfg->task > ARMENV_TASK_PICK) return fail(ARMENV_EINVAL, "armenv_create: unknown task %d", cfg->task);
   if (cfg->ik_max_iters < 0 || cfg->ik_max_iters > 1000) return fail(ARMENV_EINVAL, "armenv_create: ik_max_iters out of range");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -433,7 +167,7 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   std::unique_ptr<ArmEnv> env(new (std::nothrow) ArmEnv());
   if (!env) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
   env->cfg = *cfg;
-  env->eng.reset(cfg->precision == 64 ? make_engine<double>(*cfg) : make_engine<float>(*cfg));
+  env->eng.reset(make_engine(*cfg));
   if (!env->eng) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
   const int rc = env->eng->init(*cfg);
   if (rc != ARMENV_OK) return rc;
@@ -494,16 +228,16 @@ int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_
 int armenv_get_state(ArmEnv *env, double *q_dev, float *goal_dev, int32_t *step_dev, uint32_t *episode_dev,
                      double *ep_return_dev, double *aux_dev, void *stream) {
   ENV_ENTER(env);
-  if (aux_dev && env->cfg.task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_get_state: aux is only defined for the push task");
-  if (goal_dev && env->cfg.task == ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_get_state: push keeps cube/target in aux, not goal");
+  if (aux_dev && env->cfg.task == ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_get_state: aux is only defined for the push and pick tasks");
+  if (goal_dev && env->cfg.task != ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_get_state: push / pick keep cube and target in aux, not goal");
   return env->eng->get_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, const int32_t *step_dev,
                      const uint32_t *episode_dev, const double *ep_return_dev, const double *aux_dev, void *stream) {
   ENV_ENTER(env);
-  if (aux_dev && env->cfg.task != ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_set_state: aux is only defined for the push task");
-  if (goal_dev && env->cfg.task == ARMENV_TASK_PUSH) return fail(ARMENV_EINVAL, "armenv_set_state: push keeps cube/target in aux, not goal");
+  if (aux_dev && env->cfg.task == ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_set_state: aux is only defined for the push and pick tasks");
+  if (goal_dev && env->cfg.task != ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_set_state: push / pick keep cube and target in aux, not goal");
   return env->eng->set_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -625,7 +359,11 @@ int armenv_her_sample(int32_t device, const ArmEnvHerArgs *a, void *stream) {
 }
 
 int64_t armenv_num_envs(const ArmEnv *env) { return env ? env->cfg.num_envs : 0; }
-int32_t armenv_obs_dim(const ArmEnv *env) { return env ? (env->cfg.task == ARMENV_TASK_PUSH ? 9 : 6) : 0; }
+int32_t armenv_obs_dim(const ArmEnv *env) { return env ? (env->cfg.task == ARMENV_TASK_REACH ? 6 : 9) : 0; }
+int32_t armenv_aux_dim(const ArmEnv *env) {
+  if (!env) return 0;
+  return env->cfg.task == ARMENV_TASK_PUSH ? 8 : (env->cfg.task == ARMENV_TASK_PICK ? 12 : 0);
+}
 int32_t armenv_action_dim(const ArmEnv *) { return 3; }
 const char *armenv_kernel_name(const ArmEnv *env) { return env ? env->eng->name() : ""; }
 

@@ -1,0 +1,282 @@
+// armenv_engine.h -- host-side engine shared by the translation units of libarmenv.so: error plumbing, device guard,
+// chain classification, the EngineBase interface the C ABI (armenv.hip) talks to, and the Engine template that owns
+// one handle's HBM state and launches the kernels of armenv_env.h.
+//
+// Data layout in HBM (N envs, T = f64 or f32 by ArmEnvConfig.precision), struct-of-arrays with the env index fastest
+// so that a wave's 64 lanes touch 64 consecutive elements of every array:
+//   q[7][N] T | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
+//   last_len[N] i32 | last_success[N] u8 | counters[8] u64 | push: aux[7][N] T | pick: aux[11][N] T
+// Caller-facing buffers keep the reference's array-of-struct shapes (action [N][3], obs [N][6|9]); a wave still
+// reads/writes one contiguous span of them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "armenv_env.h"
+
+// sets the thread-local message behind armenv_last_error() and returns `code` (armenv.hip)
+int armenv_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3), visibility("hidden")));
+#define fail armenv_fail
+
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(ARMENV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+static inline void rpy_to_mat(const double rpy[3], double R[9]) {  // row-major, Rz(yaw) Ry(pitch) Rx(roll)
+  const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]);
+  const double cp = std::cos(rpy[1]), sp = std::sin(rpy[1]);
+  const double cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
+  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+
+template <class C> static inline bool chain_matches(const ArmEnvChain &ch) {
+  for (int k = 0; k < 3; ++k)
+    if (ch.base_xyz[k] != 0.0 || ch.base_rpy[k] != 0.0) return false;
+  for (int j = 0; j < NJ; ++j) {
+    double R[9];
+    rpy_to_mat(ch.origin_rpy[j], R);
+    for (int c = 0; c < 3; ++c) {
+      if (std::fabs(ch.origin_xyz[j][c] - C::xyz[j][c]) > 1e-12) return false;
+      for (int r = 0; r < 3; ++r) {
+        const double want = (r == C::perm[j][c]) ? (double)C::sgn[j][c] : 0.0;
+        if (std::fabs(R[3 * r + c] - want) > 1e-9) return false;
+      }
+    }
+  }
+  return true;
+}
+
+struct EngineBase {
+  virtual ~EngineBase() {
+    if (actor_buf) (void)hipFree(actor_buf);
+  }
+  virtual int init(const ArmEnvConfig &cfg) = 0;
+  virtual int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) = 0;
+  virtual int step(const StepIO &io, hipStream_t s) = 0;
+  virtual int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) = 0;
+  PolicyParams pol{};
+  float *actor_buf = nullptr;   // packed W1P | W2P | B2W3 on the handle's device
+  int set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                int in_dim, float bound, hipStream_t s);
+  int actor_forward(int64_t n, const float *states, float *actions, hipStream_t s);
+  virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
+  virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
+  virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
+                        hipStream_t s) = 0;
+  virtual int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
+                        const double *ep_return, const double *aux, hipStream_t s) = 0;
+  virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
+  virtual int counters(uint64_t out[8], hipStream_t s) = 0;
+  virtual int summary(double *out_dev, hipStream_t s) = 0;
+  virtual const char *name() const = 0;
+};
+
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+
+// One engine per (task, chain, precision); each task x precision pair is compiled in its own translation unit
+// (armenv_task.hip, see the Makefile) so that the kernel variants build in parallel.
+template <template <class, class> class LaneT, class C, typename T> struct Engine final : EngineBase {
+  using Lane = LaneT<C, T>;
+  EnvParams<T> P{};
+  void *pool = nullptr;
+  int block = 256;
+  static constexpr int task = Lane::kTask;
+  std::string kname;
+
+  ~Engine() override {
+    if (pool) (void)hipFree(pool);
+  }
+
+  int init(const ArmEnvConfig &cfg) override {
+    const int64_t n = cfg.num_envs;
+    P.n = n;
+    // carve one allocation, 256-byte aligned sections
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
+    const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
+    const size_t o_ls = take(n), o_cnt = take(8 * 8), o_tmp = take(sizeof(T) * 4);
+    const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n);
+    if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
+    HIP_TRY(hipMemset(pool, 0, off));
+    char *b = static_cast<char *>(pool);
+    P.q = reinterpret_cast<T *>(b + o_q);
+    P.ep_return = reinterpret_cast<T *>(b + o_er);
+    P.last_return = reinterpret_cast<T *>(b + o_lr);
+    P.goal = reinterpret_cast<float *>(b + o_goal);
+    P.step = reinterpret_cast<int32_t *>(b + o_step);
+    P.episode = reinterpret_cast<uint32_t *>(b + o_ep);
+    P.last_len = reinterpret_cast<int32_t *>(b + o_ll);
+    P.last_success = reinterpret_cast<uint8_t *>(b + o_ls);
+    P.counters = reinterpret_cast<unsigned long long *>(b + o_cnt);
+    T *tmp = reinterpret_cast<T *>(b + o_tmp);
+    P.aux = Lane::kAuxRows ? reinterpret_cast<T *>(b + o_aux) : nullptr;
+    P.push_success_dis = (T)cfg.push_success_dis;
+    P.push_cube_half = (T)cfg.push_cube_half;
+    P.push_eef_radius = (T)cfg.push_eef_radius;
+    P.push_rest_z = cfg.push_rest_z;
+    P.push_place_min = cfg.push_place_min;
+    P.push_place_max = cfg.push_place_max;
+    P.pick_gripper_length = (T)cfg.pick_gripper_length;
+    P.pick_trigger_dis = (T)cfg.pick_trigger_dis;
+    P.pick_jaw_half = (T)cfg.pick_jaw_half;
+
+    P.dv = (T)cfg.dv;
+    P.reach_dis = (T)cfg.reach_dis;
+    P.max_steps = cfg.max_steps;
+    P.auto_reset = cfg.auto_reset;
+    P.seed = cfg.seed;
+    P.env_id0 = cfg.env_id_offset;
+    for (int k = 0; k < 3; ++k) {
+      P.box_lo[k] = (T)cfg.box_lo[k]; P.box_hi[k] = (T)cfg.box_hi[k];
+      P.goal_lo[k] = cfg.goal_lo[k]; P.goal_hi[k] = cfg.goal_hi[k];
+    }
+    for (int j = 0; j < NJ; ++j) {
+      P.q_init[j] = (T)cfg.q_init[j];
+      P.ik.lim_lo[j] = (T)cfg.chain.limit_lo[j];
+      P.ik.lim_hi[j] = (T)cfg.chain.limit_hi[j];
+    }
+    for (int k = 0; k < 4; ++k) P.ik.tq[k] = (T)cfg.target_quat[k];
+    P.ik.lambda = (T)cfg.ik_lambda;
+    P.ik.residual = (T)cfg.ik_residual;
+    P.ik.max_dtheta = (T)cfg.ik_max_dtheta;
+    P.ik.max_iters = cfg.ik_max_iters;
+    P.ik.exit_mode = cfg.ik_exit_mode;
+    P.ik.angle_f32 = cfg.ik_angle_f32;
+    P.ik.clamp_limits = cfg.clamp_joint_limits;
+    for (int j = 0; j < NJ; ++j) {
+      double R[9];
+      rpy_to_mat(cfg.chain.origin_rpy[j], R);
+      for (int k = 0; k < 9; ++k) P.chain.R[j][k] = (T)R[k];
+      for (int k = 0; k < 3; ++k) P.chain.xyz[j][k] = (T)cfg.chain.origin_xyz[j][k];
+    }
+    {
+      double R[9];
+      rpy_to_mat(cfg.chain.base_rpy, R);
+      for (int k = 0; k < 9; ++k) P.chain.base_R[k] = (T)R[k];
+      for (int k = 0; k < 3; ++k) P.chain.base_p[k] = (T)cfg.chain.base_xyz[k];
+    }
+    hipLaunchKernelGGL((init_consts_kernel<C, T>), dim3(1), dim3(64), 0, 0, P, tmp);
+    HIP_TRY(hipGetLastError());
+    T host_p[3];
+    HIP_TRY(hipMemcpy(host_p, tmp, sizeof host_p, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) P.p_init[k] = host_p[k];
+    if (const char *bs = getenv("ARMENV_BLOCK")) {
+      const int v = atoi(bs);
+      if (v == 64 || v == 128 || v == 256) block = v;
+    }
+    kname = std::string(Lane::kName) + "_step<" + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
+    return ARMENV_OK;
+  }
+
+  int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) override {
+    hipLaunchKernelGGL((env_reset_kernel<Lane, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, mask, goal, obs);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int step(const StepIO &io, hipStream_t s) override {
+    hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  template <int POLICY>
+  void launch_rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
+    hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
+                       actions, io0, actions_out);
+  }
+  void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
+    if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
+    else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
+    else if (pol.kind == ARMENV_POLICY_ACTOR_F16X3) launch_rollout<ARMENV_POLICY_ACTOR_F16X3>(steps, actions, io0, actions_out, s);
+    else launch_rollout<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
+  }
+  int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {
+    launch_rollout_policy(steps, actions, io0, actions_out, s);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) override {
+    hipLaunchKernelGGL((fk_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, pos, quat);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) override {
+    hipLaunchKernelGGL((ik_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, tgt, q_out, iters);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
+                hipStream_t s) override {
+    hipLaunchKernelGGL((get_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
+                       ep_return, aux, (int)Lane::kAuxRows, (int)Lane::kAuxDim);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
+                const double *ep_return, const double *aux, hipStream_t s) override {
+    hipLaunchKernelGGL((set_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
+                       ep_return, aux, (int)Lane::kAuxRows, (int)Lane::kAuxDim);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) override {
+    hipLaunchKernelGGL((episode_stats_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, last_return,
+                       last_len, last_success);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int counters(uint64_t out[8], hipStream_t s) override {
+    HIP_TRY(hipMemcpyAsync(out, P.counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ARMENV_OK;
+  }
+  int summary(double *out_dev, hipStream_t s) override {
+    HIP_TRY(hipMemsetAsync(out_dev, 0, 8 * sizeof(double), s));
+    hipLaunchKernelGGL((env_summary_kernel<Lane, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  const char *name() const override { return kname.c_str(); }
+};
+
+
+template <template <class, class> class LaneT, typename T> static EngineBase *make_task_engine(const ArmEnvConfig &cfg) {
+  if (cfg.fk_path == ARMENV_FK_AUTO) {
+    if (chain_matches<KukaChain>(cfg.chain)) return new (std::nothrow) Engine<LaneT, KukaChain, T>();
+    if (chain_matches<DianaChain>(cfg.chain)) return new (std::nothrow) Engine<LaneT, DianaChain, T>();
+  }
+  return new (std::nothrow) Engine<LaneT, GenericChain, T>();
+}
+
+// the six translation units of armenv_task.hip
+EngineBase *armenv_make_engine_reach_f64(const ArmEnvConfig &cfg) __attribute__((visibility("hidden")));
+EngineBase *armenv_make_engine_reach_f32(const ArmEnvConfig &cfg) __attribute__((visibility("hidden")));
+EngineBase *armenv_make_engine_push_f64(const ArmEnvConfig &cfg) __attribute__((visibility("hidden")));
+EngineBase *armenv_make_engine_push_f32(const ArmEnvConfig &cfg) __attribute__((visibility("hidden")));
+EngineBase *armenv_make_engine_pick_f64(const ArmEnvConfig &cfg) __attribute__((visibility("hidden")));
+EngineBase *armenv_make_engine_pick_f32(const ArmEnvConfig &cfg) __attribute__((visibility("hidden")));

@@ -1,5 +1,5 @@
 // armenv_env.h -- device side of the env engine: per-env state layout (EnvParams), the per-lane env bodies (ReachLane,
-// PushLane), and the kernels built from them: reset, one-step, T-step rollout with optional fused policy, FK / IK
+// PushLane, PickLane), and the kernels built from them: reset, one-step, T-step rollout with optional fused policy, FK / IK
 // entry kernels, state exchange, actor entry + weight packing.  Host side and C ABI: armenv.hip.
 #pragma once
 #include "../../include/armenv.h"
@@ -20,7 +20,7 @@ template <typename T> struct EnvParams {
   int32_t *last_len;
   uint8_t *last_success;
   unsigned long long *counters;
-  T *aux;  // push only: [7][N] = cube xyz, target xyz, d_last
+  T *aux;  // push: [7][N] = cube xyz, target xyz, d_last;  pick: [11][N] = the same + gripper state + hold offset xyz
   int64_t n;
   // task constants
   T dv;
@@ -38,6 +38,8 @@ template <typename T> struct EnvParams {
   // push task (rl_push_env.py): simplified pusher model + reward constants
   T push_success_dis, push_cube_half, push_eef_radius;
   double push_rest_z, push_place_min, push_place_max;
+  // pick task (rl_pick_env.py): gripper model
+  T pick_gripper_length, pick_trigger_dis, pick_jaw_half;
   IKParams<T> ik;
   ChainDev<T> chain;
 };
@@ -90,32 +92,10 @@ __global__ void init_consts_kernel(EnvParams<T> P, T *out) {
   out[0] = S.p[0]; out[1] = S.p[1]; out[2] = S.p[2];
 }
 
-// RLReachEnv.reset (rl_reach_env.py:132-217) for masked envs.
-template <typename T>
-__global__ __launch_bounds__(256) void reach_reset_kernel(EnvParams<T> P, const uint8_t *mask, const float *goal_in,
-                                                          float *obs) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n) return;
-  if (mask && !mask[i]) return;
-  float g[3];
-  if (goal_in) {
-    g[0] = goal_in[3 * i]; g[1] = goal_in[3 * i + 1]; g[2] = goal_in[3 * i + 2];
-  } else {
-    const uint32_t ep = P.episode[i];
-    sample_goal(P, i, ep, g);
-    P.episode[i] = ep + 1u;
-  }
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.q_init[j]; });
-  static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = g[k]; });
-  P.step[i] = 0;
-  P.ep_return[i] = T(0);
-  if (obs) store_obs6<T>(obs, i, P.p_init, g);
-}
-
 // Optional per-wave timeline (make timeline; csrc/exp/run_timeline.py): wall-clock stamps at kernel entry, after
 // the state loads, after the IK loop and at exit, plus IK update count and placement.  Off in the product build.
 #ifdef ARMENV_TIMELINE
-__device__ unsigned long long *g_timeline;
+static __device__ unsigned long long *g_timeline;
 #define TL_STAMP(name) const unsigned long long name = wall_clock64()
 #else
 #define TL_STAMP(name)
@@ -150,7 +130,7 @@ __global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH 
 }
 
 // torch Linear layouts ([out][in]) -> the operand layouts of armenv_actor.h
-__global__ void actor_pack_kernel(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+static __global__ void actor_pack_kernel(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                                   int in_dim, float *W1P, float *W2P, float *B2W3, _Float16 *W2H, _Float16 *W2L) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ACTOR_HID * ACTOR_HID) {   // f16 hi/lo split of W2 in the 32x32x16 A-operand order
@@ -193,7 +173,39 @@ AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint3
 // kernel both run this code, so a rollout is bit-identical to T step launches.
 template <class C, typename T> struct ReachLane {
   using M = Mth<T>;
+  static constexpr int kTask = ARMENV_TASK_REACH;
   static constexpr int kObs = 6;
+  static constexpr int kAuxRows = 0, kAuxDim = 0;
+  static constexpr const char *kName = "reach";
+
+  // RLReachEnv.reset (rl_reach_env.py:132-217) of env i; goal_in (nullable) f32 [N][3].
+  static AE_DEV void reset_env(const EnvParams<T> &P, int64_t i, const float *goal_in, float *obs) {
+    float g[3];
+    if (goal_in) {
+      g[0] = goal_in[3 * i]; g[1] = goal_in[3 * i + 1]; g[2] = goal_in[3 * i + 2];
+    } else {
+      const uint32_t ep = P.episode[i];
+      sample_goal(P, i, ep, g);
+      P.episode[i] = ep + 1u;
+    }
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.q_init[j]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = g[k]; });
+    P.step[i] = 0;
+    P.ep_return[i] = T(0);
+    if (obs) store_obs6<T>(obs, i, P.p_init, g);
+  }
+
+  // distance the logging summary reports: |FK(q) - goal|
+  static AE_DEV double summary_distance(const EnvParams<T> &P, int64_t i) {
+    T q[NJ], cq[NJ], sq[NJ];
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * P.n + i]; });
+    sincos_all<T>(q, cq, sq);
+    FKState<T> S;
+    fk<C, T>(P.chain, cq, sq, S);
+    const T x = S.p[0] - (T)P.goal[0 * P.n + i], y = S.p[1] - (T)P.goal[1 * P.n + i], z = S.p[2] - (T)P.goal[2 * P.n + i];
+    return (double)M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
+  }
+
   T q[NJ];
   float g[3];
   int32_t step;
@@ -297,34 +309,57 @@ template <class C, typename T> struct ReachLane {
   }
 };
 
-// ---- push task (/root/reference/envs/rl_push_env.py) ---------------------------------------------------------------
-// Placement of cube and target: rejection sampling, <= 1000 tries, six draws per try (:195-214); f64 always.
-template <typename T>
-AE_DEV void push_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&cube)[3], T (&target)[3]) {
-  double cx = 0, cy = 0, tx = 0, ty = 0;
+// ---- push and pick tasks (/root/reference/envs/rl_push_env.py, envs/rl_pick_env.py) -------------------------------
+// Placement of cube and target: rejection sampling, <= 1000 tries (push :195-214, pick :190-208); f64 always.
+//   push: six draws per try (x, y, yaw, x_t, y_t, yaw_t), both bodies at the rest height, planar distance test;
+//   pick: seven draws per try (x, y, yaw, x_t, y_t, z_t, yaw_t), target anywhere in the workspace box, 3-D distance.
+template <bool PICK, typename T>
+AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&cube)[3], T (&target)[3]) {
+  double cx = 0, cy = 0, tx = 0, ty = 0, tz = P.push_rest_z;
+  constexpr uint32_t kBlocks = PICK ? 4u : 3u;
   for (uint32_t t = 0; t < 1000u; ++t) {
     double u0, u1, u2, u3, u4, u5;
-    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 0u, u0, u1);
-    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 1u, u2, u3);
-    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 3u * t + 2u, u4, u5);
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, kBlocks * t + 0u, u0, u1);
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, kBlocks * t + 1u, u2, u3);
+    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, kBlocks * t + 2u, u4, u5);
     cx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u0;
     cy = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u1;
     tx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u3;
     ty = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u4;
     const double dx = cx - tx, dy = cy - ty;
-    const double d = ::sqrt(::fma(dx, dx, dy * dy));   // both rest at the same z
+    double d;
+    if constexpr (PICK) {
+      tz = P.goal_lo[2] + (P.goal_hi[2] - P.goal_lo[2]) * u5;      // 7th draw (u6, the target yaw) is unused
+      const double dz = P.push_rest_z - tz;
+      d = ::sqrt(::fma(dx, dx, ::fma(dy, dy, dz * dz)));
+    } else {
+      d = ::sqrt(::fma(dx, dx, dy * dy));   // both rest at the same z
+      (void)u5;
+    }
+    (void)u2;
     if (d >= P.push_place_min && d <= P.push_place_max) break;
-    (void)u2; (void)u5;
   }
   cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = (T)P.push_rest_z;
-  target[0] = (T)tx; target[1] = (T)ty; target[2] = (T)P.push_rest_z;
+  target[0] = (T)tx; target[1] = (T)ty; target[2] = (T)tz;
 }
 
-template <class C, typename T> struct PushLane {
+// Per-lane state and step body of the two cube tasks.
+//   PICK = false: RLPushEnv (rl_push_env.py:310-440).
+//   PICK = true:  RLPickEnv (rl_pick_env.py:310-440): same reward / done logic; the arm differs in three ways --
+//     the start position is rounded through float (:328), z is clipped to [0, 0.55 + gripper_length] (:313), and only
+//     joints 0..5 receive the IK result (:343 `range(self.end_effector_index)`), so joint 7 keeps its reset value and
+//     the tool's yaw error is never corrected; the gripper (closed by getClosestPoints, :412-416) is the build's own
+//     model, see grip().
+template <class C, typename T, bool PICK> struct CubeLane {
   using M = Mth<T>;
+  static constexpr int kTask = PICK ? ARMENV_TASK_PICK : ARMENV_TASK_PUSH;
   static constexpr int kObs = 9;
+  static constexpr int kAuxRows = PICK ? 11 : 7, kAuxDim = PICK ? 12 : 8;
+  static constexpr const char *kName = PICK ? "pick" : "push";
   T q[NJ];
   T cube[3], target[3], d_last;
+  T grip = T(0);            // pick: 0 open, 1 closed, 2 closed and holding the cube
+  T off[3] = {T(0), T(0), T(0)};   // pick: cube - tip while held
   int32_t step;
   T ep_ret;
   uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;
@@ -345,11 +380,43 @@ template <class C, typename T> struct PushLane {
     return M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
   }
 
+  static AE_DEV double summary_distance(const EnvParams<T> &P, int64_t i) {
+    const T x = P.aux[0 * P.n + i] - P.aux[3 * P.n + i], y = P.aux[1 * P.n + i] - P.aux[4 * P.n + i],
+            z = P.aux[2 * P.n + i] - P.aux[5 * P.n + i];
+    return (double)M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
+  }
+
+  // RLPushEnv.reset (rl_push_env.py:145-256) / RLPickEnv.reset (rl_pick_env.py:140-252) of env i; goal_in (nullable)
+  // f32 [N][6] = cube xyz, target xyz.
+  static AE_DEV void reset_env(const EnvParams<T> &P, int64_t i, const float *goal_in, float *obs) {
+    const int64_t n = P.n;
+    T cube[3], target[3];
+    if (goal_in) {
+      static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = (T)goal_in[6 * i + k]; target[k] = (T)goal_in[6 * i + 3 + k]; });
+    } else {
+      const uint32_t ep = P.episode[i];
+      cube_sample<PICK, T>(P, i, ep, cube, target);
+      P.episode[i] = ep + 1u;
+    }
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.q_init[j]; });
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
+    const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
+    P.aux[(int64_t)6 * n + i] = M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
+    if constexpr (PICK) static_for<7, 11>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = T(0); });   // gripper open (:235-238)
+    P.step[i] = 0;
+    P.ep_return[i] = T(0);
+    if (obs) store_obs9<T>(obs, i, P.p_init, cube, target);
+  }
+
   AE_DEV void load(const EnvParams<T> &P, int64_t i) {
     const int64_t n = P.n;
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * n + i]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = P.aux[(int64_t)k * n + i]; target[k] = P.aux[(int64_t)(3 + k) * n + i]; });
     d_last = P.aux[(int64_t)6 * n + i];
+    if constexpr (PICK) {
+      grip = P.aux[(int64_t)7 * n + i];
+      static_for<0, 3>([&](auto KI) { constexpr int k = KI; off[k] = P.aux[(int64_t)(8 + k) * n + i]; });
+    }
     step = P.step[i];
     ep_ret = P.ep_return[i];
   }
@@ -359,6 +426,10 @@ template <class C, typename T> struct PushLane {
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
     P.aux[(int64_t)6 * n + i] = d_last;
+    if constexpr (PICK) {
+      P.aux[(int64_t)7 * n + i] = grip;
+      static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)(8 + k) * n + i] = off[k]; });
+    }
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
     if (n_done) atomicAdd(&P.counters[0], (unsigned long long)n_done);
@@ -367,7 +438,7 @@ template <class C, typename T> struct PushLane {
     if (n_upd) atomicAdd(&P.counters[4], (unsigned long long)n_upd);
   }
 
-  // stepSimulation (:349), simplified: sphere (tool, radius r at the eef) vs axis-aligned box (cube, half-size h)
+  // stepSimulation (:349), simplified: sphere (tool, radius r, centre p) vs axis-aligned box (cube, half-size h)
   // overlap test; on overlap the cube is displaced horizontally -- along the contact normal by the penetration
   // depth when the tool centre is outside the footprint, ahead of the tool along its travel p0 -> p when inside.
   AE_DEV void contact(const EnvParams<T> &P, const T (&p0)[3], const T (&p)[3]) {
@@ -393,15 +464,67 @@ template <class C, typename T> struct PushLane {
     }
   }
 
-  // RLPushEnv.step + _reward (rl_push_env.py:310-440)
+  // Pick: gripper and cube after the arm's teleport (rl_pick_env.py:349 stepSimulation, :412-417 getClosestPoints ->
+  // close the fingers -> stepSimulation).  BUILD-DEFINED MODEL (Bullet's finger / cube contact dynamics are not
+  // restated): the gripper tip is the point gripper_length along the tool axis from the link-7
+  // frame, a sphere of radius push_eef_radius.
+  //   held cube:   rides with the tip (cube = tip + off), never below its rest height;
+  //   open gripper: closes for the rest of the episode once the tip sphere is within trigger_dis of the cube box
+  //                 (:412); it holds the cube iff the tip is then above the cube centre and the cube centre lies within
+  //                 jaw_half of the tool axis horizontally;
+  //   otherwise:   the tip pushes the cube like the push task's tool (contact()).
+  AE_DEV void grip_step(const EnvParams<T> &P, const T (&p0)[3], const FKState<T> &S) {
+    const T L = P.pick_gripper_length;
+    T tip[3], tip0[3];
+    static_for<0, 3>([&](auto KI) {
+      constexpr int k = KI;
+      tip[k] = M::fma(L, S.W[6 + k], S.p[k]);        // third column of the link-7 rotation = tool axis
+      tip0[k] = tip[k] - (S.p[k] - p0[k]);           // previous tip under an unchanged tool orientation
+    });
+    if (grip == T(2)) {
+      cube[0] = tip[0] + off[0];
+      cube[1] = tip[1] + off[1];
+      const T z = tip[2] + off[2];
+      cube[2] = z < (T)P.push_rest_z ? (T)P.push_rest_z : z;
+      return;
+    }
+    if (grip == T(0)) {
+      const T h = P.push_cube_half;
+      T g2 = T(0);
+      static_for<0, 3>([&](auto KI) {
+        constexpr int k = KI;
+        const T lo = cube[k] - h, hi = cube[k] + h;
+        const T c = tip[k] < lo ? lo : (tip[k] > hi ? hi : tip[k]);
+        const T g = tip[k] - c;
+        g2 = M::fma(g, g, g2);
+      });
+      if (M::sqrt(g2) - P.push_eef_radius < P.pick_trigger_dis) {
+        const T hx = cube[0] - tip[0], hy = cube[1] - tip[1];
+        const bool hold = tip[2] >= cube[2] && M::sqrt(M::fma(hx, hx, hy * hy)) <= P.pick_jaw_half;
+        grip = hold ? T(2) : T(1);
+        if (hold) {
+          off[0] = hx; off[1] = hy; off[2] = cube[2] - tip[2];
+          return;
+        }
+      }
+    }
+    contact(P, tip0, tip);
+  }
+
   AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, const float (*prefetched)[3] = nullptr) {
     FKState<T> S;
     T tgt[3];
     T p0[3];
-    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
+    const T q7 = q[NJ - 1];
+    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
     if (prefetched) asm volatile("" ::"v"((*prefetched)[0]), "v"((*prefetched)[1]), "v"((*prefetched)[2]));
     n_upd += (uint32_t)updates;
-    contact(P, p0, S.p);                                                          // :349
+    if constexpr (PICK) {
+      q[NJ - 1] = q7;               // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
+      grip_step(P, p0, S);          // :349, :412-417
+    } else {
+      contact(P, p0, S.p);          // :349
+    }
     step += 1;                                                                    // :355
     const T d_cur = dist_ct();                                                    // :388
     T test = d_cur - d_last;                                                      // :390-392
@@ -435,9 +558,10 @@ template <class C, typename T> struct PushLane {
     }
     if (done && P.auto_reset) {
       const uint32_t ep = P.episode[i];
-      push_sample(P, i, ep, cube, target);
+      cube_sample<PICK, T>(P, i, ep, cube, target);
       P.episode[i] = ep + 1u;
       d_last = dist_ct();                                                         // :243-245
+      if constexpr (PICK) { grip = T(0); off[0] = off[1] = off[2] = T(0); }
       static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
       step = 0;
       ep_ret = T(0);
@@ -450,34 +574,21 @@ template <class C, typename T> struct PushLane {
     return updates;
   }
 };
+template <class C, typename T> using PushLane = CubeLane<C, T, false>;
+template <class C, typename T> using PickLane = CubeLane<C, T, true>;
 
-// RLPushEnv.reset (rl_push_env.py:145-256) for masked envs; goal_in f32 [N][6] = cube xyz, target xyz.
-template <typename T>
-__global__ __launch_bounds__(256) void push_reset_kernel(EnvParams<T> P, const uint8_t *mask, const float *goal_in, float *obs) {
+// reset() of the envs whose mask byte is set (mask == NULL: all).
+template <class Lane, typename T>
+__global__ __launch_bounds__(256) void env_reset_kernel(EnvParams<T> P, const uint8_t *mask, const float *goal_in, float *obs) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   if (mask && !mask[i]) return;
-  const int64_t n = P.n;
-  T cube[3], target[3];
-  if (goal_in) {
-    static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = (T)goal_in[6 * i + k]; target[k] = (T)goal_in[6 * i + 3 + k]; });
-  } else {
-    const uint32_t ep = P.episode[i];
-    push_sample(P, i, ep, cube, target);
-    P.episode[i] = ep + 1u;
-  }
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.q_init[j]; });
-  static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
-  const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
-  P.aux[(int64_t)6 * n + i] = Mth<T>::sqrt(Mth<T>::fma(x, x, Mth<T>::fma(y, y, z * z)));
-  P.step[i] = 0;
-  P.ep_return[i] = T(0);
-  if (obs) store_obs9<T>(obs, i, P.p_init, cube, target);
+  Lane::reset_env(P, i, goal_in, obs);
 }
 
 // One env step per launch: load state -> FK -> target = clip(p + dv a) -> DLS IK loop -> FK -> (push: contact) ->
 // reward / done -> obs pack -> episode accounting -> optional in-place reset -> store state.
-// Lane = ReachLane (rl_reach_env.py:219-319) or PushLane (rl_push_env.py:310-440).
+// Lane = ReachLane (rl_reach_env.py:219-319), PushLane (rl_push_env.py:310-440) or PickLane (rl_pick_env.py:310-440).
 template <class Lane, typename T>
 __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io) {
   TL_STAMP(tl0);
@@ -633,29 +744,16 @@ __global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, cons
 }
 
 // Logging summary without a host round trip: per-lane reach distance |FK(q) - goal| (reach) or cube-target distance
-// (push) and the last finished episode's return / length / success, reduced across the wavefront with lane shuffles
+// (push, pick) and the last finished episode's return / length / success, reduced across the wavefront with lane shuffles
 // and accumulated with one atomic per wave into out[8] =
 //   [sum distance, max distance (as f64 bits via atomicMax on the non-negative pattern), sum last_return, sum last_len,
 //    sum last_success, envs counted, 0, 0].
-template <class C, typename T>
-__global__ __launch_bounds__(256) void env_summary_kernel(EnvParams<T> P, int32_t task, double *out) {
+template <class Lane, typename T>
+__global__ __launch_bounds__(256) void env_summary_kernel(EnvParams<T> P, double *out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < P.n;
   const int64_t ic = live ? i : P.n - 1;
-  double dist;
-  if (task == ARMENV_TASK_PUSH) {
-    const T x = P.aux[0 * P.n + ic] - P.aux[3 * P.n + ic], y = P.aux[1 * P.n + ic] - P.aux[4 * P.n + ic],
-            z = P.aux[2 * P.n + ic] - P.aux[5 * P.n + ic];
-    dist = (double)Mth<T>::sqrt(Mth<T>::fma(x, x, Mth<T>::fma(y, y, z * z)));
-  } else {
-    T q[NJ], cq[NJ], sq[NJ];
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q[(int64_t)j * P.n + ic]; });
-    sincos_all<T>(q, cq, sq);
-    FKState<T> S;
-    fk<C, T>(P.chain, cq, sq, S);
-    const T x = S.p[0] - (T)P.goal[0 * P.n + ic], y = S.p[1] - (T)P.goal[1 * P.n + ic], z = S.p[2] - (T)P.goal[2 * P.n + ic];
-    dist = (double)Mth<T>::sqrt(Mth<T>::fma(x, x, Mth<T>::fma(y, y, z * z)));
-  }
+  const double dist = Lane::summary_distance(P, ic);
   double v[5] = {live ? dist : 0.0, live ? (double)P.last_return[ic] : 0.0, live ? (double)P.last_len[ic] : 0.0,
                  live ? (double)P.last_success[ic] : 0.0, live ? 1.0 : 0.0};
   double mx = live ? dist : 0.0;
@@ -675,12 +773,13 @@ __global__ __launch_bounds__(256) void env_summary_kernel(EnvParams<T> P, int32_
 
 template <typename T>
 __global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *q, float *goal, int32_t *step,
-                                                        uint32_t *episode, double *ep_return, double *aux) {
+                                                        uint32_t *episode, double *ep_return, double *aux, int aux_rows,
+                                                        int aux_dim) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   if (aux && P.aux) {
-    static_for<0, 7>([&](auto KI) { constexpr int k = KI; aux[8 * i + k] = (double)P.aux[(int64_t)k * P.n + i]; });
-    aux[8 * i + 7] = 0.0;
+    for (int k = 0; k < aux_rows; ++k) aux[(int64_t)aux_dim * i + k] = (double)P.aux[(int64_t)k * P.n + i];
+    for (int k = aux_rows; k < aux_dim; ++k) aux[(int64_t)aux_dim * i + k] = 0.0;
   }
   if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[7 * i + j] = (double)P.q[(int64_t)j * P.n + i]; });
   if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; goal[3 * i + k] = P.goal[(int64_t)k * P.n + i]; });
@@ -692,10 +791,12 @@ __global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *
 template <typename T>
 __global__ __launch_bounds__(256) void set_state_kernel(EnvParams<T> P, const double *q, const float *goal,
                                                         const int32_t *step, const uint32_t *episode,
-                                                        const double *ep_return, const double *aux) {
+                                                        const double *ep_return, const double *aux, int aux_rows,
+                                                        int aux_dim) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
-  if (aux && P.aux) static_for<0, 7>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * P.n + i] = (T)aux[8 * i + k]; });
+  if (aux && P.aux)
+    for (int k = 0; k < aux_rows; ++k) P.aux[(int64_t)k * P.n + i] = (T)aux[(int64_t)aux_dim * i + k];
   if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = (T)q[7 * i + j]; });
   if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = goal[3 * i + k]; });
   if (step) P.step[i] = step[i];

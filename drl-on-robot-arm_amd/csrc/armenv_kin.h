@@ -346,7 +346,7 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 // Per-section cycle accounting for the instrumented build (make timeline): s_memtime stamps around FK, orientation
 // error, DLS update and rotation advance, summed per wave into g_sections by lane 0.
 #ifdef ARMENV_TIMELINE
-__device__ unsigned long long g_sections[8];
+static __device__ unsigned long long g_sections[8];
 #define SEC_T0() unsigned long long sec_t = clock64()
 #define SEC_ADD(k)                                                                         \
   do {                                                                                     \
@@ -359,7 +359,9 @@ __device__ unsigned long long g_sections[8];
 #define SEC_ADD(k)
 #endif
 
-template <class C, typename T, bool FROM_ACTION>
+// START_F32: the start position is rounded through float before the action is added (rl_pick_env.py:328 casts
+// getLinkState's tuple to np.float32; reach / push keep the f64 tuple).
+template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
 AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
                    const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr) {
   using M = Mth<T>;
@@ -382,7 +384,7 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
         if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
         static_for<0, 3>([&](auto KI) {
           constexpr int k = KI;
-          T v = M::fma(a[k], dv, S.p[k]);
+          T v = M::fma(a[k], dv, START_F32 ? (T)(float)S.p[k] : S.p[k]);
           v = v < box_lo[k] ? box_lo[k] : v;   // clip_val, rl_reach_env.py:225-230
           v = v > box_hi[k] ? box_hi[k] : v;
           tgt[k] = v;

@@ -20,7 +20,7 @@
  *
  * Layouts (N = num_envs):
  *   action  f32 [N][3]      obs  f32 [N][obs_dim]  (reach: 6 = [eef xyz, goal xyz];
- *                                                    push: 9 = [eef, cube, target])
+ *                                                    push / pick: 9 = [eef, cube, target])
  *   reward  f32 [N]         done / success  u8 [N]
  *   state exchange (get/set_state): q f64 [N][7], goal f32 [N][3], step i32 [N],
  *                                   episode u32 [N], ep_return f64 [N]
@@ -46,7 +46,7 @@ enum {
   ARMENV_ESTATE = -5    /* call not valid in the handle's current state (e.g. actor not set) */
 };
 
-enum { ARMENV_TASK_REACH = 0, ARMENV_TASK_PUSH = 1 };
+enum { ARMENV_TASK_REACH = 0, ARMENV_TASK_PUSH = 1, ARMENV_TASK_PICK = 2 };
 enum { ARMENV_ROBOT_KUKA = 0, ARMENV_ROBOT_DIANA = 1 };
 enum { ARMENV_FK_AUTO = 0, ARMENV_FK_GENERIC = 1 };
 enum {
@@ -102,19 +102,26 @@ typedef struct ArmEnvConfig {
   int32_t ik_angle_f32;    /* 1: orientation-error angle rounded through f32 as Bullet does */
   int32_t reserved0;
 
-  /* push task, /root/reference/envs/rl_push_env.py */
-  double push_success_dis; /* 0.05  :422 */
+  /* push task, /root/reference/envs/rl_push_env.py (the pick task, envs/rl_pick_env.py, shares all six) */
+  double push_success_dis; /* 0.05  :422 (pick :425) */
   double push_cube_half;   /* 0.02  models/cube_small_push.urdf */
-  double push_eef_radius;  /* pusher radius of the simplified contact model */
+  double push_eef_radius;  /* pusher radius of the simplified contact model (pick: radius of the gripper tip) */
   double push_rest_z;      /* z at which the cube rests */
-  double push_place_min;   /* 0.22  :213 */
-  double push_place_max;   /* 0.25  :213 */
+  double push_place_min;   /* 0.22  :213 (pick :207) */
+  double push_place_max;   /* 0.25  :213 (pick :207) */
+
+  /* pick task, /root/reference/envs/rl_pick_env.py: gripper model (build-defined) */
+  double pick_gripper_length; /* 0.257 :79 -- the gripper tip sits this far along the tool axis from the link-7 frame */
+  double pick_trigger_dis;    /* 0.006 :412 -- p.getClosestPoints distance that closes the gripper */
+  double pick_jaw_half;       /* the closing gripper holds the cube when the cube centre is within this horizontal
+                                 distance of the tool axis (default: push_cube_half) */
+  double pick_reserved;
 
   ArmEnvChain chain;
 } ArmEnvConfig;
 
-/* Fills `cfg` with the constants of RLReachEnv.__init__ / RLPushEnv.__init__
- * (/root/reference/envs/rl_reach_env.py:44-125, envs/rl_push_env.py:49-143), Bullet's IK defaults and
+/* Fills `cfg` with the constants of RLReachEnv.__init__ / RLPushEnv.__init__ / RLPickEnv.__init__
+ * (/root/reference/envs/rl_reach_env.py:44-125, envs/rl_push_env.py:49-143, envs/rl_pick_env.py:51-133), Bullet's IK defaults and
  * the KUKA iiwa chain.  num_envs is set to 1, precision to 64, auto_reset to 1. */
 int armenv_default_config(int32_t task, ArmEnvConfig *cfg);
 
@@ -127,20 +134,22 @@ int armenv_builtin_chain(int32_t robot, ArmEnvChain *out);
 int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out);
 void armenv_destroy(ArmEnv *env);
 
-/* Replaces RLReachEnv.reset / RLPushEnv.reset (rl_reach_env.py:132-217, rl_push_env.py:145-256) for
+/* Replaces RLReachEnv.reset / RLPushEnv.reset / RLPickEnv.reset (rl_reach_env.py:132-217, rl_push_env.py:145-256,
+ * rl_pick_env.py:140-252) for
  * the envs whose mask byte is non-zero (mask_dev == NULL: all).  Goals come from the engine's
  * Philox stream.  obs_dev (nullable) receives the first observation of the reset envs only. */
 int armenv_reset(ArmEnv *env, const uint8_t *mask_dev, float *obs_dev, void *stream);
 
 /* Same, with caller-supplied goals f32 [N][3] (reach) -- the N=1 compatibility class uses this to
- * keep the reference's Python `random` stream (rl_reach_env.py:180-183). Push: goal_dev is
+ * keep the reference's Python `random` stream (rl_reach_env.py:180-183). Push / pick: goal_dev is
  * f32 [N][6] = [cube xyz, target xyz]. */
 int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *goal_dev, float *obs_dev,
                            void *stream);
 
 /* Replaces RLReachEnv.step + _reward (rl_reach_env.py:219-319) / RLPushEnv.step + _reward
- * (rl_push_env.py:310-440) for all N envs in one fused kernel:
- *   FK -> add dv*action -> clip to the workspace box -> DLS IK -> FK -> distance/reward/done -> obs.
+ * (rl_push_env.py:310-440) / RLPickEnv.step + _reward (rl_pick_env.py:310-440) for all N envs in one fused kernel:
+ *   FK -> add dv*action -> clip to the workspace box -> DLS IK -> FK -> (push / pick: cube contact, gripper) ->
+ *   distance/reward/done -> obs.
  * action_dev may be NULL when a fused policy was installed with armenv_set_policy.
  * terminal_obs_dev (nullable, f32 [N][obs_dim]) receives the observation of this step before any
  * auto-reset; with auto_reset the obs of a finished env is its next episode's first observation. */
@@ -172,8 +181,10 @@ int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_
 
 /* State exchange for teacher-forced parity tests and checkpointing (the reference keeps this state
  * inside the PyBullet client: joint angles via resetJointState rl_reach_env.py:252-257, target via
- * loadURDF :186-189, step_counter :264).  Any pointer may be NULL to skip that field. Push adds
- * aux f64 [N][8] = [cube xyz, target xyz, d_last, pad]. */
+ * loadURDF :186-189, step_counter :264).  Any pointer may be NULL to skip that field. Push and pick keep their
+ * cube state in aux f64 [N][armenv_aux_dim()]: push [N][8] = [cube xyz, target xyz, d_last, pad]; pick [N][12] =
+ * [cube xyz, target xyz, d_last, gripper (0 open, 1 closed, 2 closed and holding the cube), cube - tip offset xyz
+ * while held, pad]. */
 int armenv_get_state(ArmEnv *env, double *q_dev, float *goal_dev, int32_t *step_dev, uint32_t *episode_dev,
                      double *ep_return_dev, double *aux_dev, void *stream);
 int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, const int32_t *step_dev,
@@ -258,6 +269,7 @@ int armenv_her_sample(int32_t device, const ArmEnvHerArgs *args, void *stream);
 /* Shape / capability queries. */
 int64_t armenv_num_envs(const ArmEnv *env);
 int32_t armenv_obs_dim(const ArmEnv *env);
+int32_t armenv_aux_dim(const ArmEnv *env);   /* row length of get/set_state's aux: 0 reach, 8 push, 12 pick */
 int32_t armenv_action_dim(const ArmEnv *env);
 /* name of the step kernel variant in use, e.g. "reach_step<f64,kuka>" (for profiles) */
 const char *armenv_kernel_name(const ArmEnv *env);

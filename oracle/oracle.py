@@ -64,6 +64,7 @@ class OrcConfig(C.Structure):
         ("ik_form", C.c_int32),
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
+        ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
     ]
 
 
@@ -115,12 +116,12 @@ def default_config(task="reach"):
     """Constants of RLReachEnv.__init__ (/root/reference/envs/rl_reach_env.py:44-125),
     config.py:41-42,51, and Bullet's IK defaults."""
     c = OrcConfig()
-    c.task = 0 if task == "reach" else 1
+    c.task = {"reach": 0, "push": 1, "pick": 2}[task]
     c.dv = 0.02 if task == "reach" else 0.08
     c.reach_dis = 0.01
     c.max_steps = 500
     c.box_lo[:] = [0.2, -0.3, 0.0]
-    c.box_hi[:] = [0.7, 0.3, 0.55 if task == "reach" else 0.1]
+    c.box_hi[:] = [0.7, 0.3, {"reach": 0.55, "push": 0.1, "pick": 0.55 + 0.257}[task]]   # rl_push_env.py:314, rl_pick_env.py:313
     c.goal_lo[:] = [0.2, -0.3, 0.0]
     c.goal_hi[:] = [0.7, 0.3, 0.55]
     c.target_quat[:] = quat_from_euler([0.0, -math.pi, math.pi / 2.0])
@@ -138,6 +139,9 @@ def default_config(task="reach"):
     c.push_rest_z = 0.01
     c.push_place_min = 0.22
     c.push_place_max = 0.25
+    c.pick_gripper_length = 0.257      # rl_pick_env.py:79
+    c.pick_trigger_dis = 0.006         # rl_pick_env.py:412
+    c.pick_jaw_half = 0.02
     return c
 
 
@@ -382,3 +386,55 @@ def push_outcome(cfg, cube, target, d_last, step_counter):
     lib().orc_push_outcome(C.byref(cfg), (C.c_double * 3)(*cube), (C.c_double * 3)(*target), C.byref(dl), C.c_int32(step_counter),
                            C.byref(r), C.byref(d), C.byref(s))
     return r.value, bool(d.value), bool(s.value), dl.value
+
+
+# ------------------------------------------------------------------ pick env
+
+class PickState(ReachState):
+    """adds aux [N,12] = cube xyz, target xyz, d_last, gripper (0 open, 1 closed, 2 holding), hold offset xyz, pad"""
+
+    def __init__(self, n):
+        super().__init__(n)
+        self.aux = np.zeros((n, 12))
+
+
+def pick_reset(chain, cfg, st, seed=0, env_id0=0, mask=None):
+    obs = np.zeros((st.n, 9), dtype=np.float32)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_pick_reset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(st.n), _p(m),
+                         _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(obs))
+    if mask is None:
+        st.ep_return[:] = 0
+    else:
+        st.ep_return[np.asarray(mask, dtype=bool)] = 0
+    return obs
+
+
+def pick_reset_with_goal(chain, cfg, st, goal6):
+    obs = np.zeros((st.n, 9), dtype=np.float32)
+    g = np.ascontiguousarray(goal6, dtype=np.float32).reshape(st.n, 6)
+    lib().orc_pick_reset_with_goal(C.byref(chain), C.byref(cfg), C.c_int64(st.n), _p(g), _p(st.q), _p(st.aux), _p(st.step), _p(obs))
+    st.ep_return[:] = 0
+    return obs
+
+
+def pick_step(chain, cfg, st, action):
+    n = st.n
+    a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
+    obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
+    done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); iters = np.zeros(n, dtype=np.int32)
+    lib().orc_pick_step(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(st.q), _p(st.aux), _p(st.step), _p(a), _p(obs),
+                        _p(rew), _p(done), _p(succ), _p(iters))
+    st.ep_return += rew
+    return obs, rew, done, succ, iters
+
+
+def pick_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0):
+    n = st.n
+    a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
+    obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
+    done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); term = np.zeros((n, 9), dtype=np.float32)
+    lib().orc_pick_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
+                                  _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a), _p(obs),
+                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success))
+    return obs, rew, done, succ, term

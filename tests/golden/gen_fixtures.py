@@ -21,6 +21,10 @@ reference's importable Python (config, algo.TD3) -- never reference source text.
                                (algo/TD3/TD3_mlp.py:114-161), produced by importing the reference
   G7 push_reward_truth.json    (cube, target, d_last, step_counter) -> (reward, done, is_success) of
                                envs/rl_push_env.py:387-432 with its float32 / float64 mix
+  G9 py_random_{push,pick}_seed0.json  cube / target placements of successive resets (5 steps apart), produced by
+                               EXECUTING the reference's own rejection-sampling loop (envs/rl_push_env.py:195-214,
+                               envs/rl_pick_env.py:190-208; extracted from the module's AST because the module itself
+                               imports pybullet) under random.seed(0)
 """
 import ast
 import json
@@ -102,6 +106,43 @@ def g4_py_random():
     json.dump({"seed": 0, "steps_per_episode": 5, "episodes": episodes,
                "source": "CPython random.seed(0) stream in the draw pattern of envs/rl_reach_env.py"},
               open(os.path.join(OUT, "py_random_targets_seed0.json"), "w"), indent=1)
+
+
+def g9_py_random_placements():
+    import types
+    for task, fname in (("push", "envs/rl_push_env.py"), ("pick", "envs/rl_pick_env.py")):
+        tree = ast.parse(open(os.path.join(REF, fname)).read())
+        cls = next(n for n in tree.body if isinstance(n, ast.ClassDef))
+        fns = {f.name: f for f in cls.body if isinstance(f, ast.FunctionDef)}
+        # constants the loop reads: plain `self.<name> = <number>` assignments of __init__
+        consts = {}
+        for st in ast.walk(fns["__init__"]):
+            if (isinstance(st, ast.Assign) and len(st.targets) == 1 and isinstance(st.targets[0], ast.Attribute)
+                    and isinstance(st.targets[0].value, ast.Name) and st.targets[0].value.id == "self"):
+                try:
+                    consts[st.targets[0].attr] = ast.literal_eval(st.value)
+                except ValueError:
+                    pass
+        loop = next(n for n in fns["reset"].body if isinstance(n, ast.For) and isinstance(n.iter, ast.Call)
+                    and getattr(n.iter.func, "id", "") == "range" and ast.literal_eval(n.iter.args[0]) == 1000)
+        names = ("xpos", "ypos", "zpos", "xpos_target", "ypos_target", "zpos_target")
+        code = compile(ast.Module(body=[loop], type_ignores=[]), fname, "exec")
+        import math
+        pstub = types.SimpleNamespace(getQuaternionFromEuler=lambda e: (0.0, 0.0, math.sin(e[2] / 2), math.cos(e[2] / 2)))
+        random.seed(0)
+        placements = []
+        for ep in range(4):
+            env = {"random": random, "math": math, "p": pstub, "self": types.SimpleNamespace(**consts)}
+            exec(code, env)
+            placements.append({"cube": [env[k] for k in names[:3]], "target": [env[k] for k in names[3:]],
+                               "dis": env["self"].dis_between_target_block})
+            for _ in range(5):                                   # five steps, three unused draws each (push :435-437)
+                for lo, hi in ((consts["x_low_obs"], consts["x_high_obs"]), (consts["y_low_obs"], consts["y_high_obs"]),
+                               (consts["z_low_obs"], consts["z_high_obs"])):
+                    random.uniform(lo, hi)
+        json.dump({"seed": 0, "steps_between_resets": 5, "placements": placements,
+                   "source": f"the rejection-sampling loop of {fname} executed under random.seed(0)"},
+                  open(os.path.join(OUT, f"py_random_{task}_seed0.json"), "w"), indent=1)
 
 
 def g5_reward_truth():
@@ -276,5 +317,5 @@ def g8_td3_train():
 
 
 if __name__ == "__main__":
-    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train()
+    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements()
     print("fixtures written to", OUT)

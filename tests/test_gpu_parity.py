@@ -683,6 +683,203 @@ def test_rlpushenv_compat_surface(envs):
     env.close()
 
 
+# ------------------------------------------------------------------------------ pick task (section 8f row 4)
+
+def _pick_actions(obs, aux, dv=0.08, L=0.257, rng=None, scripted=None, sigma=0.4 * 0.98):
+    """scripted grasp-and-lift controller on the gripper tip (eef - (0,0,L)): go above the cube, descend until the
+    gripper closes, then carry the held cube to the target; envs outside `scripted` act randomly (main.py:484 noise)"""
+    n = len(obs)
+    tip = obs[:, 0:3].astype(np.float64).copy(); tip[:, 2] -= L
+    cube, tgt, grip, off = aux[:, 0:3], aux[:, 3:6], aux[:, 7], aux[:, 8:11]
+    horiz = np.linalg.norm(tip[:, :2] - cube[:, :2], axis=1)
+    want = np.where((horiz > 0.004)[:, None], cube + np.array([0, 0, 0.10]), cube + np.array([0, 0, 0.05]))
+    want = np.where((grip == 1)[:, None], tip, want)
+    want = np.where((grip == 2)[:, None], tgt - off, want)
+    a = (want - tip) / dv
+    a = a / np.maximum(np.abs(a).max(axis=1, keepdims=True), 1.0)
+    if rng is not None:
+        r = rng.normal(0.0, sigma, (n, 3))
+        a = np.where(scripted[:, None], a, r) if scripted is not None else r
+    return a.astype(np.float32)
+
+
+def test_pick_reset_matches_oracle(envs, O, kuka):
+    n = 2048 + 7
+    cfg = O.default_config("pick")
+    e = envs.BatchedPickEnv(n, device=DEV, seed=23, env_id_offset=5)
+    assert e.kernel_name == "pick_step<f64,kuka>"
+    obs = _np(e.reset())
+    st = O.PickState(n)
+    obs_ref = O.pick_reset(kuka, cfg, st, seed=23, env_id0=5)
+    assert obs.shape == (n, 9) and np.array_equal(obs[:, 3:], obs_ref[:, 3:]) and np.abs(obs - obs_ref).max() <= 6e-8
+    s = e.get_state()
+    aux = _np(s["aux"])
+    assert aux.shape == (n, 12) and np.array_equal(aux[:, :6], st.aux[:, :6]) and np.abs(aux[:, 6] - st.aux[:, 6]).max() < 1e-15
+    assert not aux[:, 7:].any()                                          # gripper open, nothing held
+    d = np.linalg.norm(aux[:, 0:3] - aux[:, 3:6], axis=1)                # rl_pick_env.py:205-208: 3-D distance
+    assert d.min() >= 0.22 and d.max() <= 0.25 and (aux[:, 2] == 0.01).all()
+    assert aux[:, 5].min() >= 0.0 and aux[:, 5].max() <= 0.26 and aux[:, 5].std() > 0.03   # target floats above the table
+    assert np.array_equal(_np(s["q"]), st.q)
+    e.close()
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_pick_step_teacher_forced(envs, O, kuka, precision):
+    """Every step starts from the oracle's state: arm (f32-rounded start, joints 0..5 only), gripper trigger / hold
+    decision, carried cube, reward.  Half of the envs follow the scripted grasp-and-lift, half act randomly."""
+    n = 1024 + 5
+    rng = np.random.default_rng(90)
+    cfg = O.default_config("pick")
+    e = envs.BatchedPickEnv(n, device=DEV, seed=4, auto_reset=False, precision=precision)
+    st = O.PickState(n)
+    obs_r = O.pick_reset(kuka, cfg, st, seed=4)
+    e.reset()
+    scripted = np.arange(n) < n // 2
+    tight = 1e-6 if precision == 64 else 1e-4
+    held_seen = closed_seen = succ_seen = 0
+    for t in range(40):
+        a = _pick_actions(obs_r, st.aux, rng=rng, scripted=scripted)
+        e.set_state(q=st.q, aux=st.aux, step=st.step, ep_return=st.ep_return)
+        q7 = st.q[:, 6].copy()
+        obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV))
+        obs, rew, done, succ = _np(obs).copy(), _np(rew).copy(), _np(done).copy(), _np(succ).copy()
+        obs_r, rew_r, done_r, succ_r, iters = O.pick_step(kuka, cfg, st, a)
+        s = e.get_state()
+        q, aux = _np(s["q"]), _np(s["aux"])
+        assert np.array_equal(q[:, 6], q7.astype(np.float32 if precision == 32 else np.float64))   # joint 7 never moves (:343)
+        dq = np.abs(q - st.q).max(1)
+        capped = iters >= 20
+        ok = (dq < tight) & ~capped
+        assert ok.mean() > (0.99 if precision == 64 else 0.95), (t, ok.mean())
+        assert (dq[~capped] < 1e-4).mean() > 0.995
+        # grip decisions are discontinuous in the tip position: compare where the arm agrees
+        same_grip = aux[ok, 7] == st.aux[ok, 7]
+        assert same_grip.mean() > 0.999, t
+        okg = ok.copy(); okg[ok] = same_grip
+        tol_c = 1e-6 if precision == 64 else 2e-4
+        assert (np.abs(aux[okg][:, :7] - st.aux[okg][:, :7]).max(1) < tol_c).mean() > 0.999, t
+        assert (np.abs(aux[okg][:, 8:11] - st.aux[okg][:, 8:11]).max(1) < tol_c).mean() > 0.999, t
+        rdiff = np.abs(rew.astype(np.float64) - rew_r)[okg]
+        assert (rdiff > (1e-4 if precision == 64 else 5e-2)).mean() < (1e-3 if precision == 64 else 2e-2), t
+        if precision == 64:
+            assert (done[okg] == done_r[okg].astype(bool)).mean() > 0.999
+            assert np.quantile(np.abs(obs - obs_r).max(1)[okg], 0.999) < 1e-6
+        held_seen = max(held_seen, int((st.aux[:, 7] == 2).sum()))
+        closed_seen = max(closed_seen, int((st.aux[:, 7] == 1).sum()))
+        succ_seen = max(succ_seen, int(succ_r.sum()))
+    assert held_seen > 0.9 * (n // 2) and succ_seen > 0.8 * (n // 2)     # the scripted envs grasp, lift and deliver
+    e.close()
+
+
+def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka):
+    """Free-running pick episodes with auto-reset (time-outs at 25 steps; scripted envs finish with +100) against
+    the oracle, and the rollout kernel against step launches bit for bit.  The random envs take small steps (sigma 0.1)
+    so that they stay in the well-conditioned middle of the workspace: with the full exploration noise some wander to
+    the top of the 0.807 m box within 15 steps, where the IK runs into its 20-iteration cap and the oracle's primal
+    solve and the dual LDL^T here drift apart (the oracle's own two solve forms do the same, see
+    test_pick_step_teacher_forced for how that case is bounded)."""
+    n, T = 256, 80
+    rng = np.random.default_rng(91)
+    cfg = O.default_config("pick"); cfg.max_steps = 24
+    mk = lambda: envs.BatchedPickEnv(n, device=DEV, seed=12, max_steps=24)
+    e, r_env, e2 = mk(), mk(), mk()
+    st = O.PickState(n)
+    obs_r = O.pick_reset(kuka, cfg, st, seed=12)
+    for x in (e, r_env, e2):
+        x.reset()
+    scripted = np.arange(n) < n // 2
+    acts = []
+    n_done = n_succ = 0
+    for t in range(T):
+        a = _pick_actions(obs_r, st.aux, rng=rng, scripted=scripted, sigma=0.1)
+        acts.append(a)
+        obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV), want_terminal_obs=True)
+        obs_r, rew_r, done_r, succ_r, term_r = O.pick_step_autoreset(kuka, cfg, st, a, seed=12)
+        assert np.array_equal(_np(done), done_r.astype(bool)), t
+        assert np.abs(_np(obs) - obs_r).max() < 1e-5 and np.abs(_np(e.terminal_obs) - term_r).max() < 1e-5, t
+        assert np.abs(_np(rew) - rew_r).max() < 1e-3, t
+        n_done += int(done_r.sum()); n_succ += int((rew_r == 100).sum())
+    assert n_done >= 3 * n and n_succ >= n // 2
+    s = e.get_state()
+    assert np.abs(_np(s["aux"])[:, :11] - st.aux[:, :11]).max() < 1e-6 and np.array_equal(_np(s["step"]), st.step)
+    c = e.counters()
+    assert c["episodes"] == n_done and c["nonfinite"] == 0
+    out = r_env.rollout(T, torch.from_numpy(np.stack(acts)).to(DEV))
+    for t in range(T):
+        o, r, d, su = e2.step(torch.from_numpy(acts[t]).to(DEV))
+        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["done"][t], d)
+    sa, sb = r_env.get_state(), e2.get_state()
+    assert torch.equal(sa["aux"], sb["aux"]) and torch.equal(sa["q"], sb["q"])
+    for x in (e, r_env, e2):
+        x.close()
+
+
+def test_pick_gripper_model_properties(envs):
+    """Size-independent properties of the gripper model at 32 768 envs: a held cube rides rigidly with the tip, a
+    closed gripper never reopens within an episode, the cube never sinks below its rest height, the eef honours the
+    pick workspace (z <= 0.55 + 0.257), and the fused random policy runs the task."""
+    n, T = 32768, 30
+    e = envs.BatchedPickEnv(n, device=DEV, seed=3, auto_reset=False)
+    obs = e.reset()
+    grip_prev = torch.zeros(n, dtype=torch.float64, device=DEV)
+    rel_prev = None
+    for t in range(T):
+        aux = e.get_state()["aux"]
+        a = torch.from_numpy(_pick_actions(_np(obs), _np(aux))).to(DEV)
+        obs, rew, done, succ = e.step(a)
+        aux = e.get_state()["aux"]
+        grip = aux[:, 7]
+        assert bool((grip >= grip_prev).all())                          # 0 -> 1 / 2, never back
+        assert float(aux[:, 2].min()) >= 0.01 - 1e-12
+        held = (grip == 2) & (grip_prev == 2)
+        if rel_prev is not None and bool(held.any()):
+            fk_p, fk_q = e.fk(e.get_state()["q"])
+            lifted = held & (aux[:, 2] > 0.0101)                        # above the table: exactly tip + offset
+            w, x, y, z = fk_q[:, 3], fk_q[:, 0], fk_q[:, 1], fk_q[:, 2]
+            axis = torch.stack([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], 1)
+            tip = fk_p + 0.257 * axis
+            assert float(((aux[:, 0:3] - tip) - aux[:, 8:11])[lifted].abs().max()) < 1e-9
+        grip_prev, rel_prev = grip.clone(), True
+    assert float((grip_prev == 2).double().mean()) > 0.95 and float(succ.double().mean()) > 0.9
+    e.close()
+    e = envs.BatchedPickEnv(n, device=DEV, seed=1)
+    e.reset()
+    e.set_policy("random", action_bound=0.4, noise_sigma=0.4 * 0.98, noise_clip=1e9)
+    out = e.rollout(40, None)
+    eef = out["obs"][..., :3]
+    # the box clips the IK *target* (:313, :330-333); near the top of the pick box the arm cannot reach it with the tool
+    # pointing down and Bullet's loop stops after 20 updates wherever it is, a few cm off at most
+    assert float(eef[..., 2].max()) <= 0.55 + 0.257 + 0.05 and float(eef[..., 2].min()) >= -0.05
+    assert float((eef[..., 2] <= 0.55 + 0.257 + 2e-4).float().mean()) > 0.999
+    c = e.counters()
+    assert c["env_steps"] == n * 40 and c["nonfinite"] == 0
+    e.close()
+
+
+def test_rlpickenv_compat_surface(envs):
+    """The reference's call pattern for the pick env (envs/rl_pick_env.py:44-448 surface) on the drop-in class."""
+    import random
+    env = envs.RLPickEnv(is_render=False, is_good_view=False)               # resets once, as the reference does (:133)
+    random.seed(0); np.random.seed(0)
+    assert abs(float(env.action_space.high[0]) - 0.4) < 1e-7 and env.observation_space.shape == (3,)
+    assert abs(float(env.observation_space.high[2]) - (0.55 + 0.257)) < 1e-6             # rl_pick_env.py:94-97
+    state = env.reset()
+    assert state.shape == (9,) and state.dtype == np.float64
+    d = np.linalg.norm(state[3:6] - state[6:9])
+    assert 0.22 <= d <= 0.25 and state[5] == 0.01 and 0.0 <= state[8] <= 0.55
+    g = golden_json("py_random_pick_seed0.json")                                         # the reference's draw pattern
+    assert list(state[3:6]) == g["placements"][0]["cube"] and list(state[6:9]) == g["placements"][0]["target"]
+    for _ in range(5):
+        action = np.zeros(3) + np.random.normal(0, 0.4 * 0.98, size=3)
+        state, reward, done, info = env.step(action)
+        assert state.shape == (9,) and isinstance(done, bool) and set(info) == {"is_success"}
+        assert info["is_success"].dtype == np.float32 and reward == -1.0 and not done
+    assert env.gripper_state == 0
+    state = env.reset()
+    assert list(state[3:6]) == g["placements"][1]["cube"] and list(state[6:9]) == g["placements"][1]["target"]
+    env.close()
+
+
 # ------------------------------------------------------------------------------ fused TD3 actor (A1, config 3)
 
 def _golden_actor():

@@ -37,13 +37,14 @@ def test_struct_layout_matches_header():
 int main(void){
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(ArmEnvConfig), sizeof(ArmEnvChain), offsetof(ArmEnvConfig, seed),
          offsetof(ArmEnvConfig, q_init), offsetof(ArmEnvConfig, push_success_dis), offsetof(ArmEnvConfig, chain));
+  printf("%zu\n", offsetof(ArmEnvConfig, pick_gripper_length));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     want = [C.sizeof(L.ArmEnvConfig), C.sizeof(L.ArmEnvChain), L.ArmEnvConfig.seed.offset, L.ArmEnvConfig.q_init.offset,
-            L.ArmEnvConfig.push_success_dis.offset, L.ArmEnvConfig.chain.offset]
+            L.ArmEnvConfig.push_success_dis.offset, L.ArmEnvConfig.chain.offset, L.ArmEnvConfig.pick_gripper_length.offset]
     assert [int(x) for x in out] == want
 
 
@@ -57,6 +58,10 @@ def test_default_config_holds_reference_constants():
     assert c.clamp_joint_limits == 0 and c.precision == 64
     p = L.default_config(L.TASK_PUSH)
     assert p.dv == 0.08 and list(p.box_hi) == [0.7, 0.3, 0.1]                     # rl_push_env.py:314,322
+    k = L.default_config(L.TASK_PICK)
+    assert k.dv == 0.08 and abs(k.box_hi[2] - (0.55 + 0.257)) < 1e-15              # rl_pick_env.py:313,322
+    assert (k.pick_gripper_length, k.pick_trigger_dis) == (0.257, 0.006)          # rl_pick_env.py:79,412
+    assert list(k.goal_hi) == [0.7, 0.3, 0.55] and list(k.q_init) == list(c.q_init)   # :61-66, :121-125 (first 7)
     with pytest.raises(L.ArmEnvError):
         L.default_config(7)
 
@@ -111,6 +116,24 @@ def test_python_random_goal_stream_matches_golden():
     for ep in g["episodes"]:
         assert draw_reset_goal() == ep["goal"]
         for _ in range(g["steps_per_episode"]):
+            draw_step_unused()
+
+
+@pytest.mark.parametrize("task", ["push", "pick"])
+def test_python_random_placement_stream_matches_reference(task):
+    """G9: cube / target placements of successive resets (five steps apart) equal what the reference's own
+    rejection-sampling loop produced under random.seed(0) (envs/rl_push_env.py:195-214, envs/rl_pick_env.py:190-208)."""
+    import random
+    from armenv.envs.rl_push_env import draw_push_placement
+    from armenv.envs.rl_pick_env import draw_pick_placement
+    from armenv.envs.rl_reach_env import draw_step_unused
+    g = golden_json(f"py_random_{task}_seed0.json")
+    draw = draw_push_placement if task == "push" else draw_pick_placement
+    random.seed(g["seed"])
+    for pl in g["placements"]:
+        cube, target = draw()
+        assert cube == pl["cube"] and target == pl["target"]
+        for _ in range(g["steps_between_resets"]):
             draw_step_unused()
 
 

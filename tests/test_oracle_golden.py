@@ -267,6 +267,72 @@ def test_push_arm_pipeline_and_contact(O, kuka):
     assert moved
 
 
+def test_pick_placement_and_reset(O, kuka):
+    cfg = O.default_config("pick")
+    st = O.PickState(4096)
+    obs = O.pick_reset(kuka, cfg, st, seed=5)
+    d = np.linalg.norm(st.aux[:, 0:3] - st.aux[:, 3:6], axis=1)
+    assert (d >= 0.22).all() and (d <= 0.25).all()                       # rl_pick_env.py:205-208 (3-D distance)
+    assert (st.aux[:, 2] == 0.01).all()                                  # :194 cube on the table
+    assert st.aux[:, 5].min() >= 0.0 and st.aux[:, 5].max() <= 0.26 and st.aux[:, 5].std() > 0.03   # :200 floating target
+    assert np.allclose(st.aux[:, 6], d) and not st.aux[:, 7:].any() and (st.episode == 1).all()
+    assert np.abs(obs[:, 3:9] - st.aux[:, :6].astype(np.float32)).max() == 0
+    g = golden_json("fk_kat.json")
+    assert np.abs(obs[:, :3] - np.float32(g["p_f32"])).max() <= 6e-8     # link-7 frame, not the gripper tip (:264)
+
+
+def test_pick_arm_pipeline_and_gripper(O, kuka):
+    """rl_pick_env.py:310-351: dv = 0.08, z <= 0.55 + 0.257, start position rounded through float32, joint 7 never
+    written; build-defined gripper: closes within 6 mm of the cube (:412), holds a cube centred under the tool, the
+    held cube rides with the tip, success when it reaches the floating target (:425)."""
+    cfg = O.default_config("pick")
+    L = cfg.pick_gripper_length
+    st = O.PickState(1)
+    O.pick_reset_with_goal(kuka, cfg, st, [[0.5, 0.0, 0.01, 0.5, 0.1, 0.2]])
+    q7 = st.q[0, 6]
+    p0 = O.fk(kuka, st.q)[0][0]
+    obs, r, d, s, it = O.pick_step(kuka, cfg, st, np.array([[0.0, 0.0, 1.0]]))
+    want_z = float(np.float32(p0[2])) + 0.08                             # f32-rounded start (:328) + dv * a
+    assert abs(O.fk(kuka, st.q)[0][0][2] - want_z) < 1e-4 and abs(want_z - (p0[2] + 0.08)) < 1e-7
+    assert st.q[0, 6] == q7 and r[0] == -1.0 and not d[0] and st.aux[0, 7] == 0
+    for _ in range(12):                                                   # straight up: clipped at 0.55 + L (:313)
+        obs, r, d, s, it = O.pick_step(kuka, cfg, st, np.array([[0.0, 0.0, 2.0]]))
+    assert obs[0, 2] <= 0.55 + L + 1e-4 and st.q[0, 6] == q7
+    # scripted grasp and lift
+    def act():
+        tip = obs[0, :3].astype(np.float64) - [0, 0, L]
+        cube, tgt, grip, off = st.aux[0, 0:3], st.aux[0, 3:6], st.aux[0, 7], st.aux[0, 8:11]
+        if grip == 2: want = tgt - off
+        elif np.linalg.norm(tip[:2] - cube[:2]) > 0.004: want = cube + [0, 0, 0.10]
+        else: want = cube + [0, 0, 0.05]
+        a = (want - tip) / 0.08
+        return (a / max(np.abs(a).max(), 1.0))[None]
+    closed_at = None
+    for t in range(40):
+        obs, r, d, s, it = O.pick_step(kuka, cfg, st, act())
+        tip = O.fk(kuka, st.q)[0][0] - [0, 0, L]
+        if st.aux[0, 7] == 2 and closed_at is None:
+            closed_at = t
+            gap = np.linalg.norm(np.maximum(np.abs(tip - st.aux[0, 0:3]) - 0.02, 0)) - 0.03
+            assert gap < 0.006 and np.allclose(st.aux[0, 0:3], [0.5, 0.0, 0.01])   # triggered by proximity, cube untouched
+        elif st.aux[0, 7] == 2:
+            assert np.abs(st.aux[0, 0:3] - (tip + st.aux[0, 8:11])).max() < 1e-6 or abs(st.aux[0, 2] - 0.01) < 1e-8
+        if d[0]:
+            break
+    assert closed_at is not None and d[0] and s[0] and r[0] == 100.0 and st.aux[0, 2] > 0.15 and st.q[0, 6] == q7
+    # a side approach closes the gripper without a hold; the closed gripper then only pushes
+    st = O.PickState(1)
+    O.pick_reset_with_goal(kuka, cfg, st, [[0.5, 0.0, 0.01, 0.5, 0.1, 0.2]])
+    obs = np.zeros((1, 9), np.float32); obs[0, :3] = O.fk(kuka, st.q)[0][0]
+    for t in range(40):
+        tip = obs[0, :3].astype(np.float64) - [0, 0, L]
+        way = np.array([0.5, -0.12, 0.02]) if (abs(tip[2] - 0.02) > 0.004 or tip[1] < -0.125) and st.aux[0, 7] == 0 and t < 15 \
+            else np.array([0.5, 0.1, 0.02])
+        a = (way - tip) / 0.08
+        obs, r, d, s, it = O.pick_step(kuka, cfg, st, (a / max(np.abs(a).max(), 2.0))[None])
+    assert st.aux[0, 7] == 1 and abs(st.aux[0, 2] - 0.01) < 1e-8 and st.aux[0, 1] > 0.02    # pushed along +y on the table, never lifted
+
+
 # ------------------------------------------------------------------------------ trajectory store + HER (next row 8f.1)
 
 @pytest.mark.parametrize("task", ["reach", "push"])
