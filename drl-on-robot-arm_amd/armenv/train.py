@@ -58,13 +58,15 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
 
 def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
                device="cuda:0", actor_kind="actor_f16x3", log_every=10, log=print, window_steps=1536, minimal_episodes=5,
-               max_steps=500):
+               max_steps=500, task="push"):
     """``train_push_with_TD3`` (/root/reference/main.py:449-515) on the device: state_dim 9, action_bound 0.4 (:455-457),
     unclipped exploration noise N(0, 0.4 * 0.98) (:484), push HER relabel rule (utils/rl_utils.py:171-188).  The cube
-    follows the build's simplified push-out model, so learning curves are not comparable with the reference's."""
+    follows the build's simplified push-out model, so learning curves are not comparable with the reference's.
+    ``task="pick"`` is ``train_pick_with_TD3`` (main.py:518-585), the same loop around RLPickEnv."""
     torch.manual_seed(seed)
     action_bound = 0.4
-    env = envs.BatchedPushEnv(num_envs, device=device, seed=seed, max_steps=max_steps)
+    Env = envs.BatchedPushEnv if task == "push" else envs.BatchedPickEnv
+    env = Env(num_envs, device=device, seed=seed, max_steps=max_steps)
     agent = TD3(9, 3, action_bound, device=device)
     store = TrajectoryStore(device=device, seed=seed, capacity_steps=window_steps)
     obs = env.reset()
@@ -97,7 +99,7 @@ def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batc
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="reach", choices=["reach", "push"])
+    ap.add_argument("--task", default="reach", choices=["reach", "push", "pick"])
     ap.add_argument("--num-envs", type=int, default=1024)
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--rollout-steps", type=int, default=32)
@@ -109,9 +111,9 @@ def main():
     ap.add_argument("--window-steps", type=int, default=1536)
     ap.add_argument("--max-steps", type=int, default=500, help="opt.max_steps_one_episode")
     a = ap.parse_args()
-    if a.task == "push":
+    if a.task != "reach":
         train_push(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
-                   window_steps=a.window_steps, max_steps=a.max_steps)
+                   window_steps=a.window_steps, max_steps=a.max_steps, task=a.task)
         return
     train_reach(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
                 expl_sigma=a.sigma, window_steps=a.window_steps, max_steps=a.max_steps)

@@ -1187,6 +1187,15 @@ def test_training_loop_smoke(envs):
     assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
 
 
+def test_training_loop_smoke_pick(envs):
+    """train_pick_with_TD3 (main.py:518-585) on the device: the 9-input fused actor drives PickLane rollouts."""
+    from armenv.train import train_push
+    agent, hist = train_push(num_envs=256, iterations=8, rollout_steps=16, updates=4, batch_size=256, window_steps=64,
+                             max_steps=20, log_every=4, log=lambda s: None, task="pick")
+    assert len(hist) == 2 and hist[-1]["env_steps"] == 256 * 16 * 8 and hist[-1]["episodes"] >= 256 * 5
+    assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
+
+
 def test_device_summary_matches_host_reduction(envs, O, kuka):
     n = 4096 + 17                                              # ragged last wave
     e = _mk(envs, n, seed=14, max_steps=9)
