@@ -137,149 +137,247 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float (&s)[IN], float
 // Fast variant: layer 2 on the f16 MFMA (v_mfma_f32_32x32x16_f16, 16x the f32 MFMA rate) with both operands split
 // x = hi + lo, hi = f16(x), lo = f16(x - hi), and three passes  hi*hi + hi*lo + lo*hi  accumulated in f32.  f16 products
 // are exact in f32, so only the lo*lo term (2^-22 relative) and f32 accumulation order separate the result from the
-// exact-f32 path above: within the 1e-5 actor tolerance of the reference's vectors (tests).  Measured: 45 us for 65 536
-// envs standalone (196 TF useful = 590 TF of f16 MFMA; a streamed-operand f16 MFMA probe reaches ~1000 TF, fixed
-// operands 1570 TF), 52 us per fused env step against 113 us for the exact-f32 actor.
-// Same transposed decomposition; per k-step of 16 a lane supplies 8 consecutive k of its env column, so layer 1 is
-// evaluated 8 rows at a time with W1 (12 KB) staged ONCE per workgroup in LDS (the only LDS use and the only barrier
-// of the kernel, before the step loop).
+// exact-f32 path above: within the 1e-5 actor tolerance of the reference's vectors (tests).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-#ifndef ACTOR_F16_NT
-#define ACTOR_F16_NT 4
-#endif
 
 struct ActorParamsH {
-  const half8 *W2H;    // [16 ks][8 tile][64 lane]: W2[32 tile + (lane&31)][16 ks + 8 (lane>>5) + j], j = 0..7 -- hi
+  const half8 *W2H;    // [16 ks][8 tile][64 lane]: W2[32 tile + (lane&31)][16 ks + 8 (j>>2) + 4 (lane>>5) + (j&3)], j = 0..7 -- hi
+                       // (the k order in which layer 1's MFMA accumulators hand a lane its eight values)
   const half8 *W2L;    //   same, lo
 };
 
-constexpr int ACTOR_W1_LDS_FLOATS = ACTOR_HID * 12;
+// LDS tables of the workgroup actor (actor_forward_wg_f16x3): layer 1's A operands for the f32 MFMA, then B2W3, then b2.
+//   W1A [8 row tiles][ACTOR_NK k-pairs][64 lanes] f32: lane l of k-pair m holds W1aug[32 R + (l & 31)][2 m + (l >> 5)],
+//   W1aug = [W1 | b1 | 0...] (the bias rides on a constant-1 input), ACTOR_NK = 5 covers IN = 6 and 9.
+constexpr int ACTOR_NK = 5;
+constexpr int ACTOR_W1A_FLOATS = 8 * ACTOR_NK * 64;
+constexpr int ACTOR_W1_LDS_FLOATS = ACTOR_W1A_FLOATS + ACTOR_HID * 4 + ACTOR_HID;
 
-// copy W1P (global, [256][12] f32) into LDS; every thread of the block must call this once, then __syncthreads()
-AE_DEV void actor_stage_w1(const float *W1P, float4 *lds) {
-  for (int i = threadIdx.x; i < ACTOR_W1_LDS_FLOATS / 4; i += blockDim.x) lds[i] = reinterpret_cast<const float4 *>(W1P)[i];
+// fills the tables from W1P (global, [256][12] f32: w0..w8, 0, 0, b1) and B2W3 ([256] float4); every thread of the
+// block must call this once, then __syncthreads()
+AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, int in_dim) {
+  float *w1a = reinterpret_cast<float *>(lds);
+  for (int i = threadIdx.x; i < ACTOR_W1A_FLOATS; i += blockDim.x) {
+    const int l = i & 63, m = (i >> 6) % ACTOR_NK, R = (i >> 6) / ACTOR_NK;
+    const int row = 32 * R + (l & 31), ka = 2 * m + (l >> 5);
+    w1a[i] = ka < in_dim ? W1P[row * 12 + ka] : (ka == in_dim ? W1P[row * 12 + 11] : 0.f);
+  }
+  for (int i = threadIdx.x; i < ACTOR_HID; i += blockDim.x) {
+    const float4 c = B2W3[i];
+    lds[ACTOR_W1A_FLOATS / 4 + i] = c;
+    reinterpret_cast<float *>(lds + ACTOR_W1A_FLOATS / 4 + ACTOR_HID)[i] = c.x;
+  }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The f16x3 actor is a WORKGROUP phase (four waves, 256 envs), same transposed decomposition as above:
+//   - one env column tile at a time with all eight neuron tiles (128 accumulators), so that nothing spills inside the
+//     k-loop (scratch traffic there would break the vmcnt accounting of the ring);
+//   - layer 1 on the f32 MFMA (W1aug . [obs, 1]); its accumulator layout is layer 2's B-operand layout up to a
+//     permutation of k inside each k-step, which the packing of W2H / W2L absorbs: only relu + the hi / lo split is VALU;
+//   - the A operands (W2 hi / lo fragments, 16 KB per k-step) reach the four waves through a ring in LDS that the waves
+//     fill cooperatively with direct-to-LDS loads (global_load_lds_dwordx4: 1 KB per wave instruction, scalar base + M0,
+//     no staging registers, no VALU).  Per-wave streaming of the same fragments from L2 left the matrix pipe waiting on
+//     memory: with one wave per SIMD nothing else hides a 1-2 us L2 round trip, and the registers to keep a dozen
+//     k-steps in flight do not exist.
+// Measured (65 536 envs): 37 us standalone, 49 us per fused env step; the MFMAs themselves take 17 us (20.7 ns each, the
+// rate of a constant-operand probe), LDS reads are hidden, fills + barriers cost 6 us, the rest is VALU that cannot
+// overlap the MFMAs of its own wave.
+// Ring protocol (R = 8 slots of 16 KB, prefetch distance P = R - 2 = 6 k-steps -- an L2 round trip is several k-steps
+// long --, slot = k-step mod R; 16 k-steps per pass, so the mapping carries over from one pass / call to the next and
+// the tail of a call prefetches the first k-steps of the following one):
+//   k-step ks:  issue fill(ks + P) -> s_waitcnt vmcnt(4 (P - 1)) (own part of fill(ks + 1) has landed; loads return
+//               in order) -> s_barrier (everyone's part has landed) -> ds_read the 16 fragments of k-step ks + 1 into
+//               the other register set -> the 24 MFMAs of k-step ks from the set read one k-step ago, with the relu /
+//               split of layer 1 for the next row tile in their shadow.
+//   fill(ks + P) overwrites the slot of k-step ks - 2; the slots being read while it is in flight are ks and ks + 1.
+// The loads are issued from inline asm so that hipcc's waitcnt insertion does not see them (it would drain the queue
+// with vmcnt(0) before every LDS read that might alias them); the waits above are therefore explicit.
+// Callers: actor_ring_init() once per kernel after computing `nw` (live waves of this workgroup), actor_ring_drain()
+// before the kernel ends (an LDS DMA must not outlive the workgroup's LDS allocation).
+#ifndef ACTOR_RING_SLOTS
+#define ACTOR_RING_SLOTS 8
+#endif
+constexpr int ACTOR_RING_AHEAD = ACTOR_RING_SLOTS - 2;         // prefetch distance in k-steps
+constexpr int ACTOR_RING_UINT4 = ACTOR_RING_SLOTS * 16 * 64;   // 16 KB per slot
+
+// one 1 KB direct-to-LDS copy: lane l moves 16 bytes from src_base + voff (voff = 16 l) to LDS byte lds_dst + 16 l.
+// src_base and lds_dst are wave-uniform (SGPRs): a fill costs scalar adds only, no VALU.
+AE_DEV void glds16(const void *src_base, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(src_base), "s"(lds_dst)
+               : "memory");
+}
+
+// fragments f = 2 tile + (0 hi | 1 lo) of k-step ks -> ring slot ks mod R; wave w takes f = w, w + nw, ...
+AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int ks, int nw) {
+  const unsigned voff = (threadIdx.x & 63u) * 16u;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned base = (unsigned)(uintptr_t)ring + (unsigned)((ks & (ACTOR_RING_SLOTS - 1)) * 16 * 64 * 16);
+  auto one = [&](int f) {
+    const uint64_t a = (uint64_t)(uintptr_t)(((f & 1) ? H.W2L : H.W2H) + (ks * 8 + (f >> 1)) * 64);
+    // wave-uniform by construction; readfirstlane tells the compiler so (the asm wants SGPR operands)
+    const uint64_t au = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
+                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
+    glds16(reinterpret_cast<const void *>(au), voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)(f * 1024))));
+  };
+  if (nw == 4) {
+    static_for<0, 4>([&](auto FI) { constexpr int fi = FI; one(wave + 4 * fi); });
+  } else {
+    for (int f = wave; f < 16; f += nw) one(f);
+  }
+}
+AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {
+  static_for<0, ACTOR_RING_AHEAD>([&](auto KI) { constexpr int k = KI; actor_ring_fill(H, ring, k, nw); });
+}
+AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int IN>
-AE_DEV void actor_forward_wave_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, const float (&s)[IN],
-                                     float (&out)[3]) {
+AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, uint4 *ring, int nw,
+                                   const float (&s)[IN], float (&out)[3]) {
+  static_assert(IN + 1 <= 2 * ACTOR_NK, "augmented input does not fit ACTOR_NK k-pairs");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5;
-  float sA[IN], sB[IN];
-  static_for<0, IN>([&](auto DI) {
-    constexpr int d = DI;
-    const float other = __shfl_xor(s[d], 32);
-    sA[d] = half ? other : s[d];
-    sB[d] = half ? s[d] : other;
-  });
-  float p[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  constexpr int NT = ACTOR_F16_NT;            // neuron tiles per pass: 8 = single pass (256 accumulators), 4 = two passes
-  constexpr int NPASS = 8 / NT;
+  constexpr int NT = 8;
+  const float *w1a = reinterpret_cast<const float *>(w1_lds) + lane;
+  const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;
+  const float4 *b2tab = b2w3 + ACTOR_HID;                  // b2 alone, four consecutive neurons per float4
+  float z[3] = {0.f, 0.f, 0.f};
+  // everything this wave has in flight (ring slots from the previous call's tail or actor_ring_init, and whatever the
+  // env step left behind) has landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // The two env column tiles of the wave (envs 0..31 and 32..63) are processed one after the other: 128 accumulator
+  // registers instead of 256 (the full set plus the operands does not fit without spills into the k-loop, and scratch
+  // traffic inside the loop would also break the vmcnt accounting of the ring).  W2 streams through the ring twice.
 #pragma unroll 1
-  for (int part = 0; part < NPASS; ++part) {
-    f32x16 acc[NT][2];
+  for (int t = 0; t < 2; ++t) {
+    // Layer 1 on the f32 MFMA: H1^T[32 R + row][env] = W1aug[32 R + row][:] . saug[:][env], saug = [obs, 1, 0..].  B operand
+    // of k-pair m: lane l holds saug[2 m + (l >> 5)] of env (l & 31) + 32 t.
+    float bv[ACTOR_NK];
+    {
+      float sv[2 * ACTOR_NK];
+      static_for<0, 2 * ACTOR_NK>([&](auto DI) {
+        constexpr int d = DI;
+        if constexpr (d < IN) {
+          const float other = __shfl_xor(s[d], 32);
+          sv[d] = (half == t) ? s[d] : other;
+        } else {
+          sv[d] = d == IN ? 1.f : 0.f;
+        }
+      });
+      static_for<0, ACTOR_NK>([&](auto MI) { constexpr int m = MI; bv[m] = half ? sv[2 * m + 1] : sv[2 * m]; });
+    }
+    auto layer1 = [&](int R) {   // raw layer-1 sums of row tile R: register i <-> neuron 32 R + 8 (i / 4) + 4 half + (i % 4)
+      f32x16 a1;
+      static_for<0, 16>([&](auto RI) { constexpr int r = RI; a1[r] = 0.f; });
+      const float *w = w1a + (R < 8 ? R : 7) * (ACTOR_NK * 64);
+      static_for<0, ACTOR_NK>([&](auto MI) {
+        constexpr int m = MI;
+        if constexpr (2 * m <= IN) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m * 64], bv[m], a1, 0, 0, 0);
+      });
+      return a1;
+    };
+    // relu + f16 hi / lo split of registers 8 u + 2 c, 8 u + 2 c + 1 of a1 -> halfs 2 c, 2 c + 1 of k-step u's B operand.
+    // K order inside a k-step: (half, j) <-> neuron 16 ks + 8 (j / 4) + 4 half + (j % 4); W2H / W2L are packed to match.
+    auto split2 = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2], half8 (&l)[2]) {
+      constexpr int u = UI, c = CI;
+      const float x0 = fmaxf(a1[8 * u + 2 * c], 0.f), x1 = fmaxf(a1[8 * u + 2 * c + 1], 0.f);
+      const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+      h[u][2 * c] = h0; h[u][2 * c + 1] = h1;
+      l[u][2 * c] = (_Float16)(x0 - (float)h0); l[u][2 * c + 1] = (_Float16)(x1 - (float)h1);
+    };
+    f32x16 acc[NT];   // start from the layer-2 bias: register r <-> neuron 32 nt + 8 (r / 4) + 4 half + (r % 4)
     static_for<0, NT>([&](auto NI) {
       constexpr int nt = NI;
-      static_for<0, 16>([&](auto RI) { constexpr int r = RI; acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f; });
+      static_for<0, 4>([&](auto QI) {
+        constexpr int q = QI;
+        const float4 b = b2tab[8 * nt + 2 * q + half];
+        acc[nt][4 * q] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
+      });
     });
-    half8 ah[NT], al[NT], nh[NT], nl[NT];
-    auto load_a = [&](int ks, half8 (&h)[NT], half8 (&l)[NT]) {
-      const int kc = ks < 16 ? ks : 15;
-      // table order is [ks][tile 0..7][lane]; pass `part` covers tiles NT*part .. NT*part + NT-1
-      const int base = (kc * 8 + NT * part) * 64 + lane;
-      static_for<0, NT>([&](auto NI) { constexpr int nt = NI; h[nt] = H.W2H[base + nt * 64]; l[nt] = H.W2L[base + nt * 64]; });
-    };
-    // B operands: h1 of the lane's two env columns for k = 16 ks + 8 half + j (j = 0..7), split into f16 hi / lo.
-    // Row j of the step is built in three pieces so that the pieces can be placed between MFMAs (below).
-    auto row_load = [&](int ks, int j, float4 &ra, float4 &rb, float4 &rc) {
-      const int kc = ks < 16 ? ks : 15;
-      const float4 *row = w1_lds + (16 * kc + 8 * half + j) * 3;
-      ra = row[0]; rb = row[1]; rc = row[2];
-    };
-    auto row_dot = [&](const float4 &ra, const float4 &rb, const float4 &rc, const float (&sv)[IN]) {
-      const float w[9] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc.x};
-      float h = rc.w;
-      static_for<0, IN>([&](auto DI) { constexpr int d = DI; h = fmaf(w[d], sv[d], h); });
-      return fmaxf(h, 0.f);
-    };
     half8 bh[2], bl[2], bh_n[2], bl_n[2];
-    load_a(0, ah, al);
-    static_for<0, 8>([&](auto JI) {
-      constexpr int j = JI;
-      float4 ra, rb, rc;
-      row_load(0, j, ra, rb, rc);
-      const float hA = row_dot(ra, rb, rc, sA), hB = row_dot(ra, rb, rc, sB);
-      const _Float16 ha = (_Float16)hA, hb = (_Float16)hB;
-      bh[0][j] = ha; bl[0][j] = (_Float16)(hA - (float)ha);
-      bh[1][j] = hb; bl[1][j] = (_Float16)(hB - (float)hb);
-    });
+    {
+      const f32x16 a1 = layer1(0);
+      static_for<0, 2>([&](auto UI) { static_for<0, 4>([&](auto CI) { split2(a1, UI, CI, bh, bl); }); });
+    }
+    // one k-step: refill the ring, make k-step ks + 1 visible (own part landed, then everyone's), start its LDS reads
+    // into (nh, nl) and run the 24 MFMAs of k-step ks from (ch, cl), which were read one k-step ago
+    auto kstep_head = [&](int ks, half8 (&nh)[NT], half8 (&nl)[NT]) {
+      actor_ring_fill(H, ring, (ks + ACTOR_RING_AHEAD) & 15, nw);
+      if (nw == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ACTOR_RING_AHEAD - 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const half8 *slot = reinterpret_cast<const half8 *>(ring) + ((ks + 1) & (ACTOR_RING_SLOTS - 1)) * 16 * 64 + lane;
+      static_for<0, NT>([&](auto NI) { constexpr int nt = NI; nh[nt] = slot[(2 * nt) * 64]; nl[nt] = slot[(2 * nt + 1) * 64]; });
+    };
+    half8 ah0[NT], al0[NT], ah1[NT], al1[NT];   // A fragments of even / odd k-steps
+    // k-step 0 of this pass.  First pass: every wave's share of it has landed after the vmcnt(0) above and this barrier;
+    // second pass: it was made visible by the last k-step of the first pass (its own read there is dropped so that no
+    // A fragments stay live across the pass epilogue).
+    if (t == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const half8 *slot = reinterpret_cast<const half8 *>(ring) + lane;
+      static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah0[nt] = slot[(2 * nt) * 64]; al0[nt] = slot[(2 * nt + 1) * 64]; });
+    }
 #pragma unroll 1
-    for (int ks = 0; ks < 16; ++ks) {
-      load_a(ks + 1, nh, nl);                               // A operands of the next k-step, in flight under the MFMAs
-      // Software pipeline, pinned by sched_barrier(0): the 6*NT MFMAs of k-step ks are issued one at a time with a
-      // slice of the layer-1 VALU / LDS work for k-step ks+1 behind each, so the VALU runs while the matrix pipe is
-      // busy (an in-order wave cannot overlap the two phases otherwise; left alone hipcc emits them back to back).
-      float4 ra, rb, rc, na, nb, nc;
-      row_load(ks + 1, 0, ra, rb, rc);
-      static_for<0, 8>([&](auto JI) {
-        constexpr int j = JI;
-        constexpr int m0 = 3 * j;                            // MFMA slots of this row: m0, m0+1, m0+2 (of 6*NT)
-        auto mfma = [&](auto MI) {
+    for (int R = 0; R < 8; ++R) {
+      f32x16 a1n;
+      {   // k-step 2 R: 24 MFMAs, then layer 1 of row tile R + 1 goes into the matrix pipe behind them
+        kstep_head(2 * R, ah1, al1);
+        static_for<0, 3 * NT>([&](auto MI) {
           constexpr int m = MI;
-          if constexpr (m < 6 * NT) {
-            // order: pass (hi*hi, hi*lo, lo*hi) outermost, so consecutive MFMAs never share an accumulator -- three
-            // back-to-back MFMAs on one accumulator each wait out the full dependent latency (measured 103 instead
-            // of 32 cycles per MFMA)
-            constexpr int k3 = m / (2 * NT), nt = (m % (2 * NT)) / 2, t = m % 2;
-            acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al[nt] : ah[nt], k3 == 1 ? bl[t] : bh[t], acc[nt][t], 0, 0, 0);
-          }
-        };
+          // order: pass (hi*hi, hi*lo, lo*hi) outermost, so consecutive MFMAs never share an accumulator
+          constexpr int k3 = m / NT, nt = m % NT;
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al0[nt] : ah0[nt], k3 == 1 ? bl[0] : bh[0], acc[nt], 0, 0, 0);
+        });
+        a1n = layer1(R + 1);
+      }
+      {   // k-step 2 R + 1: 24 MFMAs with the relu / split of row tile R + 1 in their shadow (one slice per third MFMA)
+        kstep_head(2 * R + 1, ah0, al0);
+        static_for<0, 8>([&](auto JI) {
+          constexpr int j = JI;
+          auto mfma = [&](auto MI) {
+            constexpr int m = MI;
+            constexpr int k3 = m / NT, nt = m % NT;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al1[nt] : ah1[nt], k3 == 1 ? bl[1] : bh[1], acc[nt], 0, 0, 0);
+          };
+          __builtin_amdgcn_sched_barrier(0);
+          mfma(std::integral_constant<int, 3 * j>{});
+          mfma(std::integral_constant<int, 3 * j + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+          split2(a1n, std::integral_constant<int, j / 4>{}, std::integral_constant<int, j % 4>{}, bh_n, bl_n);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma(std::integral_constant<int, 3 * j + 2>{});
+        });
         __builtin_amdgcn_sched_barrier(0);
-        mfma(std::integral_constant<int, m0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        const float hA = row_dot(ra, rb, rc, sA);
-        const _Float16 ha = (_Float16)hA;
-        bh_n[0][j] = ha; bl_n[0][j] = (_Float16)(hA - (float)ha);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(std::integral_constant<int, m0 + 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (j < 7) row_load(ks + 1, j + 1, na, nb, nc);
-        const float hB = row_dot(ra, rb, rc, sB);
-        const _Float16 hb = (_Float16)hB;
-        bh_n[1][j] = hb; bl_n[1][j] = (_Float16)(hB - (float)hb);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(std::integral_constant<int, m0 + 2>{});
-        ra = na; rb = nb; rc = nc;
-      });
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<24, 6 * NT>([&](auto MI) {                  // NT = 8: the remaining MFMAs (none for NT = 4)
-        constexpr int m = MI;
-        constexpr int k3 = m / (2 * NT), nt = (m % (2 * NT)) / 2, t = m % 2;
-        acc[nt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al[nt] : ah[nt], k3 == 1 ? bl[t] : bh[t], acc[nt][t], 0, 0, 0);
-      });
-      static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah[nt] = nh[nt]; al[nt] = nl[nt]; });
+      }
       bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
     }
+    // layer 2 bias + relu and layer 3 over the 128 neurons this lane holds for its env column (the other 128 are in
+    // lane ^ 32)
+    float p[3] = {0.f, 0.f, 0.f};
     static_for<0, NT>([&](auto NI) {
       constexpr int nt = NI;
+      __builtin_amdgcn_sched_barrier(0);                     // one tile's 16 table rows in flight at a time
       static_for<0, 16>([&](auto RI) {
         constexpr int r = RI;
-        const int n = 32 * (NT * part + nt) + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float4 c = A.B2W3[n];
-        const float h0 = fmaxf(acc[nt][0][r] + c.x, 0.f);
-        const float h1 = fmaxf(acc[nt][1][r] + c.x, 0.f);
-        p[0][0] = fmaf(c.y, h0, p[0][0]); p[0][1] = fmaf(c.z, h0, p[0][1]); p[0][2] = fmaf(c.w, h0, p[0][2]);
-        p[1][0] = fmaf(c.y, h1, p[1][0]); p[1][1] = fmaf(c.z, h1, p[1][1]); p[1][2] = fmaf(c.w, h1, p[1][2]);
+        const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float4 c = b2w3[n];
+        const float h2 = fmaxf(acc[nt][r], 0.f);               // the bias is already in the accumulator
+        p[0] = fmaf(c.y, h2, p[0]); p[1] = fmaf(c.z, h2, p[1]); p[2] = fmaf(c.w, h2, p[2]);
       });
     });
+    static_for<0, 3>([&](auto OI) {
+      constexpr int o = OI;
+      const float tot = p[o] + __shfl_xor(p[o], 32);         // lane e holds env e: tile e >> 5, column e & 31
+      z[o] = (half == t) ? tot : z[o];
+    });
   }
-  static_for<0, 3>([&](auto OI) {
-    constexpr int o = OI;
-    const float t0 = p[0][o] + __shfl_xor(p[0][o], 32);
-    const float t1 = p[1][o] + __shfl_xor(p[1][o], 32);
-    const float z = (half ? t1 : t0) + A.b3[o];
-    out[o] = tanhf(z) * A.bound;
-  });
+  static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
 }
 
 }  // namespace armenv

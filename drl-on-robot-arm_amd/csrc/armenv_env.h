@@ -116,16 +116,22 @@ struct PolicyParams {
 template <int IN, int MODE>
 __global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH H, int64_t n, const float *states, float *actions) {
   __shared__ float4 w1_lds[MODE == 1 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  __shared__ uint4 w2_ring[MODE == 1 ? ACTOR_RING_UINT4 : 1];
   if constexpr (MODE == 1) {
-    actor_stage_w1(A.W1P, w1_lds);
+    actor_stage_w1(A.W1P, w1_lds, A.B2W3, IN);
+    actor_ring_init(H, w2_ring, 4);
     __syncthreads();
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 256
   const int64_t ic = i < n ? i : n - 1;
   float s[IN], a[3];
   static_for<0, IN>([&](auto DI) { constexpr int d = DI; s[d] = states[ic * IN + d]; });
-  if constexpr (MODE == 1) actor_forward_wave_f16x3<IN>(A, H, w1_lds, s, a);
-  else actor_forward_wave<IN>(A, s, a);
+  if constexpr (MODE == 1) {
+    actor_forward_wg_f16x3<IN>(A, H, w1_lds, w2_ring, 4, s, a);
+    actor_ring_drain();
+  } else {
+    actor_forward_wave<IN>(A, s, a);
+  }
   if (i < n) { actions[3 * i] = a[0]; actions[3 * i + 1] = a[1]; actions[3 * i + 2] = a[2]; }
 }
 
@@ -135,7 +141,7 @@ static __global__ void actor_pack_kernel(const float *W1, const float *b1, const
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ACTOR_HID * ACTOR_HID) {   // f16 hi/lo split of W2 in the 32x32x16 A-operand order
     const int j = t & 7, lane = (t >> 3) & 63, nt = (t >> 9) & 3, part = (t >> 11) & 1, ks = t >> 12;
-    const float x = W2[(32 * (4 * part + nt) + (lane & 31)) * ACTOR_HID + 16 * ks + 8 * (lane >> 5) + j];
+    const float x = W2[(32 * (4 * part + nt) + (lane & 31)) * ACTOR_HID + 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)];
     const _Float16 hi = (_Float16)x;
     W2H[t] = hi;
     W2L[t] = (_Float16)(x - (float)hi);
@@ -636,8 +642,13 @@ template <class Lane, typename T, int POLICY>
 __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
                                                           const float *actions, StepIO io0, float *actions_out) {
   __shared__ float4 w1_lds[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
-  if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // the kernel's only LDS use and only barrier: W1, once
-    actor_stage_w1(pol.actor.W1P, w1_lds);
+  __shared__ uint4 w2_ring[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_RING_UINT4 : 1];
+  int nw = 4;   // live waves of this workgroup (the last one may be ragged; num_envs is a multiple of 64)
+  if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // W1 staged once; W2 streams through the ring every step
+    actor_stage_w1(pol.actor.W1P, w1_lds, pol.actor.B2W3, Lane::kObs);
+    const int64_t left = P.n - (int64_t)blockIdx.x * blockDim.x;
+    nw = (int)(((left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x) + 63) >> 6);
+    if ((int)(threadIdx.x >> 6) < nw) actor_ring_init(pol.actor_h, w2_ring, nw);
     __syncthreads();
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -673,7 +684,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
       } else if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {
         float s[kObs];
         L.policy_obs(s);
-        actor_forward_wave_f16x3<kObs>(pol.actor, pol.actor_h, w1_lds, s, mu);
+        actor_forward_wg_f16x3<kObs>(pol.actor, pol.actor_h, w1_lds, w2_ring, nw, s, mu);
       }
       float nz[3];
       // the episode index of the stream is the number of resets so far minus one (the running episode)
@@ -706,6 +717,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
     }
   }
   L.store(P, i);
+  if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) actor_ring_drain();
   if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)n * (unsigned long long)steps);
 }
 
