@@ -85,7 +85,9 @@ class TrajectoryStore:
         """number of complete episodes in the window (host sync)"""
         return 0 if self.chunk is None else int(self.chunk["num_episodes"].item())
 
-    def sample(self, batch_size, use_her=True, dis_threshold=0.1, her_ratio=0.8, picks=None, return_picks=False):
+    def sample(self, batch_size, use_her=True, dis_threshold=0.1, her_ratio=0.8, picks=None, return_picks=False, out=None):
+        """`out` (optional): dict of preallocated tensors under the same keys (e.g. the static buffers of
+        ``TD3.capture``); the batch is then written in place and no memory is allocated."""
         ch = self.chunk
         if ch is None:
             raise RuntimeError("TrajectoryStore.sample: no rollout stored")
@@ -104,11 +106,19 @@ class TrajectoryStore:
         a.seed, a.draw = self.seed, self._draw
         self._draw += 1
         a.her_ratio, a.dis_threshold = float(her_ratio), float(dis_threshold)
-        out = dict(states=torch.empty((B, D), dtype=torch.float32, device=dev),
-                   actions=torch.empty((B, 3), dtype=torch.float32, device=dev),
-                   next_states=torch.empty((B, D), dtype=torch.float32, device=dev),
-                   rewards=torch.empty(B, dtype=torch.float32, device=dev),
-                   dones=torch.empty(B, dtype=torch.uint8, device=dev))
+        if out is None:
+            out = dict(states=torch.empty((B, D), dtype=torch.float32, device=dev),
+                       actions=torch.empty((B, 3), dtype=torch.float32, device=dev),
+                       next_states=torch.empty((B, D), dtype=torch.float32, device=dev),
+                       rewards=torch.empty(B, dtype=torch.float32, device=dev),
+                       dones=torch.empty(B, dtype=torch.uint8, device=dev))
+        else:
+            want = dict(states=((B, D), torch.float32), actions=((B, 3), torch.float32), next_states=((B, D), torch.float32),
+                        rewards=((B,), torch.float32), dones=((B,), torch.uint8))
+            for k, (shape, dt) in want.items():
+                t = out[k]
+                if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != dev:
+                    raise ValueError(f"TrajectoryStore.sample: out[{k!r}] must be a contiguous {dt} tensor of shape {shape} on {dev}")
         a.states_dev, a.actions_dev, a.next_states_dev = out["states"].data_ptr(), out["actions"].data_ptr(), out["next_states"].data_ptr()
         a.rewards_dev, a.dones_dev = out["rewards"].data_ptr(), out["dones"].data_ptr()
         if return_picks:

@@ -53,11 +53,13 @@ class TD3:
         self.target_critic = TwinCritic(state_dim, hidden_dim, action_dim).to(self.device)
         self.target_critic.load_state_dict(self.critic.state_dict())
         self.target_actor.load_state_dict(self.actor.state_dict())
-        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=actor_lr)
-        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=critic_lr)
+        cap = self.device.type == "cuda"      # step counters on the device: the update can be captured in a hipGraph
+        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=actor_lr, capturable=cap)
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=critic_lr, capturable=cap)
         self.tau, self.gamma, self.action_bound = tau, gamma, action_bound
         self.policy_noise, self.noise_clip, self.policy_freq = policy_noise, noise_clip, policy_freq
         self.total_it = 0
+        self._graphs = None
 
     @torch.no_grad()
     def _soft_update(self, net, target):
@@ -73,6 +75,9 @@ class TD3:
         s2 = batch["next_states"].to(self.device, torch.float32)
         d = batch["dones"].to(self.device, torch.float32).view(-1, 1)
         self.total_it += 1
+        return self._update(s, a, r, s2, d, self.total_it % self.policy_freq == 0)
+
+    def _update(self, s, a, r, s2, d, with_actor):
         with torch.no_grad():
             noise = (torch.randn_like(a) * self.policy_noise).clamp(-self.noise_clip, self.noise_clip)
             a2 = (self.target_actor(s2) + noise).clamp(-self.action_bound, self.action_bound)
@@ -83,7 +88,7 @@ class TD3:
         self.critic_opt.zero_grad()
         critic_loss.backward()
         self.critic_opt.step()
-        if self.total_it % self.policy_freq == 0:
+        if with_actor:
             actor_loss = -self.critic.q1(s, self.actor(s)).mean()
             self.actor_opt.zero_grad()
             actor_loss.backward()
@@ -91,6 +96,76 @@ class TD3:
             self._soft_update(self.actor, self.target_actor)
             self._soft_update(self.critic, self.target_critic)
         return critic_loss.detach()
+
+    # ---- hipGraph path: one update is ~130 small kernels (1.7 ms of launch latency at any batch size up to 16 k);
+    # replayed from a captured graph it costs its kernel time only.
+    def capture(self, batch_size):
+        """Captures the two update variants (critic only / critic + delayed actor + soft updates) as hipGraphs over
+        static input buffers of `batch_size` rows; ``train_graphed`` then replays them.  Parameters and optimiser state
+        are left exactly as they were (the warm-up and capture passes run on a snapshot that is restored)."""
+        dev, B = self.device, int(batch_size)
+        D, A = self.actor.fc1.in_features, self.actor.fc3.out_features
+        buf = dict(states=torch.zeros(B, D, device=dev), actions=torch.zeros(B, A, device=dev),
+                   next_states=torch.zeros(B, D, device=dev), rewards=torch.zeros(B, device=dev),
+                   dones=torch.zeros(B, dtype=torch.uint8, device=dev))
+        loss = torch.zeros((), device=dev)
+        nets = (self.actor, self.critic, self.target_actor, self.target_critic)
+
+        def run(with_actor):
+            out = self._update(buf["states"], buf["actions"], buf["rewards"].view(-1, 1), buf["next_states"],
+                               buf["dones"].to(torch.float32).view(-1, 1), with_actor)
+            loss.copy_(out)
+
+        def snapshot():
+            return ([{k: v.clone() for k, v in n.state_dict().items()} for n in nets],
+                    copy.deepcopy(self.actor_opt.state_dict()), copy.deepcopy(self.critic_opt.state_dict()))
+
+        def restore(snap):
+            with torch.no_grad():
+                for n, sd in zip(nets, snap[0]):
+                    for k, v in n.state_dict().items():
+                        v.copy_(sd[k])
+                # in place (the graphs alias these tensors); state that did not exist before the warm-up goes back to a
+                # fresh Adam's: zero moments, step 0
+                for opt, saved in ((self.actor_opt, snap[1]["state"]), (self.critic_opt, snap[2]["state"])):
+                    for pid, p in enumerate(opt.param_groups[0]["params"]):
+                        for k, v in opt.state[p].items():
+                            if pid in saved:
+                                v.copy_(saved[pid][k])
+                            else:
+                                v.zero_()
+
+        first = snapshot()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up: allocates grads and optimiser state
+            for _ in range(2):
+                run(True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graphs = {}
+        for with_actor in (False, True):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run(with_actor)
+            graphs[with_actor] = g
+        # optimiser state may not have existed before the warm-up: "restore" then means zero moments and step 0
+        restore(first)
+        torch.cuda.synchronize(dev)
+        self._graphs = dict(buf=buf, loss=loss, g=graphs, B=B)
+        return buf
+
+    def train_graphed(self, batch):
+        """``train`` through the captured graphs: `batch` is copied into the static buffers (or IS the dict returned by
+        ``capture`` / filled in place by ``TrajectoryStore.sample(out=...)``).  Returns the loss tensor of the replay."""
+        g = self._graphs
+        if g is None:
+            raise RuntimeError("TD3.train_graphed: call capture(batch_size) first")
+        if batch is not g["buf"]:
+            for k, v in g["buf"].items():
+                v.copy_(batch[k].view_as(v))
+        self.total_it += 1
+        g["g"][self.total_it % self.policy_freq == 0].replay()
+        return g["loss"]
 
     def actor_state_dict(self):
         return {k: v.detach() for k, v in self.actor.state_dict().items()}

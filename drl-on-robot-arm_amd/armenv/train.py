@@ -18,11 +18,12 @@ from .td3 import TD3
 
 def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
                 device="cuda:0", actor_kind="actor_f16x3", expl_sigma=0.7 * 0.98, log_every=10, log=print,
-                window_steps=1536, minimal_episodes=5, max_steps=500):
+                window_steps=1536, minimal_episodes=5, max_steps=500, use_graphs=True):
     torch.manual_seed(seed)
     action_bound = 0.7                                            # main.py:87
     env = envs.BatchedReachEnv(num_envs, device=device, seed=seed, max_steps=max_steps)
     agent = TD3(6, 3, action_bound, device=device)
+    static = agent.capture(batch_size) if use_graphs else None     # TD3 update as hipGraphs: launch-bound otherwise
     store = TrajectoryStore(device=device, seed=seed, capacity_steps=window_steps)   # last `window_steps` steps of every env
     ready = False
     obs = env.reset()
@@ -42,7 +43,10 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
             ready = store.size() >= minimal_episodes
         if ready:
             for _ in range(updates):                              # main.py:136-138
-                agent.train(store.sample(batch_size, use_her=True, her_ratio=her_ratio))
+                if use_graphs:     # HER batch written straight into the captured update's static buffers
+                    agent.train_graphed(store.sample(batch_size, use_her=True, her_ratio=her_ratio, out=static))
+                else:
+                    agent.train(store.sample(batch_size, use_her=True, her_ratio=her_ratio))
         if (it + 1) % log_every == 0:
             c = env.counters()
             ep = c["episodes"] - c_prev["episodes"]
@@ -58,7 +62,7 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
 
 def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
                device="cuda:0", actor_kind="actor_f16x3", log_every=10, log=print, window_steps=1536, minimal_episodes=5,
-               max_steps=500, task="push"):
+               max_steps=500, task="push", use_graphs=True):
     """``train_push_with_TD3`` (/root/reference/main.py:449-515) on the device: state_dim 9, action_bound 0.4 (:455-457),
     unclipped exploration noise N(0, 0.4 * 0.98) (:484), push HER relabel rule (utils/rl_utils.py:171-188).  The cube
     follows the build's simplified push-out model, so learning curves are not comparable with the reference's.
@@ -68,6 +72,7 @@ def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batc
     Env = envs.BatchedPushEnv if task == "push" else envs.BatchedPickEnv
     env = Env(num_envs, device=device, seed=seed, max_steps=max_steps)
     agent = TD3(9, 3, action_bound, device=device)
+    static = agent.capture(batch_size) if use_graphs else None
     store = TrajectoryStore(device=device, seed=seed, capacity_steps=window_steps)
     obs = env.reset()
     history, ready, bufs = [], False, {}
@@ -84,7 +89,10 @@ def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batc
             ready = store.size() >= minimal_episodes
         if ready:
             for _ in range(updates):
-                agent.train(store.sample(batch_size, use_her=True, her_ratio=her_ratio))
+                if use_graphs:     # HER batch written straight into the captured update's static buffers
+                    agent.train_graphed(store.sample(batch_size, use_her=True, her_ratio=her_ratio, out=static))
+                else:
+                    agent.train(store.sample(batch_size, use_her=True, her_ratio=her_ratio))
         if (it + 1) % log_every == 0:
             c = env.counters()
             ep = c["episodes"] - c_prev["episodes"]

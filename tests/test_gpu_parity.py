@@ -1187,6 +1187,43 @@ def test_training_loop_smoke(envs):
     assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
 
 
+def test_td3_update_as_hipgraph_equals_eager(envs):
+    """TD3.capture / train_graphed (the update replayed from hipGraphs over static buffers) follows the eager update:
+    identical batches, target-policy noise off (its random stream differs inside a graph), 30 updates incl. ten delayed
+    actor + soft updates.  Compared functionally (losses, Q values and actions on a held-out batch): Adam's
+    normalisation turns last-bit differences of near-zero gradients into lr-sized parameter differences, so individual
+    parameters are not comparable bit for bit between two executions.  capture() leaves parameters untouched."""
+    from armenv.td3 import TD3
+    torch.manual_seed(3)
+    a = TD3(6, 3, 0.7, device=DEV, policy_noise=0.0)
+    b = TD3(6, 3, 0.7, device=DEV, policy_noise=0.0)
+    for nb, na in zip((b.actor, b.critic, b.target_actor, b.target_critic), (a.actor, a.critic, a.target_actor, a.target_critic)):
+        nb.load_state_dict(na.state_dict())
+    B = 512
+    before = [p.detach().clone() for p in list(b.critic.parameters()) + list(b.actor.parameters())]
+    static = b.capture(B)
+    assert all(torch.equal(p, q) for p, q in zip(list(b.critic.parameters()) + list(b.actor.parameters()), before))
+    assert all(float(v.abs().max()) == 0.0 for st in b.critic_opt.state.values() for v in st.values())   # fresh Adam state
+    gen = torch.Generator(device=DEV); gen.manual_seed(11)
+    mk = lambda: dict(states=torch.rand(B, 6, device=DEV, generator=gen), actions=torch.rand(B, 3, device=DEV, generator=gen) - 0.5,
+                      next_states=torch.rand(B, 6, device=DEV, generator=gen), rewards=torch.rand(B, device=DEV, generator=gen),
+                      dones=(torch.rand(B, device=DEV, generator=gen) < 0.1).to(torch.uint8))
+    for it in range(30):
+        batch = mk()
+        la, lb = float(a.train(batch)), float(b.train_graphed(batch))
+        assert abs(la - lb) < 2e-3 * max(1.0, abs(la)), (it, la, lb)
+    assert a.total_it == b.total_it == 30
+    held = mk()
+    with torch.no_grad():
+        qa, qb = a.critic(held["states"], held["actions"]), b.critic(held["states"], held["actions"])
+        assert float((qa[0] - qb[0]).abs().max()) < 5e-3 and float((qa[1] - qb[1]).abs().max()) < 5e-3
+        assert float((a.actor(held["states"]) - b.actor(held["states"])).abs().max()) < 5e-3
+        assert float((a.target_actor(held["states"]) - b.target_actor(held["states"])).abs().max()) < 5e-3
+        moved = float((b.actor(held["states"]) - TD3(6, 3, 0.7, device=DEV).actor(held["states"])).abs().max())
+    assert moved > 1e-2                                    # the graphed learner really updated its actor
+    assert static is b._graphs["buf"]
+
+
 def test_training_loop_smoke_pick(envs):
     """train_pick_with_TD3 (main.py:518-585) on the device: the 9-input fused actor drives PickLane rollouts."""
     from armenv.train import train_push
