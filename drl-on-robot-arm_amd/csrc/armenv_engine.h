@@ -104,7 +104,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   using Lane = LaneT<C, T>;
   EnvParams<T> P{};
   void *pool = nullptr;
-  int block = 256;
+  static constexpr int block = 256;   // four waves: one per SIMD of a CU; the f16x3 actor phase is a 4-wave workgroup
   static constexpr int task = Lane::kTask;
   std::string kname;
 
@@ -186,10 +186,6 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     T host_p[3];
     HIP_TRY(hipMemcpy(host_p, tmp, sizeof host_p, hipMemcpyDeviceToHost));
     for (int k = 0; k < 3; ++k) P.p_init[k] = host_p[k];
-    if (const char *bs = getenv("ARMENV_BLOCK")) {
-      const int v = atoi(bs);
-      if (v == 64 || v == 128 || v == 256) block = v;
-    }
     kname = std::string(Lane::kName) + "_step<" + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
     return ARMENV_OK;
   }

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 outputs of profiles/collect.sh (gpurun_out/prof/) into the summaries kept in profiles/:
+  r01_kernel_stats_<config>.csv   --stats tables, armenv kernels only
+  r01_bench_<config>.json         the bench.py line of the same run
+  r01_pmc_default_bench_f64.json  per-launch means of every counter for the rollout / step kernels of the default bench
+  r01_pmc_actor_f16x3.json        same for the fused f16x3 actor rollout kernel
+  traffic.json                    HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; gfx950 reports
+                                  half of the fetched bytes, MI355X_MICROARCH.md HBM section) -- read by bench.py
+Only launches with the full step count are averaged (the warm-up launch of a different length is dropped by taking the
+most frequent duration class: launches whose duration is within 30 % of the median)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import statistics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    if "env_rollout_kernel" in name:
+        return "rollout"
+    if "env_step_kernel" in name:
+        return "step"
+    return None
+
+
+def pmc(files, want):
+    """{kernel: {counter: {launches, mean_per_launch}}} for kernels `want` maps to a label"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for f in files:
+        rows = list(csv.DictReader(open(f)))
+        dur = collections.defaultdict(list)
+        for r in rows:
+            k = want(r["Kernel_Name"])
+            if k:
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        med = {k: statistics.median(v) for k, v in dur.items()}
+        for r in rows:
+            k = want(r["Kernel_Name"])
+            if not k:
+                continue
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if abs(d - med[k]) > 0.3 * med[k]:
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = {"_kernel": r["Kernel_Name"][:140],
+                       "_meta": {"VGPR": r["VGPR_Count"], "AGPR": r["Accum_VGPR_Count"], "SGPR": r["SGPR_Count"],
+                                 "workgroup": r["Workgroup_Size"], "grid": r["Grid_Size"], "lds": r["LDS_Block_Size"],
+                                 "scratch": r["Scratch_Size"]}}
+    out = {}
+    for k, cs in acc.items():
+        out[k] = dict(meta[k])
+        for c, v in sorted(cs.items()):
+            out[k][c] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+    return out
+
+
+def main():
+    for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):
+        cfg = os.path.basename(f)[: -len("_kernel_stats.csv")]
+        rows = [l for i, l in enumerate(open(f)) if i == 0 or any(s in l for s in ("env_", "actor_", "her_", "index_episodes"))]
+        open(os.path.join(DST, f"r01_kernel_stats_{cfg}.csv"), "w").writelines(rows)
+        b = os.path.join(SRC, f"{cfg}_bench.json")
+        if os.path.exists(b) and open(b).read().strip().startswith("{"):
+            shutil.copy(b, os.path.join(DST, f"r01_bench_{cfg}.json"))
+    default = pmc(sorted(glob.glob(os.path.join(SRC, "pmc[0-9]_counters.csv"))), short)
+    json.dump(default, open(os.path.join(DST, "r01_pmc_default_bench_f64.json"), "w"), indent=1)
+    actor = pmc(sorted(glob.glob(os.path.join(SRC, "pmc_actor*_counters.csv"))), short)
+    json.dump(actor, open(os.path.join(DST, "r01_pmc_actor_f16x3.json"), "w"), indent=1)
+    traffic = {}
+    names = {"rollout": "reach_rollout<f64,kuka>", "step": "reach_step<f64,kuka>"}
+    steps = {"rollout": 50, "step": 1}
+    for k, name in names.items():
+        if k in default and "FETCH_SIZE" in default[k] and "WRITE_SIZE" in default[k]:
+            fe, wr = default[k]["FETCH_SIZE"]["mean_per_launch"], default[k]["WRITE_SIZE"]["mean_per_launch"]
+            traffic[name] = {"hbm_bytes_per_launch": (2 * fe + wr) * 1024, "fetch_size_kb_raw": fe, "write_size_kb_raw": wr,
+                             "steps_per_launch": steps[k]}
+    traffic["_note"] = ("FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over `bench.py --steps 500 --warmup 50` "
+                        "(KiB per launch, mean over launches, N=65536; profiles/collect.sh + aggregate.py). "
+                        "hbm_bytes_per_launch = 2*FETCH + WRITE: FETCH doubled per the gfx950 note in MI355X_MICROARCH.md "
+                        "(HBM section).")
+    json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+    for k in ("rollout", "step"):
+        if k in default:
+            d = default[k]
+            g = lambda c: d.get(c, {}).get("mean_per_launch")
+            print(k, {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")})
+    if "rollout" in actor:
+        print("actor rollout", {c: v["mean_per_launch"] for c, v in actor["rollout"].items() if not c.startswith("_")}, actor["rollout"]["_meta"])
+
+
+if __name__ == "__main__":
+    main()

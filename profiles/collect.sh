@@ -1,0 +1,48 @@
+#!/bin/bash
+# Collects the round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only)
+# Writes under gpurun_out/prof/; profiles/aggregate.py turns the PMC passes into the JSON summaries kept in profiles/.
+# PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
+set -u
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof
+MODE=${1:-all}
+[ "$MODE" = "all" ] && rm -rf "$OUT"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+stats() {   # name, bench args...
+  local name=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
+  find "$OUT/$name" -name '*kernel_stats.csv' -exec cp {} "$OUT/${name}_kernel_stats.csv" \;
+  grep -h "^{\"metric\"" "$OUT/$name.log" | tail -1 > "$OUT/${name}_bench.json"
+}
+if [ "$MODE" = "all" ]; then
+stats default                                   # the headline command (with cpu_baseline)
+stats actor_f16x3 --policy actor_f16x3 --steps 400 --no-cpu-baseline
+stats actor_f32 --policy actor --steps 200 --no-cpu-baseline
+stats push32768 --task push --envs-per-gpu 32768 --steps 400 --no-cpu-baseline
+stats pick32768 --task pick --envs-per-gpu 32768 --steps 400 --no-cpu-baseline
+stats f32engine --precision 32 --steps 400 --no-cpu-baseline
+fi
+# one small counter set per pass: a set the hardware cannot collect in one pass makes rocprofv3 abort and then hang in its
+# signal handler (FETCH_SIZE + WRITE_SIZE + GRBM_GUI_ACTIVE did), hence the timeouts
+pmc() {   # name, counters..., then -- bench args
+  local name=$1; shift
+  local ctrs=()
+  while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+  shift
+  timeout 240 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
+  find "$OUT/$name" -name '*counter_collection.csv' -exec cp {} "$OUT/${name}_counters.csv" \;
+}
+if [ "${1:-all}" = "all" ]; then
+pmc pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES -- --steps 500 --warmup 50 --no-cpu-baseline
+pmc pmc2 SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- --steps 500 --warmup 50 --no-cpu-baseline
+fi
+pmc pmc3 FETCH_SIZE -- --steps 500 --warmup 50 --no-cpu-baseline
+pmc pmc4 WRITE_SIZE -- --steps 500 --warmup 50 --no-cpu-baseline
+pmc pmc5 GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- --steps 500 --warmup 50 --no-cpu-baseline
+pmc pmc_actor SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- --policy actor_f16x3 --steps 200 --no-cpu-baseline
+pmc pmc_actor2 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- --policy actor_f16x3 --steps 200 --no-cpu-baseline
+# keep only the summaries (the raw trees are large)
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+ls -la "$OUT"
