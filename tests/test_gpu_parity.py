@@ -1187,6 +1187,27 @@ def test_training_loop_smoke(envs):
     assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
 
 
+def test_plain_c_consumer(envs, tmp_path):
+    """tests/c_abi/consumer.c -- plain C against include/armenv.h, its own process, no torch -- produces what the Python
+    host side produces for the same seed and actions."""
+    import subprocess
+    from test_host_logic import build_c_consumer
+    exe = build_c_consumer(str(tmp_path))
+    n, steps = 4096, 10
+    r = subprocess.run([exe, str(n), str(steps)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    f = r.stdout.split()
+    e = envs.BatchedReachEnv(n, device=DEV, seed=7)
+    e.reset()
+    a = torch.tensor([[0.5, -0.25, -0.6]], device=DEV).repeat(n, 1).contiguous()
+    for _ in range(steps):
+        obs, rew, done, succ = e.step(a)
+    assert np.array_equal(np.float32([float(x) for x in f[:6]]), _np(obs)[0])
+    assert abs(float(f[6]) - float(rew.double().sum())) < 1e-3
+    assert int(f[7]) == n * steps and int(f[8]) == 0 and f[9] == e.kernel_name
+    e.close()
+
+
 def test_td3_update_as_hipgraph_equals_eager(envs):
     """TD3.capture / train_graphed (the update replayed from hipGraphs over static buffers) follows the eager update:
     identical batches, target-policy noise off (its random stream differs inside a graph), 30 updates incl. ten delayed

@@ -137,6 +137,30 @@ def test_python_random_placement_stream_matches_reference(task):
             draw_step_unused()
 
 
+def build_c_consumer(out_dir):
+    """gcc-compiles tests/c_abi/consumer.c (plain C11) against include/armenv.h and links it with libarmenv.so."""
+    from armenv import _lib as L
+    exe = os.path.join(out_dir, "consumer")
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "consumer.c"), "-o", exe,
+                           "-L", libdir, "-larmenv", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_plain_c_consumer_links_and_fails_loudly_without_gpu(tmp_path):
+    """The boundary is usable from plain C (no torch, no C++): the consumer compiles with -Werror, links against
+    libarmenv.so, and without a HIP device armenv_create refuses with ARMENV_ENODEV and a message instead of computing
+    anything on the CPU."""
+    import torch
+    exe = build_c_consumer(str(tmp_path))
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the run is covered by tests/test_gpu_parity.py::test_plain_c_consumer")
+    r = subprocess.run([exe, "64", "2"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
