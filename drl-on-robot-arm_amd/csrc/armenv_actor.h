@@ -22,6 +22,30 @@ namespace armenv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Optional cycle attribution of the workgroup actor (make actor_timeline; csrc/exp/run_actor_timeline.py): s_memtime deltas per
+// section, summed over waves by lane 0.  Off in the product build.
+#ifdef ARMENV_ACTOR_TIMELINE
+static __device__ unsigned long long g_actor_sections[16];
+#define ASEC_T0()                                  \
+  unsigned long long asec_acc[9] = {0};            \
+  unsigned long long asec_t = clock64()
+#define ASEC_ADD(k)                                \
+  do {                                             \
+    const unsigned long long now_ = clock64();     \
+    asec_acc[k] += now_ - asec_t;                  \
+    asec_t = now_;                                 \
+  } while (0)
+#define ASEC_FLUSH()                                                                              \
+  do {                                                                                            \
+    if ((threadIdx.x & 63) == 0)                                                                  \
+      for (int k_ = 0; k_ < 9; ++k_) atomicAdd(&g_actor_sections[k_], asec_acc[k_]);              \
+  } while (0)
+#else
+#define ASEC_T0()
+#define ASEC_ADD(k)
+#define ASEC_FLUSH()
+#endif
+
 constexpr int ACTOR_HID = 256;
 
 struct ActorParams {
@@ -186,10 +210,10 @@ AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, in
 // Ring protocol (R = 8 slots of 16 KB, prefetch distance P = R - 2 = 6 k-steps -- an L2 round trip is several k-steps
 // long --, slot = k-step mod R; 16 k-steps per pass, so the mapping carries over from one pass / call to the next and
 // the tail of a call prefetches the first k-steps of the following one):
-//   k-step ks:  issue fill(ks + P) -> s_waitcnt vmcnt(4 (P - 1)) (own part of fill(ks + 1) has landed; loads return
-//               in order) -> s_barrier (everyone's part has landed) -> ds_read the 16 fragments of k-step ks + 1 into
-//               the other register set -> the 24 MFMAs of k-step ks from the set read one k-step ago, with the relu /
-//               split of layer 1 for the next row tile in their shadow.
+//   k-step ks:  s_waitcnt vmcnt(4 (P - 2)) (own share of fill(ks + 1) has landed; loads return in order; the younger
+//               fills are ks + 2 .. ks + P - 1) -> s_barrier (everyone's share has landed) -> the 24 MFMAs of k-step
+//               ks from the register set read one k-step ago, with everything else issued in their shadow: the LDS
+//               reads of k-step ks + 1 into the other register set, fill(ks + P), and the relu / split of layer 1.
 //   fill(ks + P) overwrites the slot of k-step ks - 2; the slots being read while it is in flight are ks and ks + 1.
 // The loads are issued from inline asm so that hipcc's waitcnt insertion does not see them (it would drain the queue
 // with vmcnt(0) before every LDS read that might alias them); the waits above are therefore explicit.
@@ -211,22 +235,23 @@ AE_DEV void glds16(const void *src_base, unsigned voff, unsigned lds_dst) {
                : "memory");
 }
 
-// fragments f = 2 tile + (0 hi | 1 lo) of k-step ks -> ring slot ks mod R; wave w takes f = w, w + nw, ...
-AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int ks, int nw) {
+// fragment f = 2 tile + (0 hi | 1 lo) of k-step ks -> ring slot ks mod R
+AE_DEV void actor_ring_fill_one(const ActorParamsH &H, uint4 *ring, int ks, int f) {
   const unsigned voff = (threadIdx.x & 63u) * 16u;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned base = (unsigned)(uintptr_t)ring + (unsigned)((ks & (ACTOR_RING_SLOTS - 1)) * 16 * 64 * 16);
-  auto one = [&](int f) {
-    const uint64_t a = (uint64_t)(uintptr_t)(((f & 1) ? H.W2L : H.W2H) + (ks * 8 + (f >> 1)) * 64);
-    // wave-uniform by construction; readfirstlane tells the compiler so (the asm wants SGPR operands)
-    const uint64_t au = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
-                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
-    glds16(reinterpret_cast<const void *>(au), voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)(f * 1024))));
-  };
+  const uint64_t a = (uint64_t)(uintptr_t)(((f & 1) ? H.W2L : H.W2H) + (ks * 8 + (f >> 1)) * 64);
+  // wave-uniform by construction; readfirstlane tells the compiler so (the asm wants SGPR operands)
+  const uint64_t au = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
+                      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
+  glds16(reinterpret_cast<const void *>(au), voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)(f * 1024))));
+}
+// the whole k-step: wave w takes f = w, w + nw, ... (four each when all four waves of the workgroup are live)
+AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int ks, int nw) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (nw == 4) {
-    static_for<0, 4>([&](auto FI) { constexpr int fi = FI; one(wave + 4 * fi); });
+    static_for<0, 4>([&](auto FI) { constexpr int fi = FI; actor_ring_fill_one(H, ring, ks, wave + 4 * fi); });
   } else {
-    for (int f = wave; f < 16; f += nw) one(f);
+    for (int f = wave; f < 16; f += nw) actor_ring_fill_one(H, ring, ks, f);
   }
 }
 AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {
@@ -245,9 +270,26 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
   const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;
   const float4 *b2tab = b2w3 + ACTOR_HID;                  // b2 alone, four consecutive neurons per float4
   float z[3] = {0.f, 0.f, 0.f};
+  // this wave's four fragments of a fill (f = wave + 4 fi): wave-uniform source bases and LDS destinations, once per call
+  const unsigned voff16 = (threadIdx.x & 63u) * 16u;
+  uint64_t fill_src[4];
+  unsigned fill_dst[4];
+  {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    static_for<0, 4>([&](auto FI) {
+      constexpr int fi = FI;
+      const int f = wave + 4 * fi;
+      const uint64_t a = (uint64_t)(uintptr_t)(((f & 1) ? H.W2L : H.W2H) + (f >> 1) * 64);
+      fill_src[fi] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
+                     ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
+      fill_dst[fi] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)ring + (unsigned)(f * 1024)));
+    });
+  }
+  ASEC_T0();
   // everything this wave has in flight (ring slots from the previous call's tail or actor_ring_init, and whatever the
   // env step left behind) has landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ASEC_ADD(0);   // entry wait
   // The two env column tiles of the wave (envs 0..31 and 32..63) are processed one after the other: 128 accumulator
   // registers instead of 256 (the full set plus the operands does not fit without spills into the k-loop, and scratch
   // traffic inside the loop would also break the vmcnt accounting of the ring).  W2 streams through the ring twice.
@@ -281,12 +323,28 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     };
     // relu + f16 hi / lo split of registers 8 u + 2 c, 8 u + 2 c + 1 of a1 -> halfs 2 c, 2 c + 1 of k-step u's B operand.
     // K order inside a k-step: (half, j) <-> neuron 16 ks + 8 (j / 4) + 4 half + (j % 4); W2H / W2L are packed to match.
+    auto relu = [](float x) {   // one v_max (fmaxf would add a canonicalising v_max of the accumulator read in front)
+      float y;
+      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+      return y;
+    };
     auto split2 = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2], half8 (&l)[2]) {
       constexpr int u = UI, c = CI;
-      const float x0 = fmaxf(a1[8 * u + 2 * c], 0.f), x1 = fmaxf(a1[8 * u + 2 * c + 1], 0.f);
+      const float x0 = relu(a1[8 * u + 2 * c]), x1 = relu(a1[8 * u + 2 * c + 1]);
       const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
       h[u][2 * c] = h0; h[u][2 * c + 1] = h1;
       l[u][2 * c] = (_Float16)(x0 - (float)h0); l[u][2 * c + 1] = (_Float16)(x1 - (float)h1);
+    };
+    // the same in two halves that fit the shadow of one MFMA each: (A) relu + hi, (B) lo
+    float sx0 = 0.f, sx1 = 0.f;
+    auto split2a = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2]) {
+      constexpr int u = UI, c = CI;
+      sx0 = relu(a1[8 * u + 2 * c]); sx1 = relu(a1[8 * u + 2 * c + 1]);
+      h[u][2 * c] = (_Float16)sx0; h[u][2 * c + 1] = (_Float16)sx1;
+    };
+    auto split2b = [&](auto UI, auto CI, const half8 (&h)[2], half8 (&l)[2]) {
+      constexpr int u = UI, c = CI;
+      l[u][2 * c] = (_Float16)(sx0 - (float)h[u][2 * c]); l[u][2 * c + 1] = (_Float16)(sx1 - (float)h[u][2 * c + 1]);
     };
     f32x16 acc[NT];   // start from the layer-2 bias: register r <-> neuron 32 nt + 8 (r / 4) + 4 half + (r % 4)
     static_for<0, NT>([&](auto NI) {
@@ -302,72 +360,104 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       const f32x16 a1 = layer1(0);
       static_for<0, 2>([&](auto UI) { static_for<0, 4>([&](auto CI) { split2(a1, UI, CI, bh, bl); }); });
     }
-    // one k-step: refill the ring, make k-step ks + 1 visible (own part landed, then everyone's), start its LDS reads
-    // into (nh, nl) and run the 24 MFMAs of k-step ks from (ch, cl), which were read one k-step ago
-    auto kstep_head = [&](int ks, half8 (&nh)[NT], half8 (&nl)[NT]) {
-      actor_ring_fill(H, ring, (ks + ACTOR_RING_AHEAD) & 15, nw);
-      if (nw == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ACTOR_RING_AHEAD - 1)) : "memory");
+    // One k-step.  Head: make k-step ks + 1 visible (own share landed, then everyone's).  Body: the 24 MFMAs of k-step
+    // ks from (ch, cl), read one k-step ago, each followed by one slice of the other work so that it issues while the
+    // matrix pipe is busy (an MFMA holds the pipe for 8 issue slots and the wave issues in order: work placed behind a
+    // block of MFMAs waits for all of them):
+    //   slots 0..15   one LDS read each of k-step ks + 1's fragments into (nh, nl),
+    //   slots 0..15   odd k-steps: half of the relu + hi / lo split of a pair of layer-1 values of the next row tile,
+    //   slots 16..22  every other slot one quarter of fill(ks + P) (scalar address arithmetic + one LDS DMA).
+    auto kstep = [&](auto ODD, int ks, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT],
+                     const f32x16 &a1n) {
+      constexpr int u = ODD;
+      uint64_t fsrc = 0;     // operands of the fill quarter whose DMA goes out in the next slot
+      unsigned fdst = 0;
+      ASEC_ADD(5);
+      if (nw == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ACTOR_RING_AHEAD - 2)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ASEC_ADD(2);   // counted vmcnt wait
+#ifndef EXP_NOBARRIER
       __builtin_amdgcn_s_barrier();
+#endif
       asm volatile("" ::: "memory");
+      ASEC_ADD(3);   // barrier
       const half8 *slot = reinterpret_cast<const half8 *>(ring) + ((ks + 1) & (ACTOR_RING_SLOTS - 1)) * 16 * 64 + lane;
-      static_for<0, NT>([&](auto NI) { constexpr int nt = NI; nh[nt] = slot[(2 * nt) * 64]; nl[nt] = slot[(2 * nt + 1) * 64]; });
+      const int kf = (ks + ACTOR_RING_AHEAD) & 15;
+      static_for<0, 3 * NT>([&](auto MI) {
+        constexpr int m = MI;
+        // order: pass (hi*hi, hi*lo, lo*hi) outermost, so consecutive MFMAs never share an accumulator
+        constexpr int k3 = m / NT, nt = m % NT;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? cl[nt] : ch[nt], k3 == 1 ? bl[u] : bh[u], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (m < 16) {
+          if constexpr (m % 2 == 0) nh[m / 2] = slot[m * 64];
+          else nl[m / 2] = slot[m * 64];
+        }
+        if constexpr (u == 1 && m < 16) {   // value pair m / 2: (A) in the even slot, (B) in the odd one
+          if constexpr (m % 2 == 0) split2a(a1n, std::integral_constant<int, (m / 2) / 4>{}, std::integral_constant<int, (m / 2) % 4>{}, bh_n);
+          else split2b(std::integral_constant<int, (m / 2) / 4>{}, std::integral_constant<int, (m / 2) % 4>{}, bh_n, bl_n);
+        }
+        // fill(ks + P), one quarter per two slots: scalar address arithmetic in one, the LDS DMA in the next
+        if constexpr (m >= 15 && m < 23 && m % 2 == 1) {
+          constexpr int fi = (m - 15) / 2;
+          fsrc = fill_src[fi] + (uint64_t)(unsigned)kf * (8u * 64u * 16u);
+          fdst = fill_dst[fi] + (unsigned)(kf & (ACTOR_RING_SLOTS - 1)) * (16u * 64u * 16u);
+        }
+        if constexpr (m >= 16 && m < 24 && m % 2 == 0) {
+          if (nw == 4) glds16(reinterpret_cast<const void *>(fsrc), voff16, fdst);
+          else if (m == 16) actor_ring_fill(H, ring, kf, nw);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
     };
     half8 ah0[NT], al0[NT], ah1[NT], al1[NT];   // A fragments of even / odd k-steps
     // k-step 0 of this pass.  First pass: every wave's share of it has landed after the vmcnt(0) above and this barrier;
     // second pass: it was made visible by the last k-step of the first pass (its own read there is dropped so that no
     // A fragments stay live across the pass epilogue).
+    ASEC_ADD(6);     // pass prologue: operands of layer 1, bias init, first layer-1 tile + split
     if (t == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
       const half8 *slot = reinterpret_cast<const half8 *>(ring) + lane;
       static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah0[nt] = slot[(2 * nt) * 64]; al0[nt] = slot[(2 * nt + 1) * 64]; });
     }
+    f32x16 a1n = {};
+#ifdef EXP_RLOOP
+#pragma unroll 1
+    for (int R = 0; R < EXP_RLOOP; ++R) {
+#else
 #pragma unroll 1
     for (int R = 0; R < 8; ++R) {
-      f32x16 a1n;
-      {   // k-step 2 R: 24 MFMAs, then layer 1 of row tile R + 1 goes into the matrix pipe behind them
-        kstep_head(2 * R, ah1, al1);
-        static_for<0, 3 * NT>([&](auto MI) {
-          constexpr int m = MI;
-          // order: pass (hi*hi, hi*lo, lo*hi) outermost, so consecutive MFMAs never share an accumulator
-          constexpr int k3 = m / NT, nt = m % NT;
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al0[nt] : ah0[nt], k3 == 1 ? bl[0] : bh[0], acc[nt], 0, 0, 0);
-        });
-        a1n = layer1(R + 1);
-      }
-      {   // k-step 2 R + 1: 24 MFMAs with the relu / split of row tile R + 1 in their shadow (one slice per third MFMA)
-        kstep_head(2 * R + 1, ah0, al0);
-        static_for<0, 8>([&](auto JI) {
-          constexpr int j = JI;
-          auto mfma = [&](auto MI) {
-            constexpr int m = MI;
-            constexpr int k3 = m / NT, nt = m % NT;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? al1[nt] : ah1[nt], k3 == 1 ? bl[1] : bh[1], acc[nt], 0, 0, 0);
-          };
-          __builtin_amdgcn_sched_barrier(0);
-          mfma(std::integral_constant<int, 3 * j>{});
-          mfma(std::integral_constant<int, 3 * j + 1>{});
-          __builtin_amdgcn_sched_barrier(0);
-          split2(a1n, std::integral_constant<int, j / 4>{}, std::integral_constant<int, j % 4>{}, bh_n, bl_n);
-          __builtin_amdgcn_sched_barrier(0);
-          mfma(std::integral_constant<int, 3 * j + 2>{});
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      }
+#endif
+      kstep(std::integral_constant<int, 0>{}, 2 * R, ah0, al0, ah1, al1, a1n);
+      a1n = layer1(R + 1);     // layer 1 of row tile R + 1 goes into the matrix pipe behind the 24 MFMAs
+      kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n);
       bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
     }
+    ASEC_ADD(5);
     // layer 2 bias + relu and layer 3 over the 128 neurons this lane holds for its env column (the other 128 are in
     // lane ^ 32)
     float p[3] = {0.f, 0.f, 0.f};
-    static_for<0, NT>([&](auto NI) {
+    // table rows of tile nt + 1 are read from LDS while tile nt is reduced (two register sets of 16 float4)
+    float4 tab[2][16];
+    auto tab_load = [&](auto NI, float4 (&c)[16]) {
       constexpr int nt = NI;
-      __builtin_amdgcn_sched_barrier(0);                     // one tile's 16 table rows in flight at a time
       static_for<0, 16>([&](auto RI) {
         constexpr int r = RI;
-        const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float4 c = b2w3[n];
-        const float h2 = fmaxf(acc[nt][r], 0.f);               // the bias is already in the accumulator
+        c[r] = b2w3[32 * nt + (r & 3) + 8 * (r >> 2) + 4 * half];
+      });
+    };
+    tab_load(std::integral_constant<int, 0>{}, tab[0]);
+    static_for<0, NT>([&](auto NI) {
+      constexpr int nt = NI;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (nt + 1 < NT) tab_load(std::integral_constant<int, nt + 1>{}, tab[(nt + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 16>([&](auto RI) {
+        constexpr int r = RI;
+        const float4 c = tab[nt & 1][r];
+        const float h2 = relu(acc[nt][r]);                     // the bias is already in the accumulator
         p[0] = fmaf(c.y, h2, p[0]); p[1] = fmaf(c.z, h2, p[1]); p[2] = fmaf(c.w, h2, p[2]);
       });
     });
@@ -376,8 +466,11 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       const float tot = p[o] + __shfl_xor(p[o], 32);         // lane e holds env e: tile e >> 5, column e & 31
       z[o] = (half == t) ? tot : z[o];
     });
+    ASEC_ADD(7);     // pass epilogue: relu, layer 3, exchange
   }
   static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
+  ASEC_ADD(8);       // tanh
+  ASEC_FLUSH();
 }
 
 }  // namespace armenv
