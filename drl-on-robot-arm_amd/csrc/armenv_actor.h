@@ -1,20 +1,20 @@
-// armenv_actor.h -- the TD3 actor (PolicyNet, /root/reference/algo/TD3/net_mlp.py:29-40) evaluated per wavefront
-// for the 64 envs a wave owns, exact f32:
+// armenv_actor.h -- the TD3 actor (PolicyNet, /root/reference/algo/TD3/net_mlp.py:29-40) evaluated for the envs a
+// wavefront owns:
 //     a = action_bound * tanh(W3 relu(W2 relu(W1 s + b1) + b2) + b3),   6|9 -> 256 -> 256 -> 3
 //
 // Layer 2 is the only dense contraction on the env path (131 kflop of the 136 kflop per env) and runs on the matrix
-// cores with the f32-input MFMA (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain).  It is computed
-// TRANSPOSED, H2^T[neuron][env] = W2 * H1^T, so that in the accumulator layout a lane holds 128 neurons of ONE env:
-// layer 3's reduction over neurons is then in-register plus one lane<->lane+32 exchange, and no activation ever goes
-// through LDS.  Per k-pair (k = 2kk, 2kk+1) a lane
-//   - computes its B operand on the VALU: h1[env][k] for k = 2kk + (lane>>5) and env = (lane&31) [tile 0] and
-//     (lane&31)+32 [tile 1]  (layer 1 is 6|9 FMAs per value -- cheaper to recompute in the operand layout than to move),
-//   - fetches its A operand, W2[32 nt + (lane&31)][k] for the eight neuron tiles nt, as two 16-byte loads from a
-//     pre-packed copy of W2 (256 KB, L2-resident, shared by every wave; prefetched one k-pair ahead; one 16-byte load
-//     per pass),
-//   - issues 8 MFMAs (4 neuron tiles x 2 env tiles) into 128 accumulator registers, in two passes over the tiles.
-// 2048 MFMAs x 64 cycles per wave per step: the fused-actor configuration is MFMA-bound at the f32 matrix rate.
-// No LDS, no barriers: waves of a workgroup stay unsynchronised, as in the rest of the rollout kernel.
+// cores, TRANSPOSED: H2^T[neuron][env] = W2 * H1^T, so that in the accumulator layout a lane holds 128 neurons of ONE
+// env -- layer 3's reduction over neurons is in-register plus one lane<->lane+32 exchange and no activation ever goes
+// through LDS.  Layer 1 also runs on the (f32) MFMA, as W1aug * [obs, 1]: its accumulator layout IS layer 2's
+// B-operand layout up to a permutation of k, which the A-operand indexing / packing absorbs, so only a relu (and, for
+// the f16 variant, the hi / lo split) separates the two layers.
+// Two variants:
+//   actor_forward_wave      exact f32: v_mfma_f32_32x32x2_f32 for both layers; the A operand of layer 2 streams from an
+//                           L2-resident packed copy of W2 through a register ring with counted waits; per wave, no barriers.
+//   actor_forward_wg_f16x3  f32 emulated by three f16 MFMA passes (hi*hi + hi*lo + lo*hi); a workgroup phase with the W2
+//                           fragments shared through an LDS ring filled by direct-to-LDS loads.
+// One wave per SIMD (the env step needs the whole register file): an MFMA holds the matrix pipe for 8 / 16 issue slots and
+// the wave issues in order, so everything that is not an MFMA is placed between two MFMAs, never behind a block of them.
 #pragma once
 #include "armenv_math.h"
 
@@ -49,113 +49,13 @@ static __device__ unsigned long long g_actor_sections[16];
 constexpr int ACTOR_HID = 256;
 
 struct ActorParams {
-  const float *W1P;    // [128 kk][2 rows k = 2kk, 2kk+1][12]: w0..w8 (zero beyond in_dim), 0, 0, b1 -- read through the
-                       // scalar cache (wave-uniform address), never through the vector memory path
+  const float *W1P;    // [256 k][12]: w0..w8 (zero beyond in_dim), 0, 0, b1 -- source of the LDS tables (actor_stage_w1)
   const float4 *W2P;   // [256 k][2 part][32 lane]: (W2[32*(4 part + c) + lane][k], c = 0..3)
   const float4 *B2W3;  // [256]: (b2[n], W3[0][n], W3[1][n], W3[2][n])
   float b3[3];
   float bound;
   int32_t in_dim;      // 6 (reach obs) or 9 (push obs)
 };
-
-// s: this lane's env observation (IN floats).  All 64 lanes of the wave must be active.
-template <int IN>
-AE_DEV void actor_forward_wave(const ActorParams &A, const float (&s)[IN], float (&out)[3]) {
-  const int lane = threadIdx.x & 63;
-  const int half = lane >> 5;
-  const int l32 = lane & 31;
-  // observation of the env in tile 0 (env l32) and tile 1 (env l32 + 32) of this lane's MFMA column
-  float sA[IN], sB[IN];
-  static_for<0, IN>([&](auto DI) {
-    constexpr int d = DI;
-    const float other = __shfl_xor(s[d], 32);
-    sA[d] = half ? other : s[d];
-    sB[d] = half ? s[d] : other;
-  });
-  // Two passes of four neuron tiles (128 accumulator registers each) keep the whole kernel free of spills; layer 1
-  // is recomputed per pass (16 VALU ops per k-pair beside 8 x 64 cycles of MFMA).
-  float p[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  const float4 *w2 = A.W2P + l32;
-#pragma unroll 1
-  for (int part = 0; part < 2; ++part) {
-    f32x16 acc[4][2];
-    static_for<0, 4>([&](auto NI) {
-      constexpr int nt = NI;
-      static_for<0, 16>([&](auto RI) { constexpr int r = RI; acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f; });
-    });
-    // Software pipeline, two k-pairs deep: while the eight MFMAs of k-pair kk occupy the matrix pipe (8 x 64 cycles),
-    // the VALU computes layer 1 for kk+1 from W1 rows fetched during kk-1, and the loads for kk+2 are in flight.
-    // W1 rows: both halves of the wave need a different row (k = 2kk + lane/32), i.e. two wave-uniform rows per
-    // k-pair.  Fetching them per lane through the vector path (64 lanes x 16 B of identical addresses, three times
-    // per k-pair) halved the MFMA rate (57 vs 110 TF); through the scalar cache they cost nothing visible.
-    typedef const float __attribute__((address_space(4))) *scalar_ptr;
-    const scalar_ptr w1s = (scalar_ptr)A.W1P;
-    struct Rows { float r0[12], r1[12]; };
-    auto load_rows = [&](int kk, Rows &R) {
-      const int kc = kk < ACTOR_HID / 2 ? kk : ACTOR_HID / 2 - 1;   // the tail prefetches re-read the last pair
-      static_for<0, 12>([&](auto JI) { constexpr int j = JI; R.r0[j] = w1s[kc * 24 + j]; R.r1[j] = w1s[kc * 24 + 12 + j]; });
-    };
-    auto load_a = [&](int kk) {
-      const int kc = kk < ACTOR_HID / 2 ? kk : ACTOR_HID / 2 - 1;
-      return w2[((2 * kc + half) * 2 + part) * 32];
-    };
-    auto layer1 = [&](const Rows &R, float &hA, float &hB) {
-      float a0 = R.r0[11], a1 = R.r1[11], b0 = R.r0[11], b1 = R.r1[11];
-      static_for<0, IN>([&](auto DI) {
-        constexpr int d = DI;
-        a0 = fmaf(R.r0[d], sA[d], a0); a1 = fmaf(R.r1[d], sA[d], a1);
-        b0 = fmaf(R.r0[d], sB[d], b0); b1 = fmaf(R.r1[d], sB[d], b1);
-      });
-      hA = fmaxf(half ? a1 : a0, 0.f);
-      hB = fmaxf(half ? b1 : b0, 0.f);
-    };
-    // Software pipeline: while the eight MFMAs of k-pair kk occupy the matrix pipe (8 x 64 cycles), the VALU computes
-    // layer 1 for kk+1 and the loads for kk+2 (A operand) / kk+1 (W1 rows) are in flight.
-    Rows R;
-    float hA, hB, hA_n, hB_n;
-    load_rows(0, R);
-    layer1(R, hA, hB);
-    float4 a_cur = load_a(0), a_nxt = load_a(1);
-    load_rows(1, R);
-#pragma unroll 1
-    for (int kk = 0; kk < ACTOR_HID / 2; ++kk) {
-      const float4 a_nn = load_a(kk + 2);
-      // keep the loads above the MFMAs: hipcc otherwise sinks them to their first use and exposes an L2 round trip
-      __builtin_amdgcn_sched_barrier(0);
-      const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
-      static_for<0, 4>([&](auto NI) {
-        constexpr int nt = NI;
-        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hA, acc[nt][0], 0, 0, 0);
-        acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hB, acc[nt][1], 0, 0, 0);
-      });
-      layer1(R, hA_n, hB_n);                                // layer 1 for kk+1
-      load_rows(kk + 2, R);
-      __builtin_amdgcn_sched_barrier(0);
-      hA = hA_n; hB = hB_n;
-      a_cur = a_nxt; a_nxt = a_nn;
-    }
-    // layer 2 bias + relu, layer 3 partial sums over the 64 neurons this lane holds per env tile in this pass
-    static_for<0, 4>([&](auto NI) {
-      constexpr int nt = NI;
-      static_for<0, 16>([&](auto RI) {
-        constexpr int r = RI;
-        const int n = 32 * (4 * part + nt) + (r & 3) + 8 * (r >> 2) + 4 * half;   // accumulator row -> neuron
-        const float4 c = A.B2W3[n];
-        const float h0 = fmaxf(acc[nt][0][r] + c.x, 0.f);
-        const float h1 = fmaxf(acc[nt][1][r] + c.x, 0.f);
-        p[0][0] = fmaf(c.y, h0, p[0][0]); p[0][1] = fmaf(c.z, h0, p[0][1]); p[0][2] = fmaf(c.w, h0, p[0][2]);
-        p[1][0] = fmaf(c.y, h1, p[1][0]); p[1][1] = fmaf(c.z, h1, p[1][1]); p[1][2] = fmaf(c.w, h1, p[1][2]);
-      });
-    });
-  }
-  static_for<0, 3>([&](auto OI) {
-    constexpr int o = OI;
-    const float t0 = p[0][o] + __shfl_xor(p[0][o], 32);
-    const float t1 = p[1][o] + __shfl_xor(p[1][o], 32);
-    const float z = (half ? t1 : t0) + A.b3[o];     // lane e holds env e: tile e>>5, column e&31
-    out[o] = tanhf(z) * A.bound;                    // net_mlp.py:40
-  });
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Fast variant: layer 2 on the f16 MFMA (v_mfma_f32_32x32x16_f16, 16x the f32 MFMA rate) with both operands split
@@ -191,6 +91,126 @@ AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, in
     lds[ACTOR_W1A_FLOATS / 4 + i] = c;
     reinterpret_cast<float *>(lds + ACTOR_W1A_FLOATS / 4 + ACTOR_HID)[i] = c.x;
   }
+}
+
+// Exact-f32 actor for the 64 envs of one wave.  s: this lane's env observation (IN floats); all 64 lanes must be active;
+// w1_lds: the tables of actor_stage_w1.
+//   Layer 1 runs on the f32 MFMA as W1aug . [obs, 1] per 32-neuron row tile and env column tile.  In the accumulator
+//   layout lane (half h) holds, in register i = 4 b + c, neuron 32 R + 8 b + 4 h + c of its env column -- which is exactly
+//   the B operand of layer 2's k-pair {32 R + 8 b + c, 32 R + 8 b + 4 + c}: relu(register i) feeds the MFMAs directly and
+//   the A operand is fetched for that k (no repacking: W2P is indexed by k).
+//   Layer 2: per k-pair 8 MFMAs (4 neuron tiles x 2 env tiles) into 128 accumulators, two passes over the neuron tiles.
+//   The A operand (one 16-byte load per lane per k-pair) is prefetched AD k-pairs ahead into a register ring with
+//   explicit loads and counted waits: left to hipcc the loop waits with vmcnt(0) at its head, i.e. for the load issued
+//   one iteration earlier, and an iteration then lasts one L2 round trip (875 cycles against 512 of MFMA).
+template <int IN>
+AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const float (&s)[IN], float (&out)[3]) {
+  static_assert(IN + 1 <= 2 * ACTOR_NK, "augmented input does not fit ACTOR_NK k-pairs");
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+  const float *w1a = reinterpret_cast<const float *>(w1_lds) + lane;
+  // layer-1 B operands: k-pair m of [obs, 1, 0..] of the env in tile 0 (env l32) and tile 1 (env l32 + 32)
+  float bvA[ACTOR_NK], bvB[ACTOR_NK];
+  {
+    float svA[2 * ACTOR_NK], svB[2 * ACTOR_NK];
+    static_for<0, 2 * ACTOR_NK>([&](auto DI) {
+      constexpr int d = DI;
+      if constexpr (d < IN) {
+        const float other = __shfl_xor(s[d], 32);
+        svA[d] = half ? other : s[d];
+        svB[d] = half ? s[d] : other;
+      } else {
+        svA[d] = svB[d] = d == IN ? 1.f : 0.f;
+      }
+    });
+    static_for<0, ACTOR_NK>([&](auto MI) {
+      constexpr int m = MI;
+      bvA[m] = half ? svA[2 * m + 1] : svA[2 * m];
+      bvB[m] = half ? svB[2 * m + 1] : svB[2 * m];
+    });
+  }
+  auto layer1 = [&](int R, f32x16 &a1A, f32x16 &a1B) {
+    static_for<0, 16>([&](auto RI) { constexpr int r = RI; a1A[r] = 0.f; a1B[r] = 0.f; });
+    const float *w = w1a + (R < 8 ? R : 7) * (ACTOR_NK * 64);
+    static_for<0, ACTOR_NK>([&](auto MI) {
+      constexpr int m = MI;
+      if constexpr (2 * m <= IN) {
+        const float wv = w[m * 64];
+        a1A = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, bvA[m], a1A, 0, 0, 0);
+        a1B = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, bvB[m], a1B, 0, 0, 0);
+      }
+    });
+  };
+  auto relu = [](float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+  };
+  float p[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  const float4 *w2 = A.W2P + l32;
+  const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;     // staged beside the layer-1 table
+  constexpr int AD = 4;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll 1
+  for (int part = 0; part < 2; ++part) {
+    f32x16 acc[4][2];
+    static_for<0, 4>([&](auto NI) {
+      constexpr int nt = NI;
+      static_for<0, 16>([&](auto RI) { constexpr int r = RI; acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f; });
+    });
+    f32x4 aring[AD];
+    auto load_a_async = [&](int kk, f32x4 &dst) {   // k-pair kk = 16 R + i, i = 4 b + c  ->  k = 32 R + 8 b + 4 half + c
+      const int kc = kk < ACTOR_HID / 2 ? kk : ACTOR_HID / 2 - 1;   // the tail's prefetches re-read the last pair
+      const int k = 32 * (kc >> 4) + 8 * ((kc >> 2) & 3) + 4 * half + (kc & 3);
+      const float4 *src = w2 + (k * 2 + part) * 32;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+    };
+    static_for<0, AD>([&](auto I) { constexpr int i = I; load_a_async(i, aring[i]); });
+    f32x16 a1A, a1B, nA, nB;
+    layer1(0, a1A, a1B);
+#pragma unroll 1
+    for (int R = 0; R < 8; ++R) {
+      static_for<0, 16>([&](auto I) {
+        constexpr int i = I;
+        const int kk = 16 * R + i;
+        const float hA = relu(a1A[i]), hB = relu(a1B[i]);
+        // the load of k-pair kk is the oldest of the AD in flight
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(aring[i % AD]) : "n"(AD - 1) : "memory");
+        const float av[4] = {aring[i % AD][0], aring[i % AD][1], aring[i % AD][2], aring[i % AD][3]};
+        static_for<0, 4>([&](auto NI) {
+          constexpr int nt = NI;
+          acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hA, acc[nt][0], 0, 0, 0);
+          acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hB, acc[nt][1], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        load_a_async(kk + AD, aring[i % AD]);      // this register set is free again
+        if constexpr (i == 8) layer1(R + 1, nA, nB);   // next row tile's layer 1 goes into the matrix pipe mid-way
+      });
+      a1A = nA; a1B = nB;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's prefetches
+    // layer 2 bias + relu, layer 3 partial sums over the 64 neurons this lane holds per env tile in this pass
+    static_for<0, 4>([&](auto NI) {
+      constexpr int nt = NI;
+      static_for<0, 16>([&](auto RI) {
+        constexpr int r = RI;
+        const int n = 32 * (4 * part + nt) + (r & 3) + 8 * (r >> 2) + 4 * half;   // accumulator row -> neuron
+        const float4 c = b2w3[n];
+        const float h0 = relu(acc[nt][0][r] + c.x);
+        const float h1 = relu(acc[nt][1][r] + c.x);
+        p[0][0] = fmaf(c.y, h0, p[0][0]); p[0][1] = fmaf(c.z, h0, p[0][1]); p[0][2] = fmaf(c.w, h0, p[0][2]);
+        p[1][0] = fmaf(c.y, h1, p[1][0]); p[1][1] = fmaf(c.z, h1, p[1][1]); p[1][2] = fmaf(c.w, h1, p[1][2]);
+      });
+    });
+  }
+  static_for<0, 3>([&](auto OI) {
+    constexpr int o = OI;
+    const float t0 = p[0][o] + __shfl_xor(p[0][o], 32);
+    const float t1 = p[1][o] + __shfl_xor(p[1][o], 32);
+    const float z = (half ? t1 : t0) + A.b3[o];     // lane e holds env e: tile e>>5, column e&31
+    out[o] = tanhf(z) * A.bound;                    // net_mlp.py:40
+  });
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -115,13 +115,11 @@ struct PolicyParams {
 // TD3_MLP.take_action (/root/reference/algo/TD3/TD3_mlp.py:82-97) for n states; MODE 0 exact f32, 1 f16x3.
 template <int IN, int MODE>
 __global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH H, int64_t n, const float *states, float *actions) {
-  __shared__ float4 w1_lds[MODE == 1 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  __shared__ float4 w1_lds[ACTOR_W1_LDS_FLOATS / 4];
   __shared__ uint4 w2_ring[MODE == 1 ? ACTOR_RING_UINT4 : 1];
-  if constexpr (MODE == 1) {
-    actor_stage_w1(A.W1P, w1_lds, A.B2W3, IN);
-    actor_ring_init(H, w2_ring, 4);
-    __syncthreads();
-  }
+  actor_stage_w1(A.W1P, w1_lds, A.B2W3, IN);
+  if constexpr (MODE == 1) actor_ring_init(H, w2_ring, 4);
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 256
   const int64_t ic = i < n ? i : n - 1;
   float s[IN], a[3];
@@ -130,7 +128,7 @@ __global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH 
     actor_forward_wg_f16x3<IN>(A, H, w1_lds, w2_ring, 4, s, a);
     actor_ring_drain();
   } else {
-    actor_forward_wave<IN>(A, s, a);
+    actor_forward_wave<IN>(A, w1_lds, s, a);
   }
   if (i < n) { actions[3 * i] = a[0]; actions[3 * i + 1] = a[1]; actions[3 * i + 2] = a[2]; }
 }
@@ -641,14 +639,17 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io
 template <class Lane, typename T, int POLICY>
 __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
                                                           const float *actions, StepIO io0, float *actions_out) {
-  __shared__ float4 w1_lds[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
+  __shared__ float4 w1_lds[kActor ? ACTOR_W1_LDS_FLOATS / 4 : 1];
   __shared__ uint4 w2_ring[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_RING_UINT4 : 1];
   int nw = 4;   // live waves of this workgroup (the last one may be ragged; num_envs is a multiple of 64)
-  if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // W1 staged once; W2 streams through the ring every step
+  if constexpr (kActor) {   // layer-1 / layer-3 tables staged once per launch
     actor_stage_w1(pol.actor.W1P, w1_lds, pol.actor.B2W3, Lane::kObs);
-    const int64_t left = P.n - (int64_t)blockIdx.x * blockDim.x;
-    nw = (int)(((left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x) + 63) >> 6);
-    if ((int)(threadIdx.x >> 6) < nw) actor_ring_init(pol.actor_h, w2_ring, nw);
+    if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // W2 streams through the ring every step
+      const int64_t left = P.n - (int64_t)blockIdx.x * blockDim.x;
+      nw = (int)(((left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x) + 63) >> 6);
+      if ((int)(threadIdx.x >> 6) < nw) actor_ring_init(pol.actor_h, w2_ring, nw);
+    }
     __syncthreads();
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
       if constexpr (POLICY == ARMENV_POLICY_ACTOR) {
         float s[kObs];
         L.policy_obs(s);
-        actor_forward_wave<kObs>(pol.actor, s, mu);                      // take_action, TD3_mlp.py:82-97
+        actor_forward_wave<kObs>(pol.actor, w1_lds, s, mu);              // take_action, TD3_mlp.py:82-97
       } else if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {
         float s[kObs];
         L.policy_obs(s);
