@@ -44,6 +44,16 @@ template <typename T> struct EnvParams {
   ChainDev<T> chain;
 };
 
+// The rollout's next action, loaded while the current step runs.  The load goes STRAIGHT INTO ACCUMULATION REGISTERS from
+// inline asm and is waited for explicitly after the IK: as an ordinary load hipcc parks the three values in AGPRs to
+// relieve the IK's VGPR pressure, which needs the data -- so it waited (vmcnt(0)) a few hundred instructions after issuing
+// the load, i.e. for most of an HBM round trip, every step (SQ_WAIT_ANY 15 % of the wave's cycles).
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+AE_DEV void prefetch_issue(const float *src, f32x3 &dst) {
+  asm volatile("global_load_dwordx3 %0, %1, off" : "=a"(dst) : "v"(src) : "memory");
+}
+AE_DEV void prefetch_settle(f32x3 &dst) { asm volatile("s_waitcnt vmcnt(0)" : "+a"(dst) : : "memory"); }
+
 struct StepIO {
   const float *action;
   float *obs;
@@ -244,16 +254,16 @@ template <class C, typename T> struct ReachLane {
 
   // RLReachEnv.step + _reward (rl_reach_env.py:219-319) with action a; writes row i of the caller's buffers.
   // Returns the number of IK updates.
-  // `prefetched` (nullable): registers a caller loaded before this step (the rollout's next action).  They are
+  // `prefetched` (nullable): registers a caller is loading during this step (the rollout's next action).  They are
   // consumed here, right after the IK and BEFORE this step's stores are issued: the s_waitcnt the consumption needs
   // then covers only that old load; placed at the next step's top it would also wait for this step's stores
   // (vmcnt is in-order) -- measured 15 % of the wave's cycles.
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, const float (*prefetched)[3] = nullptr) {
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, f32x3 *prefetched = nullptr) {
     const int64_t n = P.n;
     FKState<T> S;
     T tgt[3];
     const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
-    if (prefetched) asm volatile("" ::"v"((*prefetched)[0]), "v"((*prefetched)[1]), "v"((*prefetched)[2]));
+    if (prefetched) prefetch_settle(*prefetched);
 
     n_upd += (uint32_t)updates;
     step += 1;                                                                    // :264
@@ -515,13 +525,13 @@ template <class C, typename T, bool PICK> struct CubeLane {
     contact(P, tip0, tip);
   }
 
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, const float (*prefetched)[3] = nullptr) {
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, f32x3 *prefetched = nullptr) {
     FKState<T> S;
     T tgt[3];
     T p0[3];
     const T q7 = q[NJ - 1];
     const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
-    if (prefetched) asm volatile("" ::"v"((*prefetched)[0]), "v"((*prefetched)[1]), "v"((*prefetched)[2]));
+    if (prefetched) prefetch_settle(*prefetched);
     n_upd += (uint32_t)updates;
     if constexpr (PICK) {
       q[NJ - 1] = q7;               // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
@@ -668,14 +678,13 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
     // step's stores
     asm volatile("" ::"v"(an[0]), "v"(an[1]), "v"(an[2]));
   }
+  f32x3 an_next = {0.f, 0.f, 0.f};
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
     if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
       a[0] = (T)an[0]; a[1] = (T)an[1]; a[2] = (T)an[2];
-      if (t + 1 < steps) {   // prefetch the next step's action; its latency hides under this step's IK
-        const float *nx = actions + ((int64_t)(t + 1) * n + i) * 3;
-        an[0] = nx[0]; an[1] = nx[1]; an[2] = nx[2];
-      }
+      // prefetch the next step's action (the last step re-reads its own); settled inside env_step, after the IK
+      prefetch_issue(actions + ((int64_t)(t + 1 < steps ? t + 1 : t) * n + i) * 3, an_next);
     } else {
       float mu[3] = {0.f, 0.f, 0.f};
       if constexpr (POLICY == ARMENV_POLICY_ACTOR) {
@@ -711,8 +720,12 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
       else { ao[0] = an[0]; ao[1] = an[1]; ao[2] = an[2]; }
     }
     const uint32_t before = L.n_done;
-    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) L.env_step(P, i, a, io, &an);
-    else L.env_step(P, i, a, io);
+    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+      L.env_step(P, i, a, io, &an_next);
+      an[0] = an_next[0]; an[1] = an_next[1]; an[2] = an_next[2];
+    } else {
+      L.env_step(P, i, a, io);
+    }
     if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
       if (L.n_done != before && P.auto_reset) episode += 1u;
     }
