@@ -227,23 +227,27 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
 // Measured (65 536 envs): 37 us standalone, 49 us per fused env step; the MFMAs themselves take 17 us (20.7 ns each, the
 // rate of a constant-operand probe), LDS reads are hidden, fills + barriers cost 6 us, the rest is VALU that cannot
 // overlap the MFMAs of its own wave.
-// Ring protocol (R = 8 slots of 16 KB, prefetch distance P = R - 2 = 6 k-steps -- an L2 round trip is several k-steps
-// long --, slot = k-step mod R; 16 k-steps per pass, so the mapping carries over from one pass / call to the next and
-// the tail of a call prefetches the first k-steps of the following one):
-//   k-step ks:  s_waitcnt vmcnt(4 (P - 2)) (own share of fill(ks + 1) has landed; loads return in order; the younger
-//               fills are ks + 2 .. ks + P - 1) -> s_barrier (everyone's share has landed) -> the 24 MFMAs of k-step
-//               ks from the register set read one k-step ago, with everything else issued in their shadow: the LDS
-//               reads of k-step ks + 1 into the other register set, fill(ks + P), and the relu / split of layer 1.
-//   fill(ks + P) overwrites the slot of k-step ks - 2; the slots being read while it is in flight are ks and ks + 1.
+// LDS holds k-steps 0..3 of W2 permanently (64 KB, filled once per launch) and streams k-steps 4..15 through a ring of
+// four 16 KB slots (slot = k-step mod 4; 12 streamed k-steps per pass, so the mapping carries over from pass to pass
+// and call to call).  Protocol of k-step ks (the tail of a call refills for the following one):
+//   head   s_waitcnt vmcnt(0) (own share of the refill issued one k-step ago, which is k-step ks + 1's data)
+//          -> s_barrier (everyone's share has landed)
+//   body   the 24 MFMAs of k-step ks from the register set read one k-step ago, with everything else issued in their
+//          shadow: slots 1..7 the four quarters of the refill two stream positions ahead (k-step ks + 2's slot was last
+//          read during k-step ks - 3), slots 8..23 the LDS reads of k-step ks + 1 into the other register set and the
+//          relu / split of layer 1.
 // The loads are issued from inline asm so that hipcc's waitcnt insertion does not see them (it would drain the queue
 // with vmcnt(0) before every LDS read that might alias them); the waits above are therefore explicit.
 // Callers: actor_ring_init() once per kernel after computing `nw` (live waves of this workgroup), actor_ring_drain()
-// before the kernel ends (an LDS DMA must not outlive the workgroup's LDS allocation).
-#ifndef ACTOR_RING_SLOTS
-#define ACTOR_RING_SLOTS 8
-#endif
-constexpr int ACTOR_RING_AHEAD = ACTOR_RING_SLOTS - 2;         // prefetch distance in k-steps
-constexpr int ACTOR_RING_UINT4 = ACTOR_RING_SLOTS * 16 * 64;   // 16 KB per slot
+// before the kernel ends (an LDS DMA must not outlive the workgroup's LDS allocation).  The k-loop must stay free of
+// compiler-generated VMEM (no spills): hipcc's own vmcnt arithmetic does not see the DMA loads.
+constexpr int ACTOR_KRES = 4;          // k-steps 0..3 of W2 stay resident in LDS for the whole launch
+constexpr int ACTOR_RING_SLOTS = 4;    // k-steps 4..15 stream through four slots; (16 - KRES) is a multiple of the slot count
+constexpr int ACTOR_RING_UINT4 = (ACTOR_KRES + ACTOR_RING_SLOTS) * 16 * 64;   // 16 KB per k-step: 128 KB
+// LDS region (in k-step units) that holds k-step ks
+AE_DEV int actor_region(int ks) { return ks < ACTOR_KRES ? ks : ACTOR_KRES + (ks & (ACTOR_RING_SLOTS - 1)); }
+// the streamed k-step two stream positions after ks (ks >= KRES): 4 -> 6, ..., 13 -> 15, 14 -> 4, 15 -> 5
+AE_DEV int actor_next2(int ks) { const int t = ks - ACTOR_KRES + 2; return ACTOR_KRES + (t >= 16 - ACTOR_KRES ? t - (16 - ACTOR_KRES) : t); }
 
 // one 1 KB direct-to-LDS copy: lane l moves 16 bytes from src_base + voff (voff = 16 l) to LDS byte lds_dst + 16 l.
 // src_base and lds_dst are wave-uniform (SGPRs): a fill costs scalar adds only, no VALU.
@@ -258,7 +262,7 @@ AE_DEV void glds16(const void *src_base, unsigned voff, unsigned lds_dst) {
 // fragment f = 2 tile + (0 hi | 1 lo) of k-step ks -> ring slot ks mod R
 AE_DEV void actor_ring_fill_one(const ActorParamsH &H, uint4 *ring, int ks, int f) {
   const unsigned voff = (threadIdx.x & 63u) * 16u;
-  const unsigned base = (unsigned)(uintptr_t)ring + (unsigned)((ks & (ACTOR_RING_SLOTS - 1)) * 16 * 64 * 16);
+  const unsigned base = (unsigned)(uintptr_t)ring + (unsigned)(actor_region(ks) * 16 * 64 * 16);
   const uint64_t a = (uint64_t)(uintptr_t)(((f & 1) ? H.W2L : H.W2H) + (ks * 8 + (f >> 1)) * 64);
   // wave-uniform by construction; readfirstlane tells the compiler so (the asm wants SGPR operands)
   const uint64_t au = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
@@ -274,8 +278,8 @@ AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int ks, int nw) 
     for (int f = wave; f < 16; f += nw) actor_ring_fill_one(H, ring, ks, f);
   }
 }
-AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {
-  static_for<0, ACTOR_RING_AHEAD>([&](auto KI) { constexpr int k = KI; actor_ring_fill(H, ring, k, nw); });
+AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // the resident k-steps and the first two streamed
+  static_for<0, ACTOR_KRES + 2>([&](auto KI) { constexpr int k = KI; actor_ring_fill(H, ring, k, nw); });
 }
 AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -384,25 +388,23 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     // ks from (ch, cl), read one k-step ago, each followed by one slice of the other work so that it issues while the
     // matrix pipe is busy (an MFMA holds the pipe for 8 issue slots and the wave issues in order: work placed behind a
     // block of MFMAs waits for all of them):
-    //   slots 0..15   one LDS read each of k-step ks + 1's fragments into (nh, nl),
-    //   slots 0..15   odd k-steps: half of the relu + hi / lo split of a pair of layer-1 values of the next row tile,
-    //   slots 16..22  every other slot one quarter of fill(ks + P) (scalar address arithmetic + one LDS DMA).
+    //   slots 1..7    every other slot one quarter of the ring refill (scalar address arithmetic + one LDS DMA),
+    //   slots 8..23   one LDS read each of k-step ks + 1's fragments into (nh, nl) and, on odd k-steps, half of the
+    //                 relu + hi / lo split of a pair of layer-1 values of the next row tile.
     auto kstep = [&](auto ODD, int ks, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT],
                      const f32x16 &a1n) {
       constexpr int u = ODD;
-      uint64_t fsrc = 0;     // operands of the fill quarter whose DMA goes out in the next slot
-      unsigned fdst = 0;
       ASEC_ADD(5);
-      if (nw == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ACTOR_RING_AHEAD - 2)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ASEC_ADD(2);   // counted vmcnt wait
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of the fill issued one k-step ago (k-step ks + 1)
+      ASEC_ADD(2);   // vmcnt wait
 #ifndef EXP_NOBARRIER
       __builtin_amdgcn_s_barrier();
 #endif
       asm volatile("" ::: "memory");
       ASEC_ADD(3);   // barrier
-      const half8 *slot = reinterpret_cast<const half8 *>(ring) + ((ks + 1) & (ACTOR_RING_SLOTS - 1)) * 16 * 64 + lane;
-      const int kf = (ks + ACTOR_RING_AHEAD) & 15;
+      const half8 *slot = reinterpret_cast<const half8 *>(ring) + actor_region((ks + 1) & 15) * 16 * 64 + lane;
+      const bool streamed = ks >= ACTOR_KRES;            // resident k-steps consume no ring slot: nothing to refill
+      const int kf = actor_next2(streamed ? ks : ACTOR_KRES);
       static_for<0, 3 * NT>([&](auto MI) {
         constexpr int m = MI;
         // order: pass (hi*hi, hi*lo, lo*hi) outermost, so consecutive MFMAs never share an accumulator
@@ -410,23 +412,27 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
         __builtin_amdgcn_sched_barrier(0);
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? cl[nt] : ch[nt], k3 == 1 ? bl[u] : bh[u], acc[nt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (m < 16) {
-          if constexpr (m % 2 == 0) nh[m / 2] = slot[m * 64];
-          else nl[m / 2] = slot[m * 64];
+        // slots 1, 3, 5, 7: one quarter each of the refill two stream positions ahead (early, so that it has most of a
+        // k-step to land before the head of the next one waits for it)
+        if constexpr (m < 8 && m % 2 == 1) {
+          constexpr int fi = m / 2;
+          if (streamed) {
+            if (nw == 4)
+              glds16(reinterpret_cast<const void *>(fill_src[fi] + (uint64_t)(unsigned)kf * (8u * 64u * 16u)), voff16,
+                     fill_dst[fi] + (unsigned)actor_region(kf) * (16u * 64u * 16u));
+            else if (m == 1)
+              actor_ring_fill(H, ring, kf, nw);
+          }
         }
-        if constexpr (u == 1 && m < 16) {   // value pair m / 2: (A) in the even slot, (B) in the odd one
-          if constexpr (m % 2 == 0) split2a(a1n, std::integral_constant<int, (m / 2) / 4>{}, std::integral_constant<int, (m / 2) % 4>{}, bh_n);
-          else split2b(std::integral_constant<int, (m / 2) / 4>{}, std::integral_constant<int, (m / 2) % 4>{}, bh_n, bl_n);
-        }
-        // fill(ks + P), one quarter per two slots: scalar address arithmetic in one, the LDS DMA in the next
-        if constexpr (m >= 15 && m < 23 && m % 2 == 1) {
-          constexpr int fi = (m - 15) / 2;
-          fsrc = fill_src[fi] + (uint64_t)(unsigned)kf * (8u * 64u * 16u);
-          fdst = fill_dst[fi] + (unsigned)(kf & (ACTOR_RING_SLOTS - 1)) * (16u * 64u * 16u);
-        }
-        if constexpr (m >= 16 && m < 24 && m % 2 == 0) {
-          if (nw == 4) glds16(reinterpret_cast<const void *>(fsrc), voff16, fdst);
-          else if (m == 16) actor_ring_fill(H, ring, kf, nw);
+        // slots 8..23: one LDS read each of k-step ks + 1's fragments; odd k-steps: half of the relu / split of a pair
+        if constexpr (m >= 8) {
+          constexpr int r = m - 8;
+          if constexpr (r % 2 == 0) nh[r / 2] = slot[r * 64];
+          else nl[r / 2] = slot[r * 64];
+          if constexpr (u == 1) {
+            if constexpr (r % 2 == 0) split2a(a1n, std::integral_constant<int, (r / 2) / 4>{}, std::integral_constant<int, (r / 2) % 4>{}, bh_n);
+            else split2b(std::integral_constant<int, (r / 2) / 4>{}, std::integral_constant<int, (r / 2) % 4>{}, bh_n, bl_n);
+          }
         }
       });
       __builtin_amdgcn_sched_barrier(0);
@@ -439,7 +445,7 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     if (t == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
-      const half8 *slot = reinterpret_cast<const half8 *>(ring) + lane;
+      const half8 *slot = reinterpret_cast<const half8 *>(ring) + lane;        // k-step 0: region 0
       static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah0[nt] = slot[(2 * nt) * 64]; al0[nt] = slot[(2 * nt + 1) * 64]; });
     }
     f32x16 a1n = {};
