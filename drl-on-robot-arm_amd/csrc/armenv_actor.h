@@ -100,9 +100,11 @@ AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, in
 //   the B operand of layer 2's k-pair {32 R + 8 b + c, 32 R + 8 b + 4 + c}: relu(register i) feeds the MFMAs directly and
 //   the A operand is fetched for that k (no repacking: W2P is indexed by k).
 //   Layer 2: per k-pair 8 MFMAs (4 neuron tiles x 2 env tiles) into 128 accumulators, two passes over the neuron tiles.
-//   The A operand (one 16-byte load per lane per k-pair) is prefetched AD k-pairs ahead into a register ring with
-//   explicit loads and counted waits: left to hipcc the loop waits with vmcnt(0) at its head, i.e. for the load issued
-//   one iteration earlier, and an iteration then lasts one L2 round trip (875 cycles against 512 of MFMA).
+//   The A operand (one 16-byte load per lane per k-pair) is prefetched three k-pairs ahead into a ring of four register
+//   sets inside a 16-k-pair unrolled body, where hipcc counts the loads in flight exactly; in a rolled per-k-pair loop it
+//   waits with vmcnt(0) at the loop head.  (Loads issued from inline asm with hand-counted waits were tried and dropped:
+//   nothing stops the compiler from copying or spilling a destination register between the load and the wait, and under
+//   the register pressure of the push kernels it did.)
 template <int IN>
 AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const float (&s)[IN], float (&out)[3]) {
   static_assert(IN + 1 <= 2 * ACTOR_NK, "augmented input does not fit ACTOR_NK k-pairs");
@@ -151,7 +153,6 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
   const float4 *w2 = A.W2P + l32;
   const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;     // staged beside the layer-1 table
   constexpr int AD = 4;
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll 1
   for (int part = 0; part < 2; ++part) {
     f32x16 acc[4][2];
@@ -159,14 +160,13 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
       constexpr int nt = NI;
       static_for<0, 16>([&](auto RI) { constexpr int r = RI; acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f; });
     });
-    f32x4 aring[AD];
-    auto load_a_async = [&](int kk, f32x4 &dst) {   // k-pair kk = 16 R + i, i = 4 b + c  ->  k = 32 R + 8 b + 4 half + c
+    float4 aring[AD];
+    auto load_a = [&](int kk) {   // k-pair kk = 16 R + i, i = 4 b + c  ->  k = 32 R + 8 b + 4 half + c
       const int kc = kk < ACTOR_HID / 2 ? kk : ACTOR_HID / 2 - 1;   // the tail's prefetches re-read the last pair
       const int k = 32 * (kc >> 4) + 8 * ((kc >> 2) & 3) + 4 * half + (kc & 3);
-      const float4 *src = w2 + (k * 2 + part) * 32;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+      return w2[(k * 2 + part) * 32];
     };
-    static_for<0, AD>([&](auto I) { constexpr int i = I; load_a_async(i, aring[i]); });
+    static_for<0, AD - 1>([&](auto I) { constexpr int i = I; aring[i] = load_a(i); });
     f32x16 a1A, a1B, nA, nB;
     layer1(0, a1A, a1B);
 #pragma unroll 1
@@ -174,22 +174,21 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
       static_for<0, 16>([&](auto I) {
         constexpr int i = I;
         const int kk = 16 * R + i;
+        // refill the register set k-pair kk - 1 used, three k-pairs ahead; inside this unrolled body hipcc counts the
+        // loads in flight exactly (vmcnt(2) before the use below), only the R loop's back edge drains the queue
+        aring[(i + AD - 1) % AD] = load_a(kk + AD - 1);
         const float hA = relu(a1A[i]), hB = relu(a1B[i]);
-        // the load of k-pair kk is the oldest of the AD in flight
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(aring[i % AD]) : "n"(AD - 1) : "memory");
-        const float av[4] = {aring[i % AD][0], aring[i % AD][1], aring[i % AD][2], aring[i % AD][3]};
+        const float av[4] = {aring[i % AD].x, aring[i % AD].y, aring[i % AD].z, aring[i % AD].w};
         static_for<0, 4>([&](auto NI) {
           constexpr int nt = NI;
           acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hA, acc[nt][0], 0, 0, 0);
           acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nt], hB, acc[nt][1], 0, 0, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
-        load_a_async(kk + AD, aring[i % AD]);      // this register set is free again
         if constexpr (i == 8) layer1(R + 1, nA, nB);   // next row tile's layer 1 goes into the matrix pipe mid-way
       });
       a1A = nA; a1B = nB;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's prefetches
     // layer 2 bias + relu, layer 3 partial sums over the 64 neurons this lane holds per env tile in this pass
     static_for<0, 4>([&](auto NI) {
       constexpr int nt = NI;

@@ -47,7 +47,10 @@ template <typename T> struct EnvParams {
 // The rollout's next action, loaded while the current step runs.  The load goes STRAIGHT INTO ACCUMULATION REGISTERS from
 // inline asm and is waited for explicitly after the IK: as an ordinary load hipcc parks the three values in AGPRs to
 // relieve the IK's VGPR pressure, which needs the data -- so it waited (vmcnt(0)) a few hundred instructions after issuing
-// the load, i.e. for most of an HBM round trip, every step (SQ_WAIT_ANY 15 % of the wave's cycles).
+// the load, i.e. for most of an HBM round trip, every step.
+// Hazard of the pattern: the compiler believes the registers are defined at prefetch_issue; should it ever copy or spill
+// them before prefetch_settle it would copy stale data.  They are AGPRs used by nothing else, which it has no reason to
+// touch; the bit-for-bit rollout == step tests (reach / push / pick, f64 / f32) are the guard.
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 AE_DEV void prefetch_issue(const float *src, f32x3 &dst) {
   asm volatile("global_load_dwordx3 %0, %1, off" : "=a"(dst) : "v"(src) : "memory");

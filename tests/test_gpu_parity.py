@@ -932,6 +932,46 @@ def test_actor_f16x3_within_tolerance_of_reference(envs, O):
     e.close(); ref.close()
 
 
+@pytest.mark.parametrize("n", [64, 320, 448, 1024 + 192])
+def test_actor_f16x3_ragged_workgroups(envs, n):
+    """The f16x3 actor is a 4-wave workgroup phase (W2 through an LDS ring filled cooperatively): workgroups with 1, 2 or 3
+    live waves (num_envs not a multiple of 256) take the slow fill path and must give the same trajectory as the
+    per-wave exact-f32 actor."""
+    g, sd = _golden_actor()
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    a, b = _mk(envs, n, seed=33, max_steps=15), _mk(envs, n, seed=33, max_steps=15)
+    a.set_policy("actor_f16x3", action_bound=0.7, noise_sigma=0.2, noise_clip=0.7, actor_state_dict=tsd)
+    b.set_policy("actor", action_bound=0.7, noise_sigma=0.2, noise_clip=0.7, actor_state_dict=tsd)
+    a.reset(); b.reset()
+    oa, ob = a.rollout(24, None, want_actions=True), b.rollout(24, None, want_actions=True)
+    assert float((oa["actions"] - ob["actions"]).abs().max()) < 2e-5
+    assert torch.equal(oa["done"], ob["done"]) and float((oa["obs"] - ob["obs"]).abs().max()) < 1e-5
+    assert int(oa["done"].sum()) >= n                       # episodes ended and were reset inside the launch
+    a.close(); b.close()
+
+
+def test_fused_actor_nine_inputs_push(envs, O):
+    """obs_dim 9 (push / pick): both fused actor variants against the oracle's actor on the observations they saw."""
+    rng = np.random.default_rng(82)
+    sd = {"fc1.weight": rng.normal(0, 0.5, (256, 9)), "fc1.bias": rng.normal(0, 0.3, 256),
+          "fc2.weight": rng.normal(0, 0.09, (256, 256)), "fc2.bias": rng.normal(0, 0.2, 256),
+          "fc3.weight": rng.normal(0, 0.12, (3, 256)), "fc3.bias": rng.normal(0, 0.1, 3)}
+    sd = {k: v.astype(np.float32) for k, v in sd.items()}
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    n = 320
+    for kind in ("actor", "actor_f16x3"):
+        e = envs.BatchedPushEnv(n, device=DEV, seed=6, max_steps=30)
+        e.set_policy(kind, action_bound=0.4, noise_sigma=0.0, noise_clip=1e9, actor_state_dict=tsd)
+        obs0 = e.reset().clone()
+        out = e.rollout(12, None, want_actions=True)
+        seen = torch.cat([obs0[None], out["obs"][:-1]])          # the observation each action was computed from
+        ref = O.actor_forward(sd, _np(seen).reshape(-1, 9), 0.4).reshape(12, n, 3)
+        assert np.abs(_np(out["actions"]) - ref).max() < 1e-5, kind
+        st = rng.uniform(-1, 1, (777, 9)).astype(np.float32)
+        assert np.abs(_np(e.actor_forward(torch.from_numpy(st))) - O.actor_forward(sd, st, 0.4)).max() < 1e-5, kind
+        e.close()
+
+
 def test_actor_forward_asymmetric_weights(envs, O):
     """Transpose-detecting check of the MFMA operand/accumulator maps: random, non-symmetric weights with a
     distinct scale per layer, and biases that make about half the units fire."""
