@@ -69,6 +69,31 @@ def cpu_baseline(precision, seconds=12.0):
             "pybullet": pyb}
 
 
+
+def step_api_graph(env, run, n, k2, dev):
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        run(4)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run(50)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(k2 // 50):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    w3 = time.perf_counter() - t0
+    k3 = (k2 // 50) * 50
+    return {"value": n * k3 / w3, "unit": "env-steps/s", "steps": k3, "steps_per_graph": 50,
+            "avg_launch_us": e0.elapsed_time(e1) * 1e3 / k3}
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,28 +212,8 @@ def main():
         step_api = {"value": n * k2 / w2, "unit": "env-steps/s", "steps": k2, "avg_launch_us": g2 * 1e3 / k2,
                     "kernel": env.kernel_name}
         # the same launches replayed from a hipGraph (50 armenv_step calls per graph): host launch cost removed
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            run(4)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            run(50)
-        for _ in range(2):
-            graph.replay()
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(k2 // 50):
-            graph.replay()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        w3 = time.perf_counter() - t0
-        k3 = (k2 // 50) * 50
-        step_api["hipgraph"] = {"value": n * k3 / w3, "unit": "env-steps/s", "steps": k3, "steps_per_graph": 50,
-                                "avg_launch_us": e0.elapsed_time(e1) * 1e3 / k3}
+        if k2 >= 50:
+            step_api["hipgraph"] = step_api_graph(env, run, n, k2, dev)
         args.mode = "rollout"
 
     if rank == 0:
