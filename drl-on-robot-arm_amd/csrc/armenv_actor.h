@@ -22,30 +22,6 @@ namespace armenv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Optional cycle attribution of the workgroup actor (make actor_timeline; csrc/exp/run_actor_timeline.py): s_memtime deltas per
-// section, summed over waves by lane 0.  Off in the product build.
-#ifdef ARMENV_ACTOR_TIMELINE
-static __device__ unsigned long long g_actor_sections[16];
-#define ASEC_T0()                                  \
-  unsigned long long asec_acc[9] = {0};            \
-  unsigned long long asec_t = clock64()
-#define ASEC_ADD(k)                                \
-  do {                                             \
-    const unsigned long long now_ = clock64();     \
-    asec_acc[k] += now_ - asec_t;                  \
-    asec_t = now_;                                 \
-  } while (0)
-#define ASEC_FLUSH()                                                                              \
-  do {                                                                                            \
-    if ((threadIdx.x & 63) == 0)                                                                  \
-      for (int k_ = 0; k_ < 9; ++k_) atomicAdd(&g_actor_sections[k_], asec_acc[k_]);              \
-  } while (0)
-#else
-#define ASEC_T0()
-#define ASEC_ADD(k)
-#define ASEC_FLUSH()
-#endif
-
 constexpr int ACTOR_HID = 256;
 
 struct ActorParams {
@@ -308,11 +284,9 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       fill_dst[fi] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)ring + (unsigned)(f * 1024)));
     });
   }
-  ASEC_T0();
   // everything this wave has in flight (ring slots from the previous call's tail or actor_ring_init, and whatever the
   // env step left behind) has landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  ASEC_ADD(0);   // entry wait
   // The two env column tiles of the wave (envs 0..31 and 32..63) are processed one after the other: 128 accumulator
   // registers instead of 256 (the full set plus the operands does not fit without spills into the k-loop, and scratch
   // traffic inside the loop would also break the vmcnt accounting of the ring).  W2 streams through the ring twice.
@@ -393,14 +367,9 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     auto kstep = [&](auto ODD, int ks, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT],
                      const f32x16 &a1n) {
       constexpr int u = ODD;
-      ASEC_ADD(5);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of the fill issued one k-step ago (k-step ks + 1)
-      ASEC_ADD(2);   // vmcnt wait
-#ifndef EXP_NOBARRIER
       __builtin_amdgcn_s_barrier();
-#endif
       asm volatile("" ::: "memory");
-      ASEC_ADD(3);   // barrier
       const half8 *slot = reinterpret_cast<const half8 *>(ring) + actor_region((ks + 1) & 15) * 16 * 64 + lane;
       const bool streamed = ks >= ACTOR_KRES;            // resident k-steps consume no ring slot: nothing to refill
       const int kf = actor_next2(streamed ? ks : ACTOR_KRES);
@@ -440,7 +409,6 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     // k-step 0 of this pass.  First pass: every wave's share of it has landed after the vmcnt(0) above and this barrier;
     // second pass: it was made visible by the last k-step of the first pass (its own read there is dropped so that no
     // A fragments stay live across the pass epilogue).
-    ASEC_ADD(6);     // pass prologue: operands of layer 1, bias init, first layer-1 tile + split
     if (t == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
@@ -448,19 +416,13 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah0[nt] = slot[(2 * nt) * 64]; al0[nt] = slot[(2 * nt + 1) * 64]; });
     }
     f32x16 a1n = {};
-#ifdef EXP_RLOOP
-#pragma unroll 1
-    for (int R = 0; R < EXP_RLOOP; ++R) {
-#else
 #pragma unroll 1
     for (int R = 0; R < 8; ++R) {
-#endif
       kstep(std::integral_constant<int, 0>{}, 2 * R, ah0, al0, ah1, al1, a1n);
       a1n = layer1(R + 1);     // layer 1 of row tile R + 1 goes into the matrix pipe behind the 24 MFMAs
       kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n);
       bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
     }
-    ASEC_ADD(5);
     // layer 2 bias + relu and layer 3 over the 128 neurons this lane holds for its env column (the other 128 are in
     // lane ^ 32)
     float p[3] = {0.f, 0.f, 0.f};
@@ -491,11 +453,8 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       const float tot = p[o] + __shfl_xor(p[o], 32);         // lane e holds env e: tile e >> 5, column e & 31
       z[o] = (half == t) ? tot : z[o];
     });
-    ASEC_ADD(7);     // pass epilogue: relu, layer 3, exchange
   }
   static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
-  ASEC_ADD(8);       // tanh
-  ASEC_FLUSH();
 }
 
 }  // namespace armenv

@@ -35,16 +35,3 @@ int armenv_dbg_sections(unsigned long long out[8], int reset) {
 }
 #endif
 }
-
-#ifdef ARMENV_ACTOR_TIMELINE
-extern "C" {
-int armenv_dbg_actor_sections(unsigned long long out[16], int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(armenv::g_actor_sections), 16 * sizeof(unsigned long long));
-  if (reset) {
-    unsigned long long z[16] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(armenv::g_actor_sections), z, sizeof z);
-  }
-  return rc;
-}
-}
-#endif
