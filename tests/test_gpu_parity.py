@@ -880,6 +880,50 @@ def test_rlpickenv_compat_surface(envs):
     env.close()
 
 
+@pytest.mark.parametrize("task", ["push", "pick"])
+@pytest.mark.parametrize("robot,fk_path", [("kuka", 1), ("diana", 0)])
+def test_cube_tasks_on_other_chain_paths(envs, O, task, robot, fk_path):
+    """Push / pick lanes instantiated for the generic-chain FK path and for the Diana table (a reachable Diana set-up as
+    in test_step_teacher_forced_f64): teacher-forced steps against the oracle, and rollout == step launches bit for bit."""
+    n, T = 192, 10
+    rng = np.random.default_rng(95)
+    ch = O.make_chain(robot)
+    cfg = O.default_config(task)
+    over = {}
+    if robot == "diana":
+        cfg.target_quat[:] = [1.0, 0.0, 0.0, 0.0]
+        cfg.q_init[:] = [0.0, 0.5, 0.0, 1.6, 0.0, -1.0, 0.0]
+        p_init, _ = O.fk(ch, cfg.q_init[:])
+        lo = (p_init[0] - 0.25).tolist(); hi = (p_init[0] + 0.25).tolist()
+        cfg.box_lo[:] = lo; cfg.box_hi[:] = hi; cfg.goal_lo[:] = lo; cfg.goal_hi[:] = hi
+        over = dict(target_quat=list(cfg.target_quat), q_init=list(cfg.q_init), box_lo=lo, box_hi=hi, goal_lo=lo, goal_hi=hi)
+    Env = envs.BatchedPushEnv if task == "push" else envs.BatchedPickEnv
+    State, reset, step = (O.PushState, O.push_reset, O.push_step) if task == "push" else (O.PickState, O.pick_reset, O.pick_step)
+    mk = lambda **kw: Env(n, device=DEV, seed=9, robot=robot, fk_path=fk_path, **over, **kw)
+    e = mk(auto_reset=False)
+    assert e.kernel_name == f"{task}_step<f64,{'generic' if fk_path == 1 else robot}>"
+    st = State(n)
+    reset(ch, cfg, st, seed=9)
+    e.reset()
+    for t in range(T):
+        a = rng.normal(0.0, 0.3, (n, 3)).astype(np.float32)
+        e.set_state(q=st.q, aux=st.aux, step=st.step, ep_return=st.ep_return)
+        obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV))
+        obs = _np(obs).copy()
+        obs_r, rew_r, done_r, succ_r, iters = step(ch, cfg, st, a)
+        ok = (np.abs(_np(e.get_state()["q"]) - st.q).max(1) < 1e-6) & (iters < 20)
+        assert ok.mean() > 0.97 and np.abs(obs - obs_r)[ok].max() < 1e-6, (t, ok.mean())
+    e.close()
+    a_env, b_env = mk(), mk()
+    a_env.reset(); b_env.reset()
+    acts = torch.from_numpy(rng.normal(0.0, 0.3, (T, n, 3)).astype(np.float32)).to(DEV)
+    out = a_env.rollout(T, acts)
+    for t in range(T):
+        o, r, d, su = b_env.step(acts[t])
+        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["done"][t], d)
+    a_env.close(); b_env.close()
+
+
 # ------------------------------------------------------------------------------ fused TD3 actor (A1, config 3)
 
 def _golden_actor():
