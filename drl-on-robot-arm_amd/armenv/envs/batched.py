@@ -268,6 +268,18 @@ class BatchedReachEnv(BatchedArmEnv):
         self.observation_space = Box(low=lo, high=hi)                                 # rl_reach_env.py:93-96
 
 
+def diana_cam_reach_kinematics():
+    """Keyword arguments that give ``BatchedReachEnv`` the kinematic set-up of the reference's Diana S1 environment
+    (/root/reference/envs/diana_cam_reach.py): DianaS1_robot.urdf with the base yawed by pi (:201-204), identity target
+    orientation (:156-157), workspace / object box shifted by +0.1 in x (:102-108), dv = 0.005 (:266) and NO Cartesian clip
+    of the IK target (:270-274).  Only the kinematics: that environment's camera observation (:355-361) and its
+    0 / 1 / -0.1 reward (:318-333) are outside this build's scope, the reach reward and 6-float observation apply."""
+    import math
+    big = 1.0e9
+    return dict(chain=builtin_chain("diana").with_base(rpy=(0.0, 0.0, math.pi)), target_quat=[0.0, 0.0, 0.0, 1.0], dv=0.005,
+                goal_lo=[0.3, -0.3, 0.0], goal_hi=[0.8, 0.3, 0.55], box_lo=[-big] * 3, box_hi=[big] * 3)
+
+
 class BatchedPushEnv(BatchedArmEnv):
     """N x RLPushEnv (/root/reference/envs/rl_push_env.py): arm pipeline exact (dv 0.08, z in [0, 0.1]); the cube
     follows a simplified sphere-vs-box push-out model instead of Bullet's rigid-body step (DESIGN.md section 4);

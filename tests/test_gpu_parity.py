@@ -880,6 +880,35 @@ def test_rlpickenv_compat_surface(envs):
     env.close()
 
 
+def test_diana_cam_reach_kinematics_preset(envs, O):
+    """The Diana S1 set-up of envs/diana_cam_reach.py (yawed base, identity target orientation, dv 0.005, unclipped IK
+    target) through BatchedReachEnv: a yawed base takes the generic FK path; steps match the oracle given the same
+    constants; and the first reset puts the tool where SURVEY.md derives it from the URDF."""
+    kw = envs.diana_cam_reach_kinematics()
+    n = 512
+    e = envs.BatchedReachEnv(n, device=DEV, seed=2, auto_reset=False, **kw)
+    assert e.kernel_name == "reach_step<f64,generic>"
+    ch = O.make_chain("diana", base_rpy=(0.0, 0.0, math.pi))
+    cfg = O.default_config()
+    cfg.target_quat[:] = kw["target_quat"]; cfg.dv = kw["dv"]
+    cfg.goal_lo[:] = kw["goal_lo"]; cfg.goal_hi[:] = kw["goal_hi"]; cfg.box_lo[:] = kw["box_lo"]; cfg.box_hi[:] = kw["box_hi"]
+    st = O.ReachState(n)
+    obs_r = O.reach_reset(ch, cfg, st, seed=2)
+    obs = _np(e.reset())
+    assert np.abs(obs - obs_r).max() < 1e-6
+    assert np.abs(obs[0, :3] - np.float32([0.591001, -0.1541, 0.421794])).max() < 2e-6      # SURVEY.md section 8c, G1 (derived)
+    rng = np.random.default_rng(96)
+    for t in range(20):
+        a = rng.normal(0.0, 0.5, (n, 3)).astype(np.float32)
+        e.set_state(q=st.q, goal=st.goal, step=st.step, ep_return=st.ep_return)
+        o, r, d, su = e.step(torch.from_numpy(a).to(DEV))
+        o = _np(o).copy()
+        o_r, r_r, d_r, s_r, iters = O.reach_step(ch, cfg, st, a)
+        ok = (np.abs(_np(e.get_state()["q"]) - st.q).max(1) < 1e-6) & (iters < 20)
+        assert ok.mean() > 0.97 and np.abs(o - o_r)[ok].max() < 1e-6, (t, ok.mean())
+    e.close()
+
+
 @pytest.mark.parametrize("task", ["push", "pick"])
 @pytest.mark.parametrize("robot,fk_path", [("kuka", 1), ("diana", 0)])
 def test_cube_tasks_on_other_chain_paths(envs, O, task, robot, fk_path):
