@@ -10,7 +10,7 @@
 // the f16 variant, the hi / lo split) separates the two layers.
 // Two variants:
 //   actor_forward_wave      exact f32: v_mfma_f32_32x32x2_f32 for both layers; the A operand of layer 2 streams from an
-//                           L2-resident packed copy of W2 through a register ring with counted waits; per wave, no barriers.
+//                           L2-resident packed copy of W2 through a ring of four register sets; per wave, no barriers.
 //   actor_forward_wg_f16x3  f32 emulated by three f16 MFMA passes (hi*hi + hi*lo + lo*hi); a workgroup phase with the W2
 //                           fragments shared through an LDS ring filled by direct-to-LDS loads.
 // One wave per SIMD (the env step needs the whole register file): an MFMA holds the matrix pipe for 8 / 16 issue slots and
