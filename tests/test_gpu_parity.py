@@ -9,6 +9,7 @@ Tolerances (north_star: joint positions and reward within 1e-4 of the reference)
   f32 engine vs f64 oracle   one env step 1e-4 rad / 1e-4 reward (the stated tolerance)
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1388,3 +1389,28 @@ def test_device_summary_matches_host_reduction(envs, O, kuka):
     sp = pe.summary()
     assert abs(float(sp["mean_distance"]) - np.linalg.norm(aux[:, :3] - aux[:, 3:6], axis=1).mean()) < 1e-12
     pe.close()
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the contract's keys (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+    higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline + cpu_baseline)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "120", "--warmup", "5"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 120 and d["warmup"] == 5 and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
+    assert abs(d["value"] - 65536 * 120 / (d["ms_per_step"] * 120 / 1e3)) / d["value"] < 1e-6
+    ro, cb = d["roofline"], d["cpu_baseline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert d["value"] > 1e9 and d["nonfinite_states"] == 0
