@@ -52,7 +52,7 @@ enum { ARMENV_FK_AUTO = 0, ARMENV_FK_GENERIC = 1 };
 enum {
   ARMENV_POLICY_EXTERNAL = 0,
   ARMENV_POLICY_RANDOM = 1,
-  ARMENV_POLICY_ACTOR = 2,        /* TD3 actor, exact f32 (layer 2 on the f32-input MFMA) */
+  ARMENV_POLICY_ACTOR = 2,        /* TD3 actor, exact f32 (layers 1 and 2 on the f32-input MFMA) */
   ARMENV_POLICY_ACTOR_F16X3 = 3   /* same actor, layer 2 on the f16 MFMA with 3-pass hi/lo operand splitting (~1e-6) */
 };
 
@@ -218,8 +218,8 @@ int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const fl
                       float action_bound, float noise_sigma, float noise_clip, void *stream);
 
 /* The installed actor alone (TD3_MLP.take_action without noise, /root/reference/algo/TD3/TD3_mlp.py:82-97):
- * states f32 [n][obs_dim] -> actions f32 [n][3], f32 arithmetic, layer 2 on the f32 MFMA.  Needs a prior
- * armenv_set_policy(ARMENV_POLICY_ACTOR, ...). */
+ * states f32 [n][obs_dim] -> actions f32 [n][3]; both layers on the MFMA, exact f32 or the f16x3 emulation according to
+ * the installed policy.  Needs a prior armenv_set_policy(ARMENV_POLICY_ACTOR | ARMENV_POLICY_ACTOR_F16X3, ...). */
 int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, void *stream);
 
 /* ---- trajectory store + HER-"future" sampler (consumer of the rollout buffers; replaces the per-sample Python loops of
