@@ -776,9 +776,9 @@ def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka):
     """Free-running pick episodes with auto-reset (time-outs at 25 steps; scripted envs finish with +100) against
     the oracle, and the rollout kernel against step launches bit for bit.  The random envs take small steps (sigma 0.1)
     so that they stay in the well-conditioned middle of the workspace: with the full exploration noise some wander to
-    the top of the 0.807 m box within 15 steps, where the IK runs into its 20-iteration cap and the oracle's primal
-    solve and the dual LDL^T here drift apart (the oracle's own two solve forms do the same, see
-    test_pick_step_teacher_forced for how that case is bounded)."""
+    the top of the 0.807 m box within 15 steps, where the IK runs into its 20-iteration cap: twenty damped updates
+    through a near-singular system amplify last-bit differences (the oracle's own two solve forms part ways there
+    too; profiles/r01_soak_vs_oracle.txt), see test_pick_step_teacher_forced for how that case is bounded."""
     n, T = 256, 80
     rng = np.random.default_rng(91)
     cfg = O.default_config("pick"); cfg.max_steps = 24
