@@ -21,6 +21,7 @@ reference's importable Python (config, algo.TD3) -- never reference source text.
                                (algo/TD3/TD3_mlp.py:114-161), produced by importing the reference
   G7 push_reward_truth.json    (cube, target, d_last, step_counter) -> (reward, done, is_success) of
                                envs/rl_push_env.py:387-432 with its float32 / float64 mix
+  G10 config_fields.json       names and literal defaults of config.DefaultConfig (config.py:29-80)
   G9 py_random_{push,pick}_seed0.json  cube / target placements of successive resets (5 steps apart), produced by
                                EXECUTING the reference's own rejection-sampling loop (envs/rl_push_env.py:195-214,
                                envs/rl_pick_env.py:190-208; extracted from the module's AST because the module itself
@@ -143,6 +144,21 @@ def g9_py_random_placements():
         json.dump({"seed": 0, "steps_between_resets": 5, "placements": placements,
                    "source": f"the rejection-sampling loop of {fname} executed under random.seed(0)"},
                   open(os.path.join(OUT, f"py_random_{task}_seed0.json"), "w"), indent=1)
+
+
+def g10_config_fields():
+    """field names and literal default values of the reference's DefaultConfig (config.py:29-80)"""
+    tree = ast.parse(open(os.path.join(REF, "config.py")).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef))
+    fields = {}
+    for st in cls.body:
+        if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name):
+            try:
+                fields[st.targets[0].id] = ast.literal_eval(st.value)
+            except Exception:
+                fields[st.targets[0].id] = None          # computed default (device)
+    json.dump({"fields": fields, "source": "config.py DefaultConfig class attributes"},
+              open(os.path.join(OUT, "config_fields.json"), "w"), indent=1)
 
 
 def g5_reward_truth():
@@ -317,5 +333,5 @@ def g8_td3_train():
 
 
 if __name__ == "__main__":
-    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements()
+    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements(); g10_config_fields()
     print("fixtures written to", OUT)

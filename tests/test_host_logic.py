@@ -106,6 +106,17 @@ def test_box_and_opt_surface():
     delattr(type(opt), "not_a_field") if hasattr(type(opt), "not_a_field") else None
 
 
+def test_config_mirrors_every_reference_field():
+    """G10: `from armenv.config import opt` can stand in for the reference's `from config import opt`."""
+    from armenv.config import opt
+    g = golden_json("config_fields.json")["fields"]
+    assert len(g) >= 30
+    for k, v in g.items():
+        assert hasattr(opt, k), k
+        if v is not None:
+            assert getattr(opt, k) == v, (k, getattr(opt, k), v)
+
+
 def test_python_random_goal_stream_matches_golden():
     """G4: the N=1 compat class consumes Python's `random` exactly like the reference
     (7 draws per reset, 3 per step)."""
