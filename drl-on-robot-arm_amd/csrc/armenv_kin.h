@@ -147,6 +147,46 @@ template <typename T>
 AE_DEV void sincos_all(const T (&q)[NJ], T (&cq)[NJ], T (&sq)[NJ]) {
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; sincos_joint(q[j], sq[j], cq[j]); });
 }
+// f64: the seven joints in lockstep.  Same operations per joint as sincos_joint (bitwise the same results), but stage by
+// stage across the joints: every polynomial coefficient is materialised once instead of once per joint (a 64-bit
+// literal costs two s_mov_b32, and one wave per SIMD pays for every scalar instruction), the seven independent chains
+// hide the 6-cycle latency of a dependent v_fma_f64, and the library fallback for huge arguments sits behind ONE
+// wave-level branch instead of seven divergent regions.
+template <>
+AE_DEV void sincos_all<double>(const double (&q)[NJ], double (&cq)[NJ], double (&sq)[NJ]) {
+  double k[NJ], r[NJ], z[NJ], ps[NJ], pc[NJ];
+  bool big = false;
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; big = big || !(::fabs(q[j]) < 1.0e5); k[j] = ::rint(q[j] * 6.36619772367581382433e-01); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fma(-k[j], 1.57079632673412561417e+00, q[j]); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fma(-k[j], 6.07710050630396597660e-11, r[j]); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fma(-k[j], 2.02226624871116645580e-21, r[j]); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fma(-k[j], 8.47842766036889956997e-32, r[j]); z[j] = r[j] * r[j]; });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fma(1.58969099521155010221e-10, z[j], -2.50507602534068634195e-08); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fma(ps[j], z[j], 2.75573137070700676789e-06); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fma(ps[j], z[j], -1.98412698298579493134e-04); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fma(ps[j], z[j], 8.33333333332248946124e-03); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fma(ps[j], z[j], -1.66666666666666324348e-01); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fma(-1.13596475577881948265e-11, z[j], 2.08757232129817482790e-09); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fma(pc[j], z[j], -2.75573143513906633035e-07); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fma(pc[j], z[j], 2.48015872894767294178e-05); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fma(pc[j], z[j], -1.38888888888741095749e-03); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fma(pc[j], z[j], 4.16666666666666019037e-02); });
+  static_for<0, NJ>([&](auto JI) {
+    constexpr int j = JI;
+    const double sr = ::fma(r[j] * z[j], ps[j], r[j]);
+    const double cr = ::fma(z[j] * z[j], pc[j], ::fma(-0.5, z[j], 1.0));
+    const int n = (int)k[j] & 3;
+    const double s1 = (n & 1) ? cr : sr, c1 = (n & 1) ? sr : cr;
+    sq[j] = (n & 2) ? -s1 : s1;
+    cq[j] = ((n + 1) & 2) ? -c1 : c1;
+  });
+  if (__builtin_expect(__any(big), 0)) {   // |q| >= 1e5: Cody-Waite runs out of bits, take the library's Payne-Hanek path
+    static_for<0, NJ>([&](auto JI) {
+      constexpr int j = JI;
+      if (!(::fabs(q[j]) < 1.0e5)) ::sincos(q[j], &sq[j], &cq[j]);
+    });
+  }
+}
 
 // (c,s) <- (cos(q+d), sin(q+d)) from (cos q, sin q) for |d| <= pi/4 (the DLS scale-back bounds every update by
 // max_dtheta), with the fdlibm __kernel_sin/__kernel_cos minimax polynomials (< 1 ulp on that interval): no
