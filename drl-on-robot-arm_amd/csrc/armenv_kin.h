@@ -187,6 +187,40 @@ AE_DEV void sincos_all<double>(const double (&q)[NJ], double (&cq)[NJ], double (
     });
   }
 }
+// f32 engine: the same structure in single precision (three-part pi/2, fdlibm's k_sinf / k_cosf minimax coefficients):
+// within 2 ulp of sincosf on |q| < 100, which is far inside the f32 engine's 1e-4 step tolerance; larger arguments
+// take sincosf behind one wave-level branch.
+template <>
+AE_DEV void sincos_all<float>(const float (&q)[NJ], float (&cq)[NJ], float (&sq)[NJ]) {
+  float k[NJ], r[NJ], z[NJ], ps[NJ], pc[NJ];
+  bool big = false;
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; big = big || !(::fabsf(q[j]) < 100.0f); k[j] = ::rintf(q[j] * 0.636619772f); });
+  // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188216e-8 (Cody-Waite: the first two products are exact)
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fmaf(-k[j], 1.5703125f, q[j]); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fmaf(-k[j], 4.837512969970703125e-4f, r[j]); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fmaf(-k[j], 7.54978995489188216e-8f, r[j]); z[j] = r[j] * r[j]; });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fmaf(2.7183114939898219064e-6f, z[j], -1.98393348360966317347e-4f); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fmaf(ps[j], z[j], 8.3333293858894631756e-3f); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; ps[j] = ::fmaf(ps[j], z[j], -1.66666666416265235595e-1f); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fmaf(2.43904487962774090654e-5f, z[j], -1.38867637746099294692e-3f); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fmaf(pc[j], z[j], 4.16666233237390631894e-2f); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; pc[j] = ::fmaf(pc[j], z[j], -4.99999997251031003120e-1f); });
+  static_for<0, NJ>([&](auto JI) {
+    constexpr int j = JI;
+    const float sr = ::fmaf(r[j] * z[j], ps[j], r[j]);
+    const float cr = ::fmaf(z[j], pc[j], 1.0f);
+    const int n = (int)k[j] & 3;
+    const float s1 = (n & 1) ? cr : sr, c1 = (n & 1) ? sr : cr;
+    sq[j] = (n & 2) ? -s1 : s1;
+    cq[j] = ((n + 1) & 2) ? -c1 : c1;
+  });
+  if (__builtin_expect(__any(big), 0)) {
+    static_for<0, NJ>([&](auto JI) {
+      constexpr int j = JI;
+      if (!(::fabsf(q[j]) < 100.0f)) ::sincosf(q[j], &sq[j], &cq[j]);
+    });
+  }
+}
 
 // (c,s) <- (cos(q+d), sin(q+d)) from (cos q, sin q) for |d| <= pi/4 (the DLS scale-back bounds every update by
 // max_dtheta), with the fdlibm __kernel_sin/__kernel_cos minimax polynomials (< 1 ulp on that interval): no
