@@ -268,20 +268,52 @@ AE_DEV void quat_from_frame(const T (&W)[9], T (&q)[4]) {
   const T m00 = W[0], m10 = W[1], m20 = W[2], m01 = W[3], m11 = W[4], m21 = W[5], m02 = W[6], m12 = W[7], m22 = W[8];
   // Same case selection as getRotation (trace > 0, else the largest diagonal element), evaluated with selects
   // so that a wave whose lanes disagree on the case pays one sqrt and one divide, not four branches.
+  // Every candidate is computed first and the ternaries below choose between VALUES: written as nested expressions
+  // hipcc evaluates them lazily behind divergent branches (a dozen exec-mask regions per IK trip).
   const T trace = m00 + m11 + m22;
   const bool cw = trace > T(0);
-  const bool cz = !cw && (m00 < m11 ? (m11 < m22) : (m00 < m22));
-  const bool cy = !cw && !cz && (m00 < m11);
+  const bool cz = !cw & (m00 < m11 ? (m11 < m22) : (m00 < m22));
+  const bool cy = !cw & !cz & (m00 < m11);
   // cx otherwise
-  const T t = cw ? (trace + T(1)) : cz ? (m22 - m00 - m11 + T(1)) : cy ? (m11 - m22 - m00 + T(1)) : (m00 - m11 - m22 + T(1));
+  const T tw = trace + T(1), tz = m22 - m00 - m11 + T(1), ty = m11 - m22 - m00 + T(1), tx = m00 - m11 - m22 + T(1);
+  const T t = cw ? tw : (cz ? tz : (cy ? ty : tx));
   const T h = T(0.5) * fast_rsqrt<T>(t);   // 0.5 / sqrt(t)
   const T big = t * h;                       // sqrt(t) * 0.5
-  const T d21 = m21 - m12, d02 = m02 - m20, d10 = m10 - m01;
-  const T s10 = m10 + m01, s20 = m20 + m02, s21 = m21 + m12;
-  q[0] = cw ? d21 * h : cz ? s20 * h : cy ? s10 * h : big;
-  q[1] = cw ? d02 * h : cz ? s21 * h : cy ? big : s10 * h;
-  q[2] = cw ? d10 * h : cz ? big : cy ? s21 * h : s20 * h;
-  q[3] = cw ? big : cz ? d10 * h : cy ? d02 * h : d21 * h;
+  const T d21 = (m21 - m12) * h, d02 = (m02 - m20) * h, d10 = (m10 - m01) * h;
+  const T s10 = (m10 + m01) * h, s20 = (m20 + m02) * h, s21 = (m21 + m12) * h;
+  q[0] = cw ? d21 : (cz ? s20 : (cy ? s10 : big));
+  q[1] = cw ? d02 : (cz ? s21 : (cy ? big : s10));
+  q[2] = cw ? d10 : (cz ? big : (cy ? s21 : s20));
+  q[3] = cw ? big : (cz ? d10 : (cy ? d02 : d21));
+}
+
+// acos on [-1, 1] without branches: fdlibm's e_acos.c rational approximation R(z) = p(z) / q(z), evaluated ONCE on
+// z = x^2 (|x| < 0.5) or z = (1 - |x|) / 2 (otherwise), and the three result forms chosen with selects.  The library
+// routine is the same arithmetic behind three divergent regions; inside the IK trip that costs a wave the exec-mask
+// bookkeeping of every region on every trip and keeps the error chain out of the scheduler's reach.  ~1 ulp, and the
+// engine rounds the angle through float anyway (IKParams::angle_f32).
+AE_DEV double acos_branchfree(double x) {
+  const double ax = ::fabs(x);
+  const bool small = ax < 0.5;
+  const double z = small ? x * x : ::fma(-0.5, ax, 0.5);
+  double p = ::fma(3.47933107596021167570e-05, z, 7.91534994289814532176e-04);
+  p = ::fma(p, z, -4.00555345006794114027e-02);
+  p = ::fma(p, z, 2.01212532134862925881e-01);
+  p = ::fma(p, z, -3.25565818622400915405e-01);
+  p = ::fma(p, z, 1.66666666666666657415e-01);
+  p = p * z;
+  double q = ::fma(7.70381505559019352791e-02, z, -6.88283971605453293030e-01);
+  q = ::fma(q, z, 2.02094576023350569471e+00);
+  q = ::fma(q, z, -2.40339491173441421878e+00);
+  q = ::fma(q, z, 1.0);
+  const double R = p * fast_rcp<double>(q);
+  const double sr = z * fast_rsqrt<double>(small ? 1.0 : (z > 0.0 ? z : 1.0));   // sqrt(z) for the two outer forms
+  const double s = z > 0.0 ? sr : 0.0;
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+  const double inner = pio2_hi - (x - ::fma(-x, R, pio2_lo));              // |x| < 0.5
+  const double w = ::fma(R, s, s);                                          // s + s R
+  const double outer = x < 0.0 ? ::fma(-2.0, w - pio2_lo, 3.14159265358979311600e+00) : 2.0 * w;
+  return small ? inner : outer;
 }
 
 // IKTrajectoryHelper::computeIK orientation part: deltaQ = endQ * startQ^-1, angle = 2 acos(w) wrapped to
@@ -308,7 +340,7 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
     return;
   }
   const T wc = dw < T(-1) ? T(-1) : (dw > T(1) ? T(1) : dw);
-  T angle = T(2) * M::acos(wc);
+  T angle = T(2) * (T)acos_branchfree((double)wc);
   // axis = v / sqrt(1 - w^2), renormalised (btQuaternion::getAxis + btVector3::normalize): together v / |v|; the
   // degenerate branch (1 - w^2 < 10 eps -> axis (1,0,0)) is a select so that the whole function is one basic block
   // and its long dependent chain (acos, rsqrt) can be scheduled under the Jacobian / J J^T arithmetic
