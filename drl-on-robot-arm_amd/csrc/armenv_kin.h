@@ -280,7 +280,8 @@ AE_DEV void quat_from_frame(const T (&W)[9], T (&q)[4]) {
   const T h = T(0.5) * fast_rsqrt<T>(t);   // 0.5 / sqrt(t)
   const T big = t * h;                       // sqrt(t) * 0.5
   const T d21 = (m21 - m12) * h, d02 = (m02 - m20) * h, d10 = (m10 - m01) * h;
-  const T s10 = (m10 + m01) * h, s20 = (m20 + m02) * h, s21 = (m21 + m12) * h;
+  T s10 = (m10 + m01) * h, s20 = (m20 + m02) * h, s21 = (m21 + m12) * h;
+  asm("" : "+v"(s10), "+v"(s20), "+v"(s21));   // keep the three sums out of a `!cw` branch the compiler would build for them
   q[0] = cw ? d21 : (cz ? s20 : (cy ? s10 : big));
   q[1] = cw ? d02 : (cz ? s21 : (cy ? big : s10));
   q[2] = cw ? d10 : (cz ? big : (cy ? s21 : s20));
