@@ -19,7 +19,7 @@ template <typename T> struct EnvParams {
   uint32_t *episode;
   int32_t *last_len;
   uint8_t *last_success;
-  unsigned long long *counters;
+  unsigned long long *counters;   // [ceil(N / 64)][8]: one row per wave, summed by counters_sum_kernel on read
   T *aux;  // push: [7][N] = cube xyz, target xyz, d_last;  pick: [11][N] = the same + gripper state + hold offset xyz
   int64_t n;
   // task constants
@@ -43,6 +43,47 @@ template <typename T> struct EnvParams {
   IKParams<T> ik;
   ChainDev<T> chain;
 };
+
+// Launch-end flush of a lane's event counts into the handle's counters.  Every wave owns one 64-byte row
+// counters[i >> 6][8] = {episodes, successes, env steps (row 0 only), non-finite, IK updates}; the wave sums its lanes
+// and ONE lane does a plain read-modify-write of the row -- launches on a stream are serialised, nobody else touches it.
+// Why not atomicAdd on one address: same-address atomics execute one at a time at the memory side of the fabric,
+// 12 ns each from anywhere on the chip (csrc/exp/launch_probe.hip: 4096 waves x 1 atomic = 50 us; per-wave rows =
+// nothing), and the kernel cannot complete before they have.  One atomic per wave was 12 us of every 24 us
+// armenv_step launch at 65536 envs.
+// wave_sum: a count v of b significant bits costs b ballots + popcounts on the scalar unit, no cross-lane data moves.
+AE_DEV uint32_t wave_sum(uint32_t v) {
+  uint32_t s = 0;
+  for (int b = 0; b < 32 && __ballot((v >> b) != 0u) != 0ull; ++b) s += (uint32_t)__popcll(__ballot((v >> b) & 1u)) << b;
+  return s;
+}
+template <typename T>
+AE_DEV void flush_counts(const EnvParams<T> &P, int64_t i, uint32_t n_done, uint32_t n_succ, uint32_t n_bad, uint32_t n_upd) {
+  unsigned long long *row = P.counters + 8 * (i >> 6);
+  const uint32_t d = wave_sum(n_done), s = wave_sum(n_succ), b = wave_sum(n_bad), u = wave_sum(n_upd);
+  if ((threadIdx.x & 63) == 0) {   // lane 0 of a launched wave is always a live env (i < N is a prefix)
+    if (d) row[0] += d;
+    if (s) row[1] += s;
+    if (b) row[3] += b;
+    row[4] += u;
+  }
+}
+AE_DEV void flush_env_steps(unsigned long long *counters, int64_t i, unsigned long long env_steps) {
+  if (i == 0) counters[2] += env_steps;
+}
+
+// armenv_counters: totals[8] = column sums of the per-wave rows.
+static __global__ __launch_bounds__(256) void counters_sum_kernel(const unsigned long long *rows, int64_t n_rows,
+                                                                   unsigned long long *totals) {
+  __shared__ unsigned long long part[4][8];
+  const int col = threadIdx.x & 7;
+  unsigned long long acc = 0;
+  for (int64_t r = threadIdx.x >> 3; r < n_rows; r += 32) acc += rows[8 * r + col];
+  for (int o = 8; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) < 8) part[threadIdx.x >> 6][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < 8) totals[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
 
 // The rollout's next action, loaded while the current step runs.  The load goes STRAIGHT INTO ACCUMULATION REGISTERS from
 // inline asm and is waited for explicitly after the IK: as an ordinary load hipcc parks the three values in AGPRs to
@@ -108,7 +149,8 @@ __global__ void init_consts_kernel(EnvParams<T> P, T *out) {
 // Optional per-wave timeline (make timeline; csrc/exp/run_timeline.py): wall-clock stamps at kernel entry, after
 // the state loads, after the IK loop and at exit, plus IK update count and placement.  Off in the product build.
 #ifdef ARMENV_TIMELINE
-static __device__ unsigned long long *g_timeline;
+static __device__ unsigned long long *g_timeline;   // [16 launches][waves][8]
+static __device__ unsigned g_tl_launch;             // launch counter: read at wave entry, bumped by env 0 at its exit
 #define TL_STAMP(name) const unsigned long long name = wall_clock64()
 #else
 #define TL_STAMP(name)
@@ -242,17 +284,7 @@ template <class C, typename T> struct ReachLane {
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
-    if (n_done) atomicAdd(&P.counters[0], (unsigned long long)n_done);
-    if (n_succ) atomicAdd(&P.counters[1], (unsigned long long)n_succ);
-    if (n_bad) atomicAdd(&P.counters[3], (unsigned long long)n_bad);
-    // one add per wave for the IK-update total (wave reduction first)
-    if (__ballot(1) == ~0ull) {
-      unsigned u = n_upd;
-      for (int o = 32; o; o >>= 1) u += __shfl_xor(u, o);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters[4], (unsigned long long)u);
-    } else if (n_upd) {   // ragged last wave
-      atomicAdd(&P.counters[4], (unsigned long long)n_upd);
-    }
+    flush_counts(P, i, n_done, n_succ, n_bad, n_upd);
   }
 
   // RLReachEnv.step + _reward (rl_reach_env.py:219-319) with action a; writes row i of the caller's buffers.
@@ -449,10 +481,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
     }
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
-    if (n_done) atomicAdd(&P.counters[0], (unsigned long long)n_done);
-    if (n_succ) atomicAdd(&P.counters[1], (unsigned long long)n_succ);
-    if (n_bad) atomicAdd(&P.counters[3], (unsigned long long)n_bad);
-    if (n_upd) atomicAdd(&P.counters[4], (unsigned long long)n_upd);
+    flush_counts(P, i, n_done, n_succ, n_bad, n_upd);
   }
 
   // stepSimulation (:349), simplified: sphere (tool, radius r, centre p) vs axis-aligned box (cube, half-size h)
@@ -609,6 +638,9 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams<T> P, const ui
 template <class Lane, typename T>
 __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io) {
   TL_STAMP(tl0);
+#ifdef ARMENV_TIMELINE
+  const unsigned tl_launch = __hip_atomic_load(&g_tl_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   Lane L;
@@ -623,7 +655,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io
   (void)updates;
   TL_STAMP(tl2);
   L.store(P, i);
-  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)P.n);
+  flush_env_steps(P.counters, i, (unsigned long long)P.n);
 #ifdef ARMENV_TIMELINE
   {
     TL_STAMP(tl3);
@@ -631,11 +663,12 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io
     for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
     const unsigned long long dn = __ballot(L.n_done != 0);
     if ((threadIdx.x & 63) == 0 && g_timeline) {
-      unsigned long long *r = g_timeline + 8 * (i >> 6);
+      unsigned long long *r = g_timeline + 8 * ((int64_t)(tl_launch & 15) * (P.n >> 6) + (i >> 6));
       unsigned xcc, hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       r[0] = tl0; r[1] = tl1; r[2] = tl2; r[3] = tl3; r[4] = mx; r[5] = __popcll(dn); r[6] = xcc; r[7] = hw;
+      if (i == 0) __hip_atomic_fetch_add(&g_tl_launch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #endif
@@ -735,7 +768,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   }
   L.store(P, i);
   if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) actor_ring_drain();
-  if (i == 0) atomicAdd(&P.counters[2], (unsigned long long)n * (unsigned long long)steps);
+  flush_env_steps(P.counters, i, (unsigned long long)n * (unsigned long long)steps);
 }
 
 // p.getLinkState(body, 6)[4], [5]

@@ -149,14 +149,15 @@ AE_DEV void sincos_all(const T (&q)[NJ], T (&cq)[NJ], T (&sq)[NJ]) {
 }
 // f64: the seven joints in lockstep.  Same operations per joint as sincos_joint (bitwise the same results), but stage by
 // stage across the joints: every polynomial coefficient is materialised once instead of once per joint (a 64-bit
-// literal costs two s_mov_b32, and one wave per SIMD pays for every scalar instruction), the seven independent chains
-// hide the 6-cycle latency of a dependent v_fma_f64, and the library fallback for huge arguments sits behind ONE
-// wave-level branch instead of seven divergent regions.
+// literal costs two s_mov_b32, and one wave per SIMD pays for every scalar instruction) and the seven independent chains
+// hide the 6-cycle latency of a dependent v_fma_f64.  No library fallback for huge arguments: the fused reduction stays
+// exactly rounded while k = rint(2 q / pi) is an exact integer (|q| < 2^50), far beyond any joint angle a live env can
+// hold, and the Payne-Hanek path it replaces was 1 400 instructions of never-executed code per call site -- three sites
+// per kernel, sitting between the hot regions of a kernel whose instruction fetch starts cold at every launch.
 template <>
 AE_DEV void sincos_all<double>(const double (&q)[NJ], double (&cq)[NJ], double (&sq)[NJ]) {
   double k[NJ], r[NJ], z[NJ], ps[NJ], pc[NJ];
-  bool big = false;
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; big = big || !(::fabs(q[j]) < 1.0e5); k[j] = ::rint(q[j] * 6.36619772367581382433e-01); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; k[j] = ::rint(q[j] * 6.36619772367581382433e-01); });
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fma(-k[j], 1.57079632673412561417e+00, q[j]); });
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fma(-k[j], 6.07710050630396597660e-11, r[j]); });
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fma(-k[j], 2.02226624871116645580e-21, r[j]); });
@@ -180,21 +181,14 @@ AE_DEV void sincos_all<double>(const double (&q)[NJ], double (&cq)[NJ], double (
     sq[j] = (n & 2) ? -s1 : s1;
     cq[j] = ((n + 1) & 2) ? -c1 : c1;
   });
-  if (__builtin_expect(__any(big), 0)) {   // |q| >= 1e5: Cody-Waite runs out of bits, take the library's Payne-Hanek path
-    static_for<0, NJ>([&](auto JI) {
-      constexpr int j = JI;
-      if (!(::fabs(q[j]) < 1.0e5)) ::sincos(q[j], &sq[j], &cq[j]);
-    });
-  }
 }
 // f32 engine: the same structure in single precision (three-part pi/2, fdlibm's k_sinf / k_cosf minimax coefficients):
-// within 2 ulp of sincosf on |q| < 100, which is far inside the f32 engine's 1e-4 step tolerance; larger arguments
-// take sincosf behind one wave-level branch.
+// within 1 ulp of sincosf at 1 on |q| < 100 (7e-8 measured), far inside the f32 engine's 1e-4 step tolerance; accuracy
+// degrades gradually beyond (float k stays exact to 2^24).
 template <>
 AE_DEV void sincos_all<float>(const float (&q)[NJ], float (&cq)[NJ], float (&sq)[NJ]) {
   float k[NJ], r[NJ], z[NJ], ps[NJ], pc[NJ];
-  bool big = false;
-  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; big = big || !(::fabsf(q[j]) < 100.0f); k[j] = ::rintf(q[j] * 0.636619772f); });
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; k[j] = ::rintf(q[j] * 0.636619772f); });
   // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188216e-8 (Cody-Waite: the first two products are exact)
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fmaf(-k[j], 1.5703125f, q[j]); });
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; r[j] = ::fmaf(-k[j], 4.837512969970703125e-4f, r[j]); });
@@ -214,12 +208,6 @@ AE_DEV void sincos_all<float>(const float (&q)[NJ], float (&cq)[NJ], float (&sq)
     sq[j] = (n & 2) ? -s1 : s1;
     cq[j] = ((n + 1) & 2) ? -c1 : c1;
   });
-  if (__builtin_expect(__any(big), 0)) {
-    static_for<0, NJ>([&](auto JI) {
-      constexpr int j = JI;
-      if (!(::fabsf(q[j]) < 100.0f)) ::sincosf(q[j], &sq[j], &cq[j]);
-    });
-  }
 }
 
 // (c,s) <- (cos(q+d), sin(q+d)) from (cos q, sin q) for |d| <= pi/4 (the DLS scale-back bounds every update by
@@ -450,22 +438,6 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 //   for (i = 0; i < maxIter && currentDiff > residual; ++i) { currentDiff = |p(q) - tgt|; q += dls(q); }
 // Each trip of the loop below does exactly one FK; the trip that decides to stop leaves S = FK(q_final),
 // which is the post-step FK of _reward() (:271).  Returns the number of updates applied.
-// Per-section cycle accounting for the instrumented build (make timeline): s_memtime stamps around FK, orientation
-// error, DLS update and rotation advance, summed per wave into g_sections by lane 0.
-#ifdef ARMENV_TIMELINE
-static __device__ unsigned long long g_sections[8];
-#define SEC_T0() unsigned long long sec_t = clock64()
-#define SEC_ADD(k)                                                                         \
-  do {                                                                                     \
-    const unsigned long long now_ = clock64();                                             \
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sections[k], now_ - sec_t);                  \
-    sec_t = now_;                                                                          \
-  } while (0)
-#else
-#define SEC_T0()
-#define SEC_ADD(k)
-#endif
-
 // START_F32: the start position is rounded through float before the action is added (rl_pick_env.py:328 casts
 // getLinkState's tuple to np.float32; reach / push keep the f64 tuple).
 template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
@@ -477,15 +449,12 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
   T diff2_prev = T(1e60);
   int it = 0;
   T cq[NJ], sq[NJ];
-  SEC_T0();
   sincos_all<T>(q, cq, sq);
-  SEC_ADD(0);
   // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced
   // incrementally, otherwise cos/sin are recomputed from q
   const bool small_steps = P.max_dtheta <= T(0.7854);
   for (;; ++it) {
     fk<C, T>(ch, cq, sq, S);
-    SEC_ADD(1);
     if constexpr (FROM_ACTION) {
       if (it == 0) {
         if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
@@ -506,13 +475,10 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff2_prev > res2) : !(diff2 > res2));
     if (stop) break;
     T qc[4], eo[3], dth[NJ];
-    SEC_ADD(2);
     quat_from_frame<T>(S.W, qc);
     orientation_error<T>(P.tq, qc, P.angle_f32, eo);
     e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
-    SEC_ADD(3);
     dls_update<T>(S, e, P, dth);
-    SEC_ADD(4);
     static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
     if (small_steps) {
       static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
@@ -520,7 +486,6 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
       sincos_all<T>(q, cq, sq);
     }
     diff2_prev = diff2;
-    SEC_ADD(5);
   }
   if (P.clamp_limits) {
     static_for<0, NJ>([&](auto II) {

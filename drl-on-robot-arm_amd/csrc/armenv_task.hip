@@ -25,13 +25,5 @@ extern "C" {
 int armenv_dbg_set_timeline(unsigned long long *buf_dev) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf_dev, sizeof buf_dev);
 }
-int armenv_dbg_sections(unsigned long long out[8], int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(armenv::g_sections), 8 * sizeof(unsigned long long));
-  if (reset) {
-    unsigned long long z[8] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(armenv::g_sections), z, sizeof z);
-  }
-  return rc;
-}
 #endif
 }

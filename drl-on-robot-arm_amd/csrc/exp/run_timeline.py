@@ -6,10 +6,10 @@ from armenv import _lib as L
 L.LIB_PATH=os.path.join(ROOT,'libarmenv_tl.so')
 from armenv import envs
 prec=int(sys.argv[1]) if len(sys.argv)>1 else 64
-n=65536
+n=int(sys.argv[2]) if len(sys.argv)>2 else 65536
 e=envs.BatchedReachEnv(n, device='cuda:0', precision=prec)
 lib=L.load()
-tl=torch.zeros((n//64,8),dtype=torch.int64,device='cuda:0')
+tl=torch.zeros((16,n//64,8),dtype=torch.int64,device='cuda:0')
 lib.armenv_dbg_set_timeline.argtypes=[C.c_void_p]
 assert lib.armenv_dbg_set_timeline(C.c_void_p(tl.data_ptr()))==0
 g=torch.Generator(device='cuda:0'); g.manual_seed(0)
@@ -19,7 +19,7 @@ for k in range(30): e.step(acts[k%8])
 torch.cuda.synchronize()
 for k in range(3):
     e.step(acts[k%8]); torch.cuda.synchronize()
-    t=tl.cpu().numpy().astype(np.int64)
+    t=tl.cpu().numpy().astype(np.int64)[(30+k)%16]
     t0=t[:,0].min()
     st=(t[:,0]-t0)/100.0; ld=(t[:,1]-t[:,0])/100.0; lp=(t[:,2]-t[:,1])/100.0; fin=(t[:,3]-t[:,2])/100.0; end=(t[:,3]-t0)/100.0
     print(f"step {k}: kernel span {end.max():.2f} us | start: mean {st.mean():.2f} max {st.max():.2f} | load: mean {ld.mean():.2f} max {ld.max():.2f} | loop: mean {lp.mean():.2f} min {lp.min():.2f} max {lp.max():.2f} | epilogue mean {fin.mean():.2f} max {fin.max():.2f}")
@@ -31,15 +31,14 @@ for k in range(3):
     u,c=np.unique(key,return_counts=True); print("   distinct CUs used:",len(u)," waves/CU hist:",np.bincount(c))
     key2=key*10+simd; u2,c2=np.unique(key2,return_counts=True); print("   distinct SIMDs:",len(u2)," waves/SIMD hist:",np.bincount(c2))
 
-# per-section cycle shares of the IK (s_memtime deltas summed over waves): rollout of 50 steps
-lib.armenv_dbg_sections.argtypes=[C.POINTER(C.c_uint64*8), C.c_int]
-buf=(C.c_uint64*8)(); lib.armenv_dbg_sections(C.byref(buf),1)
-a=torch.stack([acts[k%8] for k in range(50)]).contiguous()
-e.rollout(50,a); torch.cuda.synchronize()
-lib.armenv_dbg_sections(C.byref(buf),1)
-v=np.array(list(buf),dtype=np.float64); names=['sincos_all','fk','target+residual','quat+orient_err','dls_update','q+=,rotate']
-tot=v[:6].sum()
-c=e.counters()
-print('sections (cycles per wave per step, share):')
-for nme,x in zip(names,v): print(f'   {nme:18s} {x/1024/50:9.0f}  {100*x/tot:5.1f}%')
-print('   total', tot/1024/50, 'cycles per wave-step')
+# back-to-back launches (no host sync): kernel k's last wave exit -> kernel k+1's first wave entry, on the shared 100 MHz clock
+torch.cuda.synchronize()
+base=30+3
+for k in range(12): e.step(acts[k%8])
+torch.cuda.synchronize()
+t=tl.cpu().numpy().astype(np.int64)
+rows=[t[(base+k)%16] for k in range(12)]
+print("back-to-back launches: [first entry -> last exit] span, gap to the next kernel's first entry, entry-to-entry period (us)")
+for k in range(11):
+    a,b=rows[k],rows[k+1]
+    print(f"   launch {k}: span {(a[:,3].max()-a[:,0].min())/100:.2f}  gap {(b[:,0].min()-a[:,3].max())/100:.2f}  period {(b[:,0].min()-a[:,0].min())/100:.2f}  start skew max {(a[:,0].max()-a[:,0].min())/100:.2f}  slowest wave {((a[:,3]-a[:,0]).max())/100:.2f} mean {((a[:,3]-a[:,0]).mean())/100:.2f}")
