@@ -106,6 +106,17 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   void *pool = nullptr;
   unsigned long long *counter_totals = nullptr;
   static constexpr int block = 256;   // four waves: one per SIMD of a CU; the f16x3 actor phase is a 4-wave workgroup
+  int cus = 256;
+  // Workgroup size of the env kernels that have no workgroup phase (step, rollout without a fused actor): the IK keeps
+  // one wave per SIMD, so a batch that does not fill the chip is launched as smaller workgroups -- the dispatcher then
+  // spreads its waves over all CUs (1 or 2 per CU) instead of packing four onto a quarter or half of them, and a wave
+  // that shares its CU's instruction fetch with fewer neighbours runs 5-10 % faster (65 536 envs: 9.9 us per step,
+  // 16 384: 9.0).
+  int lane_block() const {
+    const int64_t waves = (P.n + 63) / 64;
+    const int64_t per_cu = (waves + cus - 1) / cus;
+    return 64 * (int)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  }
   static constexpr int task = Lane::kTask;
   std::string kname;
 
@@ -116,6 +127,10 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   int init(const ArmEnvConfig &cfg) override {
     const int64_t n = cfg.num_envs;
     P.n = n;
+    {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
     // carve one allocation, 256-byte aligned sections
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
@@ -198,13 +213,16 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     return ARMENV_OK;
   }
   int step(const StepIO &io, hipStream_t s) override {
-    hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+    const int b = lane_block();
+    hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, io);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
   template <int POLICY>
   void launch_rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
-    hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol, steps,
+    constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
+    const int b = kActor ? block : lane_block();
+    hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, pol, steps,
                        actions, io0, actions_out);
   }
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {

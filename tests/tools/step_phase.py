@@ -1,0 +1,25 @@
+"""Per-step GPU time of armenv_step across an episode (65536 reach envs, the bench's action stream): which steps of the
+100-step episode are slow?  Events around every launch; the host launch cost (~8 us) hides behind the kernel."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "drl-on-robot-arm_amd"))
+from armenv.envs.batched import BatchedReachEnv
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+dev = torch.device("cuda:0")
+env = BatchedReachEnv(n, device=dev, precision=64, seed=1)
+g = torch.Generator(device=dev); g.manual_seed(0)
+ring = [(torch.randn((n, 3), device=dev, generator=g) * 0.686).clamp_(-0.7, 0.7) for _ in range(16)]
+env.reset()
+for i in range(100): env.step(ring[i % 16])
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(201)]
+c0 = env.counters()
+ev[0].record()
+for i in range(200):
+    env.step(ring[i % 16]); ev[i + 1].record()
+torch.cuda.synchronize()
+c1 = env.counters()
+dt = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(200)]
+print("mean us/launch", sum(dt) / 200, " IK updates/step", (c1["ik_updates"] - c0["ik_updates"]) / (200 * n))
+for r in range(0, 200, 10):
+    print(f"steps {r:3d}-{r+9:3d}: " + " ".join(f"{x:5.1f}" for x in dt[r:r + 10]))
