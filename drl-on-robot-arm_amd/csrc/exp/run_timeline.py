@@ -42,3 +42,23 @@ print("back-to-back launches: [first entry -> last exit] span, gap to the next k
 for k in range(11):
     a,b=rows[k],rows[k+1]
     print(f"   launch {k}: span {(a[:,3].max()-a[:,0].min())/100:.2f}  gap {(b[:,0].min()-a[:,3].max())/100:.2f}  period {(b[:,0].min()-a[:,0].min())/100:.2f}  start skew max {(a[:,0].max()-a[:,0].min())/100:.2f}  slowest wave {((a[:,3]-a[:,0]).max())/100:.2f} mean {((a[:,3]-a[:,0]).mean())/100:.2f}")
+
+# persistence of slow waves: are the waves that need extra IK trips the same ones launch after launch?
+warm=int(sys.argv[3]) if len(sys.argv)>3 else 0
+for k in range(warm): e.step(acts[k%8])
+torch.cuda.synchronize()
+tot=np.zeros(n//64); trips=[]
+for rnd in range(4):
+    for k in range(12): e.step(acts[k%8])
+    torch.cuda.synchronize()
+    t=tl.cpu().numpy().astype(np.int64)
+    # launch counter position is unknown after warm-up: use every ring slot once (12 of the 16 slots are fresh)
+    fresh=np.argsort(-t[:,:,0].min(axis=1))[:12]
+    for s_ in fresh:
+        tot+= (t[s_][:,3]-t[s_][:,0])/100.0; trips.append(t[s_][:,4].copy())
+trips=np.array(trips)   # [48 launches][waves]
+print(f"after {warm} more steps, 48 launches: in-kernel time per wave summed: mean {tot.mean():.1f} us, std {tot.std():.1f}, max {tot.max():.1f} (+{100*(tot.max()/tot.mean()-1):.1f} %), sum of per-launch maxima n/a")
+print("   wave-trips histogram over all wave-launches:", np.bincount(trips.ravel()))
+extra=(trips>3).sum(axis=0)
+print("   launches (of 48) in which a wave needed >3 trips: histogram over waves", np.bincount(extra))
+print("   mean trips per wave-launch", trips.mean(), " mean of per-launch max", trips.max(axis=1).mean())
