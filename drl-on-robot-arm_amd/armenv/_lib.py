@@ -11,7 +11,8 @@ FK_AUTO, FK_GENERIC = 0, 1
 POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR, POLICY_ACTOR_F16X3 = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libarmenv.so")
+# ARMENV_LIB: an alternative build of the same library (A/B timing of two kernel versions inside one GPU session)
+LIB_PATH = os.environ.get("ARMENV_LIB") or os.path.join(_HERE, "libarmenv.so")
 
 
 class ArmEnvError(RuntimeError):
