@@ -50,11 +50,12 @@ def cpu_baseline(precision, seconds=12.0):
     st = O.ReachState(n)
     O.reach_reset(chain, cfg, st, seed=0)
     rng = np.random.default_rng(0)
-    acts = [np.clip(rng.normal(0, 0.686, (n, 3)), -0.7, 0.7).astype(np.float32) for _ in range(4)]
-    O.reach_step_autoreset(chain, cfg, st, acts[0], seed=0, want_terminal=False)   # warm-up
+    # i.i.d. actions per step like the device pool (a short cycle of action arrays would pin the envs in a corner of the box)
+    A = np.clip(rng.standard_normal((256, n, 3), dtype=np.float32) * np.float32(0.686), -0.7, 0.7)
+    O.reach_step_autoreset(chain, cfg, st, A[0], seed=0, want_terminal=False)   # warm-up
     t0 = time.perf_counter(); k = 0
     while True:
-        O.reach_step_autoreset(chain, cfg, st, acts[k % 4], seed=0, want_terminal=False)
+        O.reach_step_autoreset(chain, cfg, st, A[k % 256], seed=0, want_terminal=False)
         k += 1
         dt = time.perf_counter() - t0
         if (dt >= seconds and k >= 3) or k >= 2000:
@@ -70,28 +71,40 @@ def cpu_baseline(precision, seconds=12.0):
 
 
 
-def step_api_graph(env, run, n, k2, dev):
+def step_api_graph(env, pool, next_actions, n, k2, dev):
+    """50 armenv_step launches captured in one hipGraph over a static [50, N, 3] action buffer; every replay is fed the
+    next 50 rows of the action pool by one device-to-device copy (39 MB, part of the timed region)."""
+    G = 50
+    gbuf = torch.empty((G,) + tuple(pool.shape[1:]), dtype=pool.dtype, device=dev)
+    gbuf.copy_(next_actions(G))
+
+    def run_g():
+        for j in range(G):
+            env.step(gbuf[j])
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        run(4)
+        for j in range(4):
+            env.step(gbuf[j])
     torch.cuda.current_stream(dev).wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        run(50)
+        run_g()
     for _ in range(2):
+        gbuf.copy_(next_actions(G))
         graph.replay()
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(k2 // 50):
+    for _ in range(k2 // G):
+        gbuf.copy_(next_actions(G))
         graph.replay()
     e1.record()
     torch.cuda.synchronize(dev)
     w3 = time.perf_counter() - t0
-    k3 = (k2 // 50) * 50
-    return {"value": n * k3 / w3, "unit": "env-steps/s", "steps": k3, "steps_per_graph": 50,
+    k3 = (k2 // G) * G
+    return {"value": n * k3 / w3, "unit": "env-steps/s", "steps": k3, "steps_per_graph": G,
             "avg_launch_us": e0.elapsed_time(e1) * 1e3 / k3}
 
 def main():
@@ -132,10 +145,15 @@ def main():
     Env = {"reach": envs.BatchedReachEnv, "push": envs.BatchedPushEnv, "pick": envs.BatchedPickEnv}[args.task]
     env = Env(n, device=dev, seed=0, env_id_offset=rank * n, precision=args.precision)
     gen = torch.Generator(device=dev); gen.manual_seed(1000 + rank)
+    # the random policy "pre-generated on device for 1 000 steps as [1000, N, 3] f32
+    # (786 MB)": i.i.d. across steps, so every env does a genuine random walk.  (A short ring of action tensors replayed
+    # in a cycle makes every env drift ballistically into a corner of the workspace box and sit there -- a different,
+    # slower workload: more lanes with 5+ IK trips per wave.)  Capped at 2 GiB for very large batches.
+    S = int(max(64, min(1000, (2 << 30) // (12 * n))))
     if args.task == "reach":      # run() exploration with a zero actor, main.py:116-117
-        ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous() for _ in range(16)]
+        pool = (torch.randn((S, n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7)
     else:                         # train_push_with_TD3 exploration, unclipped, main.py:457,484
-        ring = [(torch.randn((n, 3), device=dev, generator=gen) * 0.392).contiguous() for _ in range(16)]
+        pool = torch.randn((S, n, 3), device=dev, generator=gen) * 0.392
     if args.policy != "external":
         args.mode = "rollout"
         bound, sig = (0.7, 0.7 * 0.98) if args.task == "reach" else (0.4, 0.4 * 0.98)
@@ -151,22 +169,30 @@ def main():
     gather = ReturnGatherer(n, dev, world)
     env.reset()
     R = max(1, min(args.rollout_steps, args.steps))
-    if args.mode == "rollout":
-        acts = torch.stack([ring[i % 16] for i in range(R)]).contiguous()      # [R, N, 3] resident in HBM
-        bufs = {}
+    R = min(R, S)
+    bufs = {}
+    cursor = [0]     # next row of the action pool
+
+    def next_actions(r):
+        """r consecutive rows of the pool as a contiguous view (wraps to row 0 when fewer than r are left)"""
+        if cursor[0] + r > S:
+            cursor[0] = 0
+        a = pool[cursor[0]:cursor[0] + r]
+        cursor[0] += r
+        return a
 
     def run(k):
         """exactly k env steps of every env of this rank"""
         if args.mode == "step":
             for i in range(k):
-                env.step(ring[i % 16])
+                env.step(next_actions(1)[0])
                 if world > 1 and (i + 1) % args.gather_every == 0:
                     gather.launch(env.episode_stats()[0])
             return k
         done_steps, launches = 0, 0
         while done_steps < k:
             r = min(R, k - done_steps)
-            a_in = None if args.policy != "external" else (acts if r == R else acts[:r].contiguous())
+            a_in = None if args.policy != "external" else next_actions(r)
             env.rollout(r, a_in, out=bufs if r == R else None)
             done_steps += r; launches += 1
             if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
@@ -213,8 +239,29 @@ def main():
                     "kernel": env.kernel_name}
         # the same launches replayed from a hipGraph (50 armenv_step calls per graph): host launch cost removed
         if k2 >= 50:
-            step_api["hipgraph"] = step_api_graph(env, run, n, k2, dev)
+            step_api["hipgraph"] = step_api_graph(env, pool, next_actions, n, k2, dev)
         args.mode = "rollout"
+
+    # "pre-generated on device ... or generated in-kernel for the persistent variant --
+    # report both".  Same rollout kernel family with the random policy drawn in-kernel (Philox), timed beside the headline.
+    in_kernel = None
+    if step_api is not None and args.steps >= R:
+        bound, sig = (0.7, 0.7 * 0.98) if args.task == "reach" else (0.4, 0.4 * 0.98)
+        env.set_policy("random", action_bound=bound, noise_sigma=sig, noise_clip=bound if args.task == "reach" else 1e9)
+        lr = max(2, min(args.steps // R, 10))
+        for _ in range(2):
+            env.rollout(R, None, out=bufs)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(lr):
+            env.rollout(R, None, out=bufs)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        w4 = time.perf_counter() - t0
+        in_kernel = {"value": n * lr * R / w4, "unit": "env-steps/s", "steps": lr * R,
+                     "us_per_step": e0.elapsed_time(e1) * 1e3 / (lr * R), "kernel": env.kernel_name.replace("_step", "_rollout") + "+philox_policy"}
 
     if rank == 0:
         total_envs = n * world
@@ -239,7 +286,7 @@ def main():
                 traffic = None
         updates = dc["ik_updates"] / max(1, dc["env_steps"])
         flops = (updates * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n * steps_per_launch
-        pol_txt = {"external": "random policy %s pre-generated in HBM, step() throughput only",
+        pol_txt = {"external": "random policy %s pre-generated in HBM as an i.i.d. [steps, N, 3] pool, step() throughput only",
                    "random": "random policy %s generated in-kernel (Philox)",
                    "actor": "TD3 actor forward (exact f32 MFMA) + exploration noise %s fused into the step kernel",
                    "actor_f16x3": "TD3 actor forward (f16 MFMA, 3-pass hi/lo split) + exploration noise %s fused into the step kernel"}
@@ -280,6 +327,8 @@ def main():
                                      "useful_tflops": af / (launch_us * 1e-6) / 1e12}
         if step_api:
             line["step_api"] = step_api
+        if in_kernel:
+            line["in_kernel_policy"] = in_kernel
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.precision)
         print(json.dumps(line), flush=True)

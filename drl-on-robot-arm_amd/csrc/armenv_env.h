@@ -90,13 +90,20 @@ static __global__ __launch_bounds__(256) void counters_sum_kernel(const unsigned
 // relieve the IK's VGPR pressure, which needs the data -- so it waited (vmcnt(0)) a few hundred instructions after issuing
 // the load, i.e. for most of an HBM round trip, every step.
 // Hazard of the pattern: the compiler believes the registers are defined at prefetch_issue; should it ever copy or spill
-// them before prefetch_settle it would copy stale data.  They are AGPRs used by nothing else, which it has no reason to
-// touch; the bit-for-bit rollout == step tests (reach / push / pick, f64 / f32) are the guard.
-typedef float f32x3 __attribute__((ext_vector_type(3)));
-AE_DEV void prefetch_issue(const float *src, f32x3 &dst) {
-  asm volatile("global_load_dwordx3 %0, %1, off" : "=a"(dst) : "v"(src) : "memory");
+// them before prefetch_settle it would copy stale data.  To give it no reason to, the three AGPRs are used by nothing
+// else and prefetch_settle itself moves them into VGPRs AFTER its wait, inside the same asm block: what is carried round
+// the loop is those VGPRs (a first version carried the AGPRs and hipcc renamed them with v_accvgpr_mov in FRONT of the
+// wait -- harmless only because the load had been in flight for a whole IK).  The bit-for-bit rollout == step tests
+// (reach / push / pick, f64 / f32) are the guard.
+struct ActionPrefetch { float x, y, z; };
+AE_DEV void prefetch_issue(const float *src, ActionPrefetch &d) {
+  asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:8"
+               : "=a"(d.x), "=a"(d.y), "=a"(d.z) : "v"(src) : "memory");
 }
-AE_DEV void prefetch_settle(f32x3 &dst) { asm volatile("s_waitcnt vmcnt(0)" : "+a"(dst) : : "memory"); }
+AE_DEV void prefetch_settle(ActionPrefetch &d, float (&out)[3]) {
+  asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, %3\n\tv_accvgpr_read_b32 %1, %4\n\tv_accvgpr_read_b32 %2, %5"
+               : "=v"(out[0]), "=v"(out[1]), "=v"(out[2]) : "a"(d.x), "a"(d.y), "a"(d.z) : "memory");
+}
 
 struct StepIO {
   const float *action;
@@ -293,12 +300,13 @@ template <class C, typename T> struct ReachLane {
   // consumed here, right after the IK and BEFORE this step's stores are issued: the s_waitcnt the consumption needs
   // then covers only that old load; placed at the next step's top it would also wait for this step's stores
   // (vmcnt is in-order) -- measured 15 % of the wave's cycles.
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, f32x3 *prefetched = nullptr) {
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
+                    float (*next_action)[3] = nullptr) {
     const int64_t n = P.n;
     FKState<T> S;
     T tgt[3];
     const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
-    if (prefetched) prefetch_settle(*prefetched);
+    if (prefetched) prefetch_settle(*prefetched, *next_action);
 
     n_upd += (uint32_t)updates;
     step += 1;                                                                    // :264
@@ -557,13 +565,14 @@ template <class C, typename T, bool PICK> struct CubeLane {
     contact(P, tip0, tip);
   }
 
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, f32x3 *prefetched = nullptr) {
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
+                    float (*next_action)[3] = nullptr) {
     FKState<T> S;
     T tgt[3];
     T p0[3];
     const T q7 = q[NJ - 1];
     const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
-    if (prefetched) prefetch_settle(*prefetched);
+    if (prefetched) prefetch_settle(*prefetched, *next_action);
     n_upd += (uint32_t)updates;
     if constexpr (PICK) {
       q[NJ - 1] = q7;               // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
     // step's stores
     asm volatile("" ::"v"(an[0]), "v"(an[1]), "v"(an[2]));
   }
-  f32x3 an_next = {0.f, 0.f, 0.f};
+  ActionPrefetch an_next{0.f, 0.f, 0.f};
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
     if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
@@ -757,8 +766,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
     }
     const uint32_t before = L.n_done;
     if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
-      L.env_step(P, i, a, io, &an_next);
-      an[0] = an_next[0]; an[1] = an_next[1]; an[2] = an_next[2];
+      L.env_step(P, i, a, io, &an_next, &an);
     } else {
       L.env_step(P, i, a, io);
     }

@@ -13,12 +13,16 @@ tl=torch.zeros((16,n//64,8),dtype=torch.int64,device='cuda:0')
 lib.armenv_dbg_set_timeline.argtypes=[C.c_void_p]
 assert lib.armenv_dbg_set_timeline(C.c_void_p(tl.data_ptr()))==0
 g=torch.Generator(device='cuda:0'); g.manual_seed(0)
-acts=[(torch.randn((n,3),device='cuda:0',generator=g)*0.686).clamp_(-0.7,0.7) for _ in range(8)]
+NA=512 if n<=65536 else 64   # i.i.d. actions per step (a short cycle would walk every env into a corner of the box)
+acts=(torch.randn((NA,n,3),device='cuda:0',generator=g)*0.686).clamp_(-0.7,0.7)
 e.reset()
-for k in range(30): e.step(acts[k%8])
+_c=[0]
+def nxt():
+    _c[0]+=1; return (_c[0]-1)%NA
+for k in range(30): e.step(acts[nxt()])
 torch.cuda.synchronize()
 for k in range(3):
-    e.step(acts[k%8]); torch.cuda.synchronize()
+    e.step(acts[nxt()]); torch.cuda.synchronize()
     t=tl.cpu().numpy().astype(np.int64)[(30+k)%16]
     t0=t[:,0].min()
     st=(t[:,0]-t0)/100.0; ld=(t[:,1]-t[:,0])/100.0; lp=(t[:,2]-t[:,1])/100.0; fin=(t[:,3]-t[:,2])/100.0; end=(t[:,3]-t0)/100.0
@@ -34,7 +38,7 @@ for k in range(3):
 # back-to-back launches (no host sync): kernel k's last wave exit -> kernel k+1's first wave entry, on the shared 100 MHz clock
 torch.cuda.synchronize()
 base=30+3
-for k in range(12): e.step(acts[k%8])
+for k in range(12): e.step(acts[nxt()])
 torch.cuda.synchronize()
 t=tl.cpu().numpy().astype(np.int64)
 rows=[t[(base+k)%16] for k in range(12)]
@@ -45,11 +49,11 @@ for k in range(11):
 
 # persistence of slow waves: are the waves that need extra IK trips the same ones launch after launch?
 warm=int(sys.argv[3]) if len(sys.argv)>3 else 0
-for k in range(warm): e.step(acts[k%8])
+for k in range(warm): e.step(acts[nxt()])
 torch.cuda.synchronize()
 tot=np.zeros(n//64); trips=[]
 for rnd in range(4):
-    for k in range(12): e.step(acts[k%8])
+    for k in range(12): e.step(acts[nxt()])
     torch.cuda.synchronize()
     t=tl.cpu().numpy().astype(np.int64)
     # launch counter position is unknown after warm-up: use every ring slot once (12 of the 16 slots are fresh)

@@ -23,6 +23,10 @@ DST = os.path.join(ROOT, "profiles")
 
 def short(name):
     if "env_rollout_kernel" in name:
+        # template argument POLICY: 0 external actions (the headline), 1 in-kernel Philox policy (the bench line's
+        # "in_kernel_policy" leg), 2 / 3 fused actors
+        if ", 1>(" in name:
+            return "rollout_philox"
         return "rollout"
     if "env_step_kernel" in name:
         return "step"

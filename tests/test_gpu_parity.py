@@ -1414,3 +1414,5 @@ def test_bench_line_contract():
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 1e9 and d["nonfinite_states"] == 0
+    # both forms of config 2: pre-generated actions (the headline) and the in-kernel random policy
+    assert d["step_api"]["value"] > 5e8 and d["in_kernel_policy"]["value"] > 1e9

@@ -8,15 +8,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 dev = torch.device("cuda:0")
 env = BatchedReachEnv(n, device=dev, precision=64, seed=1)
 g = torch.Generator(device=dev); g.manual_seed(0)
-ring = [(torch.randn((n, 3), device=dev, generator=g) * 0.686).clamp_(-0.7, 0.7) for _ in range(16)]
+ring = (torch.randn((300, n, 3), device=dev, generator=g) * 0.686).clamp_(-0.7, 0.7)   # i.i.d. per step
 env.reset()
-for i in range(100): env.step(ring[i % 16])
+for i in range(100): env.step(ring[i])
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(201)]
 c0 = env.counters()
 ev[0].record()
 for i in range(200):
-    env.step(ring[i % 16]); ev[i + 1].record()
+    env.step(ring[100 + i]); ev[i + 1].record()
 torch.cuda.synchronize()
 c1 = env.counters()
 dt = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(200)]
