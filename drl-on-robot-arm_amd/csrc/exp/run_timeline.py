@@ -61,6 +61,19 @@ for rnd in range(4):
     for s_ in fresh:
         tot+= (t[s_][:,3]-t[s_][:,0])/100.0; trips.append(t[s_][:,4].copy())
 trips=np.array(trips)   # [48 launches][waves]
+# where does the spread between waves come from: their own trip counts, or where they run?
+tsum=trips.sum(axis=0).astype(float)
+A=np.vstack([np.ones_like(tsum),tsum]).T
+coef,_,_,_=np.linalg.lstsq(A,tot,rcond=None)
+resid=tot-A@coef
+hw=t[0][:,7]; xcc=t[0][:,6]; cu=(hw>>8)&0xf; sh=(hw>>12)&1; se=(hw>>13)&0x7; simd=(hw>>4)&3
+print(f"   time = {coef[0]:.1f} + {coef[1]:.2f} us x trips; residual std {resid.std():.2f} us, max {resid.max():.1f}")
+print("   residual mean by XCC:", " ".join(f"{resid[xcc==x].mean():+.1f}" for x in np.unique(xcc)))
+print("   residual mean by SIMD:", " ".join(f"{resid[simd==x].mean():+.1f}" for x in np.unique(simd)))
+print("   residual mean by SE:", " ".join(f"{resid[se==x].mean():+.1f}" for x in np.unique(se)))
+slow=np.argsort(-tot)[:8]
+print("   slowest waves: " + "; ".join(f"w{w} {tot[w]:.0f}us trips {int(tsum[w])} xcc{xcc[w]} se{se[w]} cu{cu[w]} simd{simd[w]}" for w in slow))
+
 print(f"after {warm} more steps, 48 launches: in-kernel time per wave summed: mean {tot.mean():.1f} us, std {tot.std():.1f}, max {tot.max():.1f} (+{100*(tot.max()/tot.mean()-1):.1f} %), sum of per-launch maxima n/a")
 print("   wave-trips histogram over all wave-launches:", np.bincount(trips.ravel()))
 extra=(trips>3).sum(axis=0)

@@ -95,6 +95,22 @@ def test_fk_generic_chain_with_base_transform(envs, O):
     e.close()
 
 
+def test_fk_large_joint_angles(envs, O):
+    """The lockstep Cody-Waite sincos has no library fallback: its fused reduction stays exactly rounded far beyond any joint
+    angle a live env can hold.  |q| up to 1e7 rad (1.6 million turns) against the oracle's libm sincos; non-finite angles
+    must come out non-finite, not as a plausible pose."""
+    rng = np.random.default_rng(12)
+    q = rng.uniform(-1.0, 1.0, (2048, 7)) * 10.0 ** rng.uniform(0, 7, (2048, 1))
+    e = _mk(envs, 8, fk_path=1)
+    pos, _ = e.fk(torch.from_numpy(q))
+    p_ref, _ = O.fk(O.make_chain("kuka"), q)
+    assert np.abs(_np(pos) - p_ref).max() < 1e-9
+    bad = np.zeros((2, 7)); bad[0, 3] = np.inf; bad[1, 5] = np.nan
+    pos, _ = e.fk(torch.from_numpy(bad))
+    assert not np.isfinite(_np(pos)).all(axis=1).any()
+    e.close()
+
+
 def test_fk_empty_batch(envs):
     e = _mk(envs, 4)
     pos, quat = e.fk(torch.empty((0, 7), dtype=torch.float64))
