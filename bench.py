@@ -123,7 +123,8 @@ def main():
                     help="external = pre-generated actions in HBM (configs[1], headline); random / actor = fused in-kernel "
                          "policy (actor = configs[2]: TD3 actor forward folded into the rollout kernel)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
-    ap.add_argument("--rollout-steps", type=int, default=50, help="env steps fused per armenv_rollout launch")
+    ap.add_argument("--rollout-steps", type=int, default=100,
+                    help="env steps fused per armenv_rollout launch (default: the reference's logging period, main.py:130)")
     args = ap.parse_args()
 
     from armenv import envs
@@ -281,7 +282,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from separate rocprofv3 --pmc passes (profiles/README.md)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(kernel, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath)).get(kernel, {})
+                # measured per launch at one launch shape: only valid for the same steps per launch and batch size
+                if tj.get("steps_per_launch") == steps_per_launch and tj.get("envs", ENVS_PER_GPU) == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         updates = dc["ik_updates"] / max(1, dc["env_steps"])

@@ -79,7 +79,12 @@ def main():
     json.dump(actor, open(os.path.join(DST, "r01_pmc_actor_f16x3.json"), "w"), indent=1)
     traffic = {}
     names = {"rollout": "reach_rollout<f64,kuka>", "step": "reach_step<f64,kuka>"}
-    steps = {"rollout": 50, "step": 1}
+    spl = 50
+    try:   # steps per rollout launch of the profiled default bench
+        spl = int(json.load(open(os.path.join(SRC, "default_bench.json")))["config"]["steps_per_launch"])
+    except Exception:
+        pass
+    steps = {"rollout": spl, "step": 1}
     for k, name in names.items():
         if k in default and "FETCH_SIZE" in default[k] and "WRITE_SIZE" in default[k]:
             fe, wr = default[k]["FETCH_SIZE"]["mean_per_launch"], default[k]["WRITE_SIZE"]["mean_per_launch"]
