@@ -5,7 +5,7 @@
 // Data layout in HBM (N envs, T = f64 or f32 by ArmEnvConfig.precision), struct-of-arrays with the env index fastest
 // so that a wave's 64 lanes touch 64 consecutive elements of every array:
 //   q[7][N] T | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
-//   last_len[N] i32 | last_success[N] u8 | counters[N/64][8] u64 (one row per wave) | totals[8] u64 | push: aux[7][N] T | pick: aux[11][N] T
+//   last_len[N] i32 | last_success[N] u8 | counters[N/64][8] u64 (one row per wave) | totals[8] u64 | summary rows[N/64][8] f64 | push: aux[7][N] T | pick: aux[11][N] T
 // Caller-facing buffers keep the reference's array-of-struct shapes (action [N][3], obs [N][6|9]); a wave still
 // reads/writes one contiguous span of them.
 #pragma once
@@ -105,6 +105,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   EnvParams<T> P{};
   void *pool = nullptr;
   unsigned long long *counter_totals = nullptr;
+  double *summary_rows = nullptr;
   static constexpr int block = 256;   // four waves: one per SIMD of a CU; the f16x3 actor phase is a 4-wave workgroup
   int cus = 256;
   // Workgroup size of the env kernels that have no workgroup phase (step, rollout without a fused actor): the IK keeps
@@ -136,7 +137,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
-    const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_tmp = take(sizeof(T) * 4);
+    const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_sum = take(64 * (size_t)((n + 63) / 64)), o_tmp = take(sizeof(T) * 4);
     const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
@@ -151,6 +152,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     P.last_success = reinterpret_cast<uint8_t *>(b + o_ls);
     P.counters = reinterpret_cast<unsigned long long *>(b + o_cnt);
     counter_totals = reinterpret_cast<unsigned long long *>(b + o_tot);
+    summary_rows = reinterpret_cast<double *>(b + o_sum);
     T *tmp = reinterpret_cast<T *>(b + o_tmp);
     P.aux = Lane::kAuxRows ? reinterpret_cast<T *>(b + o_aux) : nullptr;
     P.push_success_dis = (T)cfg.push_success_dis;
@@ -274,8 +276,8 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     return ARMENV_OK;
   }
   int summary(double *out_dev, hipStream_t s) override {
-    HIP_TRY(hipMemsetAsync(out_dev, 0, 8 * sizeof(double), s));
-    hipLaunchKernelGGL((env_summary_kernel<Lane, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, out_dev);
+    hipLaunchKernelGGL((env_summary_kernel<Lane, T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, summary_rows);
+    hipLaunchKernelGGL(summary_reduce_kernel, dim3(1), dim3(256), 0, s, summary_rows, (P.n + 63) / 64, out_dev);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }

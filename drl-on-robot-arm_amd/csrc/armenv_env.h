@@ -815,12 +815,14 @@ __global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, cons
 
 // Logging summary without a host round trip: per-lane reach distance |FK(q) - goal| (reach) or cube-target distance
 // (push, pick) and the last finished episode's return / length / success, reduced across the wavefront with lane shuffles
-// and accumulated with one atomic per wave into out[8] =
-//   [sum distance, max distance (as f64 bits via atomicMax on the non-negative pattern), sum last_return, sum last_len,
-//    sum last_success, envs counted, 0, 0].
+// into one row per wave, rows[i >> 6][8] =
+//   [sum distance, max distance, sum last_return, sum last_len, sum last_success, envs counted, 0, 0];
+// summary_reduce_kernel folds the rows into out[8] in a fixed order (no atomics: same-address atomics serialise at 12 ns
+// each across the chip, and a sum of doubles accumulated by atomics depends on the order the waves happen to finish in).
 template <class Lane, typename T>
-__global__ __launch_bounds__(256) void env_summary_kernel(EnvParams<T> P, double *out) {
+__global__ __launch_bounds__(256) void env_summary_kernel(EnvParams<T> P, double *rows) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i & ~(int64_t)63) >= P.n) return;   // whole wave past the end
   const bool live = i < P.n;
   const int64_t ic = live ? i : P.n - 1;
   const double dist = Lane::summary_distance(P, ic);
@@ -832,12 +834,22 @@ __global__ __launch_bounds__(256) void env_summary_kernel(EnvParams<T> P, double
     mx = fmax(mx, __shfl_xor(mx, o));
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&out[0], v[0]);
-    atomicMax(reinterpret_cast<unsigned long long *>(&out[1]), (unsigned long long)__double_as_longlong(mx));
-    atomicAdd(&out[2], v[1]);
-    atomicAdd(&out[3], v[2]);
-    atomicAdd(&out[4], v[3]);
-    atomicAdd(&out[5], v[4]);
+    double *r = rows + 8 * (i >> 6);
+    r[0] = v[0]; r[1] = mx; r[2] = v[1]; r[3] = v[2]; r[4] = v[3]; r[5] = v[4]; r[6] = 0.0; r[7] = 0.0;
+  }
+}
+
+static __global__ __launch_bounds__(256) void summary_reduce_kernel(const double *rows, int64_t n_rows, double *out) {
+  __shared__ double part[32][8];
+  const int col = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  double acc = 0.0;
+  for (int64_t r = slot; r < n_rows; r += 32) acc = (col == 1) ? fmax(acc, rows[8 * r + col]) : acc + rows[8 * r + col];
+  part[slot][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double a = part[0][col];
+    for (int k = 1; k < 32; ++k) a = (col == 1) ? fmax(a, part[k][col]) : a + part[k][col];
+    out[col] = a;
   }
 }
 

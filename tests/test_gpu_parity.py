@@ -1398,6 +1398,8 @@ def test_device_summary_matches_host_reduction(envs, O, kuka):
     assert abs(float(s["mean_last_return"]) - _np(ret).mean()) < 1e-9
     assert abs(float(s["mean_last_len"]) - _np(ln).mean()) < 1e-9 and float(s["raw"][5]) == n
     assert abs(float(s["last_success_rate"]) - _np(su).mean()) < 1e-12
+    s2 = e.summary()                                           # fixed reduction order: repeat calls agree bit for bit
+    assert torch.equal(s["raw"], s2["raw"])
     e.close()
     pe = envs.BatchedPushEnv(1024, device=DEV, seed=3)
     pe.reset()
