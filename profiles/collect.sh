@@ -18,11 +18,11 @@ stats() {   # name, bench args...
 }
 if [ "$MODE" = "all" ]; then
 stats default                                   # the headline command (with cpu_baseline)
-stats actor_f16x3 --policy actor_f16x3 --steps 400 --no-cpu-baseline
-stats actor_f32 --policy actor --steps 200 --no-cpu-baseline
-stats push32768 --task push --envs-per-gpu 32768 --steps 400 --no-cpu-baseline
-stats pick32768 --task pick --envs-per-gpu 32768 --steps 400 --no-cpu-baseline
-stats f32engine --precision 32 --steps 400 --no-cpu-baseline
+stats actor_f16x3 --policy actor_f16x3 --steps 1000 --no-cpu-baseline
+stats actor_f32 --policy actor --steps 500 --no-cpu-baseline
+stats push32768 --task push --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
+stats pick32768 --task pick --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
+stats f32engine --precision 32 --steps 1000 --no-cpu-baseline
 fi
 # one small counter set per pass: a set the hardware cannot collect in one pass makes rocprofv3 abort and then hang in its
 # signal handler (FETCH_SIZE + WRITE_SIZE + GRBM_GUI_ACTIVE did), hence the timeouts
