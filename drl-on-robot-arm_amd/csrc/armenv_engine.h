@@ -137,7 +137,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
-    const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_sum = take(64 * (size_t)((n + 63) / 64)), o_tmp = take(sizeof(T) * 4);
+    const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_sum = take(64 * (size_t)((n + 63) / 64)), o_tmp = take(sizeof(T) * 32);
     const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
@@ -202,9 +202,10 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     }
     hipLaunchKernelGGL((init_consts_kernel<C, T>), dim3(1), dim3(64), 0, 0, P, tmp);
     HIP_TRY(hipGetLastError());
-    T host_p[3];
-    HIP_TRY(hipMemcpy(host_p, tmp, sizeof host_p, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 3; ++k) P.p_init[k] = host_p[k];
+    T host_c[3 + 2 * NJ];
+    HIP_TRY(hipMemcpy(host_c, tmp, sizeof host_c, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) P.p_init[k] = host_c[k];
+    P.trig_init = tmp + 3;
     kname = std::string(Lane::kName) + "_step<" + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
     return ARMENV_OK;
   }

@@ -33,6 +33,8 @@ template <typename T> struct EnvParams {
   double goal_hi[3];
   T q_init[NJ];
   T p_init[3];  // FK(q_init), computed on the device at create time
+  const T *trig_init;  // device: cos(q_init)[7], sin(q_init)[7] from the device's own sincos_all (same bits as a launch start computes);
+                       // read only by a lane that resets in place, so it stays out of the kernel's scalar registers
   uint64_t seed;
   uint64_t env_id0;
   // push task (rl_push_env.py): simplified pusher model + reward constants
@@ -151,6 +153,7 @@ __global__ void init_consts_kernel(EnvParams<T> P, T *out) {
   sincos_all<T>(q, cq, sq);
   fk<C, T>(P.chain, cq, sq, S);
   out[0] = S.p[0]; out[1] = S.p[1]; out[2] = S.p[2];
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; out[3 + i] = cq[i]; out[3 + NJ + i] = sq[i]; });
 }
 
 // Optional per-wave timeline (make timeline; csrc/exp/run_timeline.py): wall-clock stamps at kernel entry, after
@@ -273,6 +276,13 @@ template <class C, typename T> struct ReachLane {
   }
 
   T q[NJ];
+  // (cos q, sin q) of the seven joints.  Re-derived from q at the start of every LAUNCH (load) and carried from step to
+  // step inside it: the IK already advances them by the angle-addition formulas with each update, so a step's first FK
+  // can start from the previous step's last.  A full sincos of seven joints was 328 of a step's 3 263 instructions.
+  // Consequence: armenv_step == armenv_rollout(1) bit for bit, armenv_rollout(T) == T step launches to ~1e-14 (the
+  // re-derivation at a launch boundary rounds differently from 3 T incremental rotations), and a given sequence of
+  // launches is deterministic.
+  T trig[2 * NJ];
   float g[3];
   int32_t step;
   T ep_ret;
@@ -284,6 +294,12 @@ template <class C, typename T> struct ReachLane {
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; g[k] = P.goal[(int64_t)k * n + i]; });
     step = P.step[i];
     ep_ret = P.ep_return[i];
+    derive_trig();
+  }
+  AE_DEV void derive_trig() {
+    T c_[NJ], s_[NJ];
+    sincos_all<T>(q, c_, s_);
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; trig[j] = c_[j]; trig[NJ + j] = s_[j]; });
   }
 
   AE_DEV void store(const EnvParams<T> &P, int64_t i) {
@@ -305,7 +321,7 @@ template <class C, typename T> struct ReachLane {
     const int64_t n = P.n;
     FKState<T> S;
     T tgt[3];
-    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);  // :237-257
+    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, nullptr, &trig);  // :237-257
     if (prefetched) prefetch_settle(*prefetched, *next_action);
 
     n_upd += (uint32_t)updates;
@@ -341,6 +357,7 @@ template <class C, typename T> struct ReachLane {
       P.episode[i] = ep + 1u;
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
       static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
+      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig_init[j]; });
       step = 0;
       ep_ret = T(0);
       store_obs6<T>(io.obs, i, P.p_init, g);
@@ -357,7 +374,7 @@ template <class C, typename T> struct ReachLane {
   AE_DEV void refresh_obs(const EnvParams<T> &P) {
     FKState<T> S;
     T cq[NJ], sq[NJ];
-    sincos_all<T>(q, cq, sq);
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = trig[j]; sq[j] = trig[NJ + j]; });
     fk<C, T>(P.chain, cq, sq, S);
     cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
   }
@@ -414,6 +431,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
   static constexpr int kAuxRows = PICK ? 11 : 7, kAuxDim = PICK ? 12 : 8;
   static constexpr const char *kName = PICK ? "pick" : "push";
   T q[NJ];
+  T trig[2 * NJ];           // (cos q, sin q), re-derived at launch start and carried between steps: see ReachLane
   T cube[3], target[3], d_last;
   T grip = T(0);            // pick: 0 open, 1 closed, 2 closed and holding the cube
   T off[3] = {T(0), T(0), T(0)};   // pick: cube - tip while held
@@ -424,7 +442,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
   AE_DEV void refresh_obs(const EnvParams<T> &P) {
     FKState<T> S;
     T cq[NJ], sq[NJ];
-    sincos_all<T>(q, cq, sq);
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = trig[j]; sq[j] = trig[NJ + j]; });
     fk<C, T>(P.chain, cq, sq, S);
     cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
   }
@@ -476,6 +494,12 @@ template <class C, typename T, bool PICK> struct CubeLane {
     }
     step = P.step[i];
     ep_ret = P.ep_return[i];
+    derive_trig();
+  }
+  AE_DEV void derive_trig() {
+    T c_[NJ], s_[NJ];
+    sincos_all<T>(q, c_, s_);
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; trig[j] = c_[j]; trig[NJ + j] = s_[j]; });
   }
 
   AE_DEV void store(const EnvParams<T> &P, int64_t i) {
@@ -570,12 +594,13 @@ template <class C, typename T, bool PICK> struct CubeLane {
     FKState<T> S;
     T tgt[3];
     T p0[3];
-    const T q7 = q[NJ - 1];
-    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0);  // :322-347
+    const T q7 = q[NJ - 1], c7 = trig[NJ - 1], s7 = trig[2 * NJ - 1];
+    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0, &trig);  // :322-347
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     n_upd += (uint32_t)updates;
     if constexpr (PICK) {
       q[NJ - 1] = q7;               // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
+      trig[NJ - 1] = c7; trig[2 * NJ - 1] = s7;
       grip_step(P, p0, S);          // :349, :412-417
     } else {
       contact(P, p0, S.p);          // :349
@@ -618,6 +643,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
       d_last = dist_ct();                                                         // :243-245
       if constexpr (PICK) { grip = T(0); off[0] = off[1] = off[2] = T(0); }
       static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
+      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig_init[j]; });
       step = 0;
       ep_ret = T(0);
       store_obs9<T>(io.obs, i, P.p_init, cube, target);

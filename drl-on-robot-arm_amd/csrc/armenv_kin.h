@@ -442,14 +442,16 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 // getLinkState's tuple to np.float32; reach / push keep the f64 tuple).
 template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
 AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
-                   const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr) {
+                   const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr,
+                   T (*trig)[2 * NJ] = nullptr) {
   using M = Mth<T>;
   // the residual test |p - tgt| > residual is evaluated on squares (no sqrt on the loop-carried critical path)
   const T res2 = P.residual * P.residual;
   T diff2_prev = T(1e60);
   int it = 0;
   T cq[NJ], sq[NJ];
-  sincos_all<T>(q, cq, sq);
+  if (trig) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = (*trig)[j]; sq[j] = (*trig)[NJ + j]; }); }
+  else sincos_all<T>(q, cq, sq);
   // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced
   // incrementally, otherwise cos/sin are recomputed from q
   const bool small_steps = P.max_dtheta <= T(0.7854);
@@ -495,6 +497,7 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     sincos_all<T>(q, cq, sq);
     fk<C, T>(ch, cq, sq, S);
   }
+  if (trig) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; (*trig)[j] = cq[j]; (*trig)[NJ + j] = sq[j]; }); }
   return it;
 }
 

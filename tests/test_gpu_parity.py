@@ -32,6 +32,18 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+def _same_rollout_step(out, t, o, r, d, tol=2e-6):
+    """Row t of a multi-step rollout against the same step run as its own launch.  (cos q, sin q) are re-derived from q
+    at the start of every launch and advanced incrementally inside it, so a T-step launch and T one-step launches start
+    their FKs from values that differ in the last bit.  Bullet's orientation error 2 acos(w) is quantised at
+    3e-8 sqrt(k) rad near convergence (w = 1 - k 2^-53), which turns a last-bit difference into ~1e-7 rad of joint angle
+    -- the same noise floor the GPU / oracle comparisons have (1e-6): flags must be equal, outputs agree to that floor."""
+    assert torch.equal(out["done"][t], d), t
+    assert (out["obs"][t] - o).abs().max().item() <= tol, (t, (out["obs"][t] - o).abs().max().item())
+    assert (out["reward"][t] - r).abs().max().item() <= 20 * tol, t
+
+
+
 def _actions(rng, n):
     """the run() exploration distribution with a zero actor, main.py:116-117"""
     return np.clip(rng.normal(0.0, 0.7 * 0.98, (n, 3)), -0.7, 0.7).astype(np.float32)
@@ -471,25 +483,43 @@ def test_rlreachenv_compat_surface(envs, O, kuka):
 # ------------------------------------------------------------------------------ rollout engine (C1)
 
 @pytest.mark.parametrize("precision", [64, 32])
-def test_rollout_external_actions_equals_step_calls_bitwise(envs, precision):
-    """armenv_rollout with external actions is the same arithmetic as T armenv_step launches."""
+def test_rollout_external_actions_equals_step_calls(envs, precision):
+    """armenv_rollout with external actions against T armenv_step launches: the same trajectory (to the re-derivation of
+    (cos q, sin q) at launch boundaries), deterministic, and bit-identical for one-step launches."""
     n, T = 4096 + 64 + 3, 37
     rng = np.random.default_rng(60)
     acts = torch.from_numpy(np.stack([_actions(rng, n) for _ in range(T)])).to(DEV)
     a = _mk(envs, n, seed=9, precision=precision, max_steps=20)       # short episodes: resets inside the rollout
     b = _mk(envs, n, seed=9, precision=precision, max_steps=20)
     a.reset(); b.reset()
+    tol = 2e-6 if precision == 64 else 5e-4
     out = a.rollout(T, acts, want_actions=True, want_terminal_obs=True)
     for t in range(T):
         o, r, d, s = b.step(acts[t], want_terminal_obs=True)
-        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r), t
-        assert torch.equal(out["done"][t], d) and torch.equal(out["success"][t], s), t
-        assert torch.equal(out["terminal_obs"][t], b.terminal_obs), t
+        _same_rollout_step(out, t, o, r, d, tol)
+        assert torch.equal(out["success"][t], s), t
+        assert (out["terminal_obs"][t] - b.terminal_obs).abs().max().item() <= tol, t
     assert torch.equal(out["actions"], acts)
     sa, sb = a.get_state(), b.get_state()
     for k in sa:
-        assert torch.equal(sa[k], sb[k]), k
-    assert a.counters() == b.counters()
+        if sa[k].is_floating_point():
+            assert (sa[k] - sb[k]).abs().max().item() <= (2e-5 if precision == 64 else 5e-3), k   # ep_return sums 10 |dp| per step
+        else:
+            assert torch.equal(sa[k], sb[k]), k
+    ca, cb = a.counters(), b.counters()
+    assert all(ca[k] == cb[k] for k in ("episodes", "successes", "env_steps", "nonfinite"))
+    assert abs(ca["ik_updates"] - cb["ik_updates"]) <= 1e-3 * ca["ik_updates"]   # a count flips when a residual sits on the threshold
+    # the SAME launch sequence is deterministic, and a one-step rollout is the step kernel's arithmetic bit for bit
+    c = _mk(envs, n, seed=9, precision=precision, max_steps=20); c.reset()
+    out_c = c.rollout(T, acts, want_terminal_obs=True)
+    assert all(torch.equal(out[k], out_c[k]) for k in ("obs", "reward", "done", "success", "terminal_obs"))
+    d1 = _mk(envs, n, seed=9, precision=precision, max_steps=20); d1.reset()
+    d2 = _mk(envs, n, seed=9, precision=precision, max_steps=20); d2.reset()
+    for t in range(5):
+        o1 = d1.rollout(1, acts[t:t + 1])
+        o, r, d, s = d2.step(acts[t])
+        assert torch.equal(o1["obs"][0], o) and torch.equal(o1["reward"][0], r) and torch.equal(o1["done"][0], d), t
+    c.close(); d1.close(); d2.close()
     assert a.counters()["episodes"] >= n
     a.close(); b.close()
 
@@ -520,8 +550,8 @@ def test_rollout_random_policy_matches_oracle(envs, O, kuka):
     e2.reset()
     o1 = {k: v.clone() for k, v in e2.rollout(23, None, want_actions=True).items()}
     o2 = e2.rollout(T - 23, None, want_actions=True)
-    assert torch.equal(torch.cat([o1["obs"], o2["obs"]]), out["obs"])
-    assert torch.equal(torch.cat([o1["actions"], o2["actions"]]), out["actions"])
+    assert (torch.cat([o1["obs"], o2["obs"]]) - out["obs"]).abs().max().item() <= 2e-6     # launch boundary, see _same_rollout_step
+    assert (torch.cat([o1["actions"], o2["actions"]]) - out["actions"]).abs().max().item() <= 1e-7
     e.close(); e2.close()
 
 
@@ -532,7 +562,7 @@ def test_step_with_fused_policy_equals_one_step_rollouts(envs):
     out = a.rollout(9, None)
     for t in range(9):
         o, r, d, s = b.step(None)
-        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["done"][t], d)
+        _same_rollout_step(out, t, o, r, d)
     a.close(); b.close()
 
 
@@ -658,7 +688,7 @@ def test_push_trajectory_autoreset_and_rollout(envs, O, kuka):
     out = r_env.rollout(T, torch.from_numpy(np.stack(acts)).to(DEV))
     for t in range(T):
         o, r, d, su = e2.step(torch.from_numpy(acts[t]).to(DEV))
-        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["done"][t], d)
+        _same_rollout_step(out, t, o, r, d)
     for x in (e, r_env, e2):
         x.close()
 
@@ -824,9 +854,9 @@ def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka):
     out = r_env.rollout(T, torch.from_numpy(np.stack(acts)).to(DEV))
     for t in range(T):
         o, r, d, su = e2.step(torch.from_numpy(acts[t]).to(DEV))
-        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["done"][t], d)
+        _same_rollout_step(out, t, o, r, d)
     sa, sb = r_env.get_state(), e2.get_state()
-    assert torch.equal(sa["aux"], sb["aux"]) and torch.equal(sa["q"], sb["q"])
+    assert (sa["aux"] - sb["aux"]).abs().max().item() < 2e-6 and (sa["q"] - sb["q"]).abs().max().item() < 2e-5
     for x in (e, r_env, e2):
         x.close()
 
@@ -966,7 +996,7 @@ def test_cube_tasks_on_other_chain_paths(envs, O, task, robot, fk_path):
     out = a_env.rollout(T, acts)
     for t in range(T):
         o, r, d, su = b_env.step(acts[t])
-        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["done"][t], d)
+        _same_rollout_step(out, t, o, r, d)
     a_env.close(); b_env.close()
 
 
