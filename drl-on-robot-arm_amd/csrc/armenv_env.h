@@ -95,7 +95,7 @@ static __global__ __launch_bounds__(256) void counters_sum_kernel(const unsigned
 // them before prefetch_settle it would copy stale data.  To give it no reason to, the three AGPRs are used by nothing
 // else and prefetch_settle itself moves them into VGPRs AFTER its wait, inside the same asm block: what is carried round
 // the loop is those VGPRs (a first version carried the AGPRs and hipcc renamed them with v_accvgpr_mov in FRONT of the
-// wait -- harmless only because the load had been in flight for a whole IK).  The bit-for-bit rollout == step tests
+// wait -- harmless only because the load had been in flight for a whole IK).  The one-step-rollout == step (bit for bit) and rollout == step (1e-6) tests
 // (reach / push / pick, f64 / f32) are the guard.
 struct ActionPrefetch { float x, y, z; };
 AE_DEV void prefetch_issue(const float *src, ActionPrefetch &d) {
@@ -239,7 +239,7 @@ AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint3
 }
 
 // Per-lane state of one reach env and the body of one env step.  The single-step kernel and the T-step rollout
-// kernel both run this code, so a rollout is bit-identical to T step launches.
+// kernel both run this code: a one-step rollout is bit-identical to a step launch (see `trig` below for longer ones).
 template <class C, typename T> struct ReachLane {
   using M = Mth<T>;
   static constexpr int kTask = ARMENV_TASK_REACH;
@@ -279,9 +279,10 @@ template <class C, typename T> struct ReachLane {
   // (cos q, sin q) of the seven joints.  Re-derived from q at the start of every LAUNCH (load) and carried from step to
   // step inside it: the IK already advances them by the angle-addition formulas with each update, so a step's first FK
   // can start from the previous step's last.  A full sincos of seven joints was 328 of a step's 3 263 instructions.
-  // Consequence: armenv_step == armenv_rollout(1) bit for bit, armenv_rollout(T) == T step launches to ~1e-14 (the
-  // re-derivation at a launch boundary rounds differently from 3 T incremental rotations), and a given sequence of
-  // launches is deterministic.
+  // Consequence: armenv_step == armenv_rollout(1) bit for bit; a given sequence of launches is deterministic;
+  // armenv_rollout(T) and T step launches start their FKs from last-bit-different values (a re-derivation rounds
+  // differently from 3 T incremental rotations), which Bullet's 2 acos(w) orientation error, quantised at 3e-8 sqrt(k) rad
+  // near convergence, turns into ~1e-7 rad of joint angle: the noise floor of the algorithm (GPU vs oracle: 1e-6).
   T trig[2 * NJ];
   float g[3];
   int32_t step;
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io
 
 // The rollout inner loop of /root/reference/main.py:108-128 for `steps` consecutive env steps in ONE launch: the env
 // state stays in registers, every step's outputs go to row t of [steps][N][...] buffers, and the action of step t
-// is either read from actions[t] (external policy, identical to `steps` calls of env_step_kernel) or produced
+// is either read from actions[t] (external policy: the trajectory of `steps` calls of env_step_kernel) or produced
 // in-kernel by the fused exploration policy.  Because lanes never synchronise, a lane that needs extra IK updates
 // in one step does not hold the other envs back for the rest of the launch: per-step cost approaches the MEAN
 // update count instead of the per-launch MAX.

@@ -158,7 +158,9 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
 
 /* Replaces the rollout inner loop of /root/reference/main.py:108-128 (take_action -> noise -> step -> store) for
  * `steps` consecutive env steps of all N envs in ONE kernel launch; the env state stays in registers between steps.
- *   actions_dev  f32 [steps][N][3]: external policy -- results are bit-identical to `steps` armenv_step calls.
+ *   actions_dev  f32 [steps][N][3]: external policy -- the trajectory of `steps` armenv_step calls (bit-identical for
+ *                steps == 1; for longer launches to the IK's ~1e-7 rad noise floor: (cos q, sin q) are re-derived from q at
+ *                the start of every launch and carried between the steps of one).
  *                NULL: the fused policy installed with armenv_set_policy produces the actions in-kernel.
  *   obs_dev f32 [steps][N][obs_dim], reward_dev f32 [steps][N], done_dev / success_dev u8 [steps][N]: row t holds
  *   what armenv_step would have returned at step t.  actions_out_dev (nullable, f32 [steps][N][3]) receives the
