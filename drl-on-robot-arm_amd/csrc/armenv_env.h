@@ -282,7 +282,7 @@ template <class C, typename T> struct ReachLane {
   // Consequence: armenv_step == armenv_rollout(1) bit for bit; a given sequence of launches is deterministic;
   // armenv_rollout(T) and T step launches start their FKs from last-bit-different values (a re-derivation rounds
   // differently from 3 T incremental rotations), which Bullet's 2 acos(w) orientation error, quantised at 3e-8 sqrt(k) rad
-  // near convergence, turns into ~1e-7 rad of joint angle: the noise floor of the algorithm (GPU vs oracle: 1e-6).
+  // near convergence, turns into ~1e-7 rad of joint angle: the noise floor of the algorithm (the CPU cross-check of the tests sits at 1e-6).
   T trig[2 * NJ];
   float g[3];
   int32_t step;
