@@ -337,7 +337,11 @@ template <class C, typename T> struct ReachLane {
     ep_ret += reward;
 
     bool finite = true;
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
+    {   // one test on the sum: a NaN or an infinity among the seven angles makes it non-finite (inf - inf = NaN), and finite
+      // joint angles cannot overflow it
+      const T sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + q[6]);
+      finite = M::finite(sum);
+    }
     if (!finite) n_bad += 1;
 
     io.reward[i] = (float)reward;
@@ -623,7 +627,11 @@ template <class C, typename T, bool PICK> struct CubeLane {
     ep_ret += reward;
 
     bool finite = true;
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; finite = finite && M::finite(q[j]); });
+    {   // one test on the sum: a NaN or an infinity among the seven angles makes it non-finite (inf - inf = NaN), and finite
+      // joint angles cannot overflow it
+      const T sum = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + q[6]);
+      finite = M::finite(sum);
+    }
     if (!finite) n_bad += 1;
 
     io.reward[i] = (float)reward;
