@@ -7,9 +7,11 @@ configs[1]; N>1 = configs[4], envs sharded over GPUs, RCCL all-gather of episode
          bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of actions: every env of the rank advances once with a
-pre-generated random-policy action batch already resident in HBM.  Two launch shapes run the same per-step code:
-  --mode rollout (default, `value`): armenv_rollout, R steps per kernel launch, env state kept in registers,
-                 per-step outputs written to [R][N][...] buffers (bit-identical to R armenv_step calls);
+pre-generated random-policy action batch already resident in HBM (an i.i.d. [<=1000, N, 3] pool consumed in order).
+Before the W warm-up steps the device is brought to its steady clocks on a scratch handle (--prewarm-ms; an idle
+MI355X ramps for ~30 ms, tests/tools/clock_ramp.py).  Two launch shapes run the same per-step code:
+  --mode rollout (default, `value`): armenv_rollout, R = 100 steps per kernel launch, env state kept in registers,
+                 per-step outputs written to [R][N][...] buffers (the trajectory of R armenv_step calls);
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
                  beside the headline and reported under "step_api".
 Rank 0 prints ONE JSON line.
@@ -173,6 +175,7 @@ def main():
     # (786 MB)": i.i.d. across steps, so every env does a genuine random walk.  (A short ring of action tensors replayed
     # in a cycle makes every env drift ballistically into a corner of the workspace box and sit there -- a different,
     # slower workload: more lanes with 5+ IK trips per wave.)  Capped at 2 GiB for very large batches.
+    # ARMENV_BENCH_POOL: rows of the pool (experiments with shorter, i.e. periodic, action sequences)
     S = int(max(64, min(int(os.environ.get("ARMENV_BENCH_POOL", "1000")), (2 << 30) // (12 * n))))
     if args.task == "reach":      # run() exploration with a zero actor, main.py:116-117
         pool = (torch.randn((S, n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7)
