@@ -351,8 +351,12 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
 template <typename T>
 AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ]) {
   using M = Mth<T>;
-  T Jl[NJ][3];
-  static_for<0, NJ>([&](auto II) {
+  // fk() defines the end-effector point as the LAST joint's pivot (S.p == S.pj[NJ-1], the same values), so the lever arm of
+  // the last joint is x - x = +0 and its linear Jacobian column an exact zero: every term it enters adds +-0.  That column
+  // is left out of the build, of J J^T and of J^T y -- 27 instructions per trip, the same bits for every finite state.
+  constexpr int NL = NJ - 1;
+  T Jl[NL][3];
+  static_for<0, NL>([&](auto II) {
     constexpr int i = II;
     const T r0 = S.p[0] - S.pj[i][0], r1 = S.p[1] - S.pj[i][1], r2 = S.p[2] - S.pj[i][2];
     Jl[i][0] = M::fma(S.z[i][1], r2, -(S.z[i][2] * r1));
@@ -366,10 +370,10 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
     static_for<0, r + 1>([&](auto CI) {
       constexpr int c = CI;
       T acc = (r == c) ? P.lambda : T(0);
-      static_for<0, NJ>([&](auto KI) {
+      static_for<0, (r < 3 || c < 3) ? NL : NJ>([&](auto KI) {
         constexpr int k = KI;
-        const T a = (r < 3) ? Jl[k][r % 3] : S.z[k][r % 3];
-        const T b = (c < 3) ? Jl[k][c % 3] : S.z[k][c % 3];
+        const T a = (r < 3) ? Jl[k < NL ? k : 0][r % 3] : S.z[k][r % 3];
+        const T b = (c < 3) ? Jl[k < NL ? k : 0][c % 3] : S.z[k][c % 3];
         acc = M::fma(a, b, acc);
       });
       A[r][c] = acc;
@@ -417,10 +421,15 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
   T mx = T(0);
   static_for<0, NJ>([&](auto II) {
     constexpr int i = II;
-    T s = Jl[i][0] * y[0];
-    s = M::fma(Jl[i][1], y[1], s);
-    s = M::fma(Jl[i][2], y[2], s);
-    s = M::fma(S.z[i][0], y[3], s);
+    T s;
+    if constexpr (i < NL) {
+      s = Jl[i][0] * y[0];
+      s = M::fma(Jl[i][1], y[1], s);
+      s = M::fma(Jl[i][2], y[2], s);
+      s = M::fma(S.z[i][0], y[3], s);
+    } else {
+      s = S.z[i][0] * y[3];
+    }
     s = M::fma(S.z[i][1], y[4], s);
     s = M::fma(S.z[i][2], y[5], s);
     dth[i] = s;
