@@ -120,11 +120,13 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
       }
     });
   };
-  // relu as ONE compiler-visible instruction, v_med3_f32(x, 0, +inf): fmaxf would add a canonicalising v_max of the
-  // accumulator read in front, and an inline-asm v_max reading an MFMA result is outside hipcc's hazard bookkeeping --
-  // it is not padded against the MFMA -> VALU read hazard, so whether it saw the finished accumulator depended on what
-  // the scheduler happened to put in between (wrong actions in the 9-input push rollout after an unrelated change).
-  auto relu = [](float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); };
+  // relu as ONE compiler-visible instruction: max(bits, 0) on the float's bit pattern as a signed integer (negative
+  // floats, -0 included, are negative integers; NaNs with a clear sign bit pass through).  fmaxf / v_med3 add a
+  // canonicalising v_max of the accumulator read in front, and an inline-asm v_max reading an MFMA result is outside
+  // hipcc's hazard bookkeeping -- it is not padded against the MFMA -> VALU read hazard, so whether it saw the finished
+  // accumulator depended on what the scheduler happened to put in between (wrong actions in the 9-input push rollout
+  // after an unrelated change elsewhere in the kernel).
+  auto relu = [](float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); };
   float p[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   const float4 *w2 = A.W2P + l32;
   const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;     // staged beside the layer-1 table
@@ -320,7 +322,7 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     };
     // relu + f16 hi / lo split of registers 8 u + 2 c, 8 u + 2 c + 1 of a1 -> halfs 2 c, 2 c + 1 of k-step u's B operand.
     // K order inside a k-step: (half, j) <-> neuron 16 ks + 8 (j / 4) + 4 half + (j % 4); W2H / W2L are packed to match.
-    auto relu = [](float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); };   // one v_med3, see actor_forward_wave
+    auto relu = [](float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); };   // one v_max_i32, see actor_forward_wave
     auto split2 = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2], half8 (&l)[2]) {
       constexpr int u = UI, c = CI;
       const float x0 = relu(a1[8 * u + 2 * c]), x1 = relu(a1[8 * u + 2 * c + 1]);
