@@ -348,7 +348,33 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
 // One damped-least-squares update in the dual 6x6 form  dtheta = J^T (J J^T + lambda I)^-1 e,
 // algebraically identical to BussIK's (J^T J + lambda I) dtheta = J^T e (Jacobian::CalcDeltaThetasDLS2)
 // but SPD, pivot-free (LDL^T) and well conditioned in f32.  J columns: [z_i x (p - p_i) ; z_i].
-template <typename T>
+// First joint of a built-in chain: fk() starts from W = I, so its axis is the compile-time unit vector
+// z_0 = sgn * e_m (m = C::perm[0][2]) and its Jacobian column [z_0 x r ; z_0] has three entries that are exact zeros
+// and one that is exactly +-1.  k0_kind(row) classifies row `row` of that column: 0 run-time value, 1 exact zero,
+// 2 exactly +1, 3 exactly -1.  Terms with a zero factor are left out and a unit factor becomes an add: the same bits
+// (x * 1 is x, acc + 0 is acc), 25 instructions per trip fewer.  Generic chains (run-time base pose) keep every term.
+template <class C, bool G = C::kGeneric> struct Axis0 { static constexpr int m = 2, sg = 1; };
+template <class C> struct Axis0<C, false> { static constexpr int m = C::perm[0][2], sg = C::sgn[0][2]; };
+template <class C> constexpr int k0_kind(int row) {
+  if (C::kGeneric) return 0;
+  const int m = Axis0<C>::m, sg = Axis0<C>::sg;
+  if (row < 3) return row == m ? 1 : 0;
+  return (row - 3 == m) ? (sg > 0 ? 2 : 3) : 1;
+}
+// acc + a * b for the k = 0 term of entry (r, c), with the compile-time knowledge above
+template <class C, typename T, int R, int CC>
+AE_DEV T k0_term(T a, T b, T acc) {
+  constexpr int ka = k0_kind<C>(R), kb = k0_kind<C>(CC);
+  if constexpr (ka == 1 || kb == 1) return acc;
+  else if constexpr (ka >= 2 && kb >= 2) return acc + ((ka == kb) ? T(1) : T(-1));
+  else if constexpr (ka == 2) return acc + b;
+  else if constexpr (ka == 3) return acc - b;
+  else if constexpr (kb == 2) return acc + a;
+  else if constexpr (kb == 3) return acc - a;
+  else return Mth<T>::fma(a, b, acc);
+}
+
+template <class C, typename T>
 AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ]) {
   using M = Mth<T>;
   // fk() defines the end-effector point as the LAST joint's pivot (S.p == S.pj[NJ-1], the same values), so the lever arm of
@@ -359,9 +385,18 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
   static_for<0, NL>([&](auto II) {
     constexpr int i = II;
     const T r0 = S.p[0] - S.pj[i][0], r1 = S.p[1] - S.pj[i][1], r2 = S.p[2] - S.pj[i][2];
-    Jl[i][0] = M::fma(S.z[i][1], r2, -(S.z[i][2] * r1));
-    Jl[i][1] = M::fma(S.z[i][2], r0, -(S.z[i][0] * r2));
-    Jl[i][2] = M::fma(S.z[i][0], r1, -(S.z[i][1] * r0));
+    if constexpr (i == 0 && !C::kGeneric) {
+      // z_0 = sg e_m:  (z_0 x r)_m = 0,  (z_0 x r)_(m+1) = -sg r_(m+2),  (z_0 x r)_(m+2) = +sg r_(m+1)
+      constexpr int m = Axis0<C>::m, sg = Axis0<C>::sg;
+      const T r[3] = {r0, r1, r2};
+      Jl[0][m] = T(0);
+      Jl[0][(m + 1) % 3] = sg > 0 ? -r[(m + 2) % 3] : r[(m + 2) % 3];
+      Jl[0][(m + 2) % 3] = sg > 0 ? r[(m + 1) % 3] : -r[(m + 1) % 3];
+    } else {
+      Jl[i][0] = M::fma(S.z[i][1], r2, -(S.z[i][2] * r1));
+      Jl[i][1] = M::fma(S.z[i][2], r0, -(S.z[i][0] * r2));
+      Jl[i][2] = M::fma(S.z[i][0], r1, -(S.z[i][1] * r0));
+    }
   });
   // A = J J^T + lambda I, lower triangle, A[r][c] with row r of J = (r<3 ? Jl[.][r] : z[.][r-3])
   T A[6][6];
@@ -374,7 +409,8 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
         constexpr int k = KI;
         const T a = (r < 3) ? Jl[k < NL ? k : 0][r % 3] : S.z[k][r % 3];
         const T b = (c < 3) ? Jl[k < NL ? k : 0][c % 3] : S.z[k][c % 3];
-        acc = M::fma(a, b, acc);
+        if constexpr (k == 0) acc = k0_term<C, T, r, c>(a, b, acc);
+        else acc = M::fma(a, b, acc);
       });
       A[r][c] = acc;
     });
@@ -422,16 +458,30 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
   static_for<0, NJ>([&](auto II) {
     constexpr int i = II;
     T s;
-    if constexpr (i < NL) {
+    if constexpr (i == 0 && !C::kGeneric) {
+      // the same chain of six terms with the exact zeros left out and the unit factor as an add
+      s = T(0);
+      bool first = true;
+      static_for<0, 6>([&](auto RI) {
+        constexpr int r = RI;
+        constexpr int kind = k0_kind<C>(r);
+        const T a = (r < 3) ? Jl[0][r % 3] : S.z[0][r % 3];
+        if constexpr (kind == 0) { s = first ? a * y[r] : M::fma(a, y[r], s); first = false; }
+        else if constexpr (kind == 2) { s = first ? y[r] : s + y[r]; first = false; }
+        else if constexpr (kind == 3) { s = first ? -y[r] : s - y[r]; first = false; }
+      });
+    } else if constexpr (i < NL) {
       s = Jl[i][0] * y[0];
       s = M::fma(Jl[i][1], y[1], s);
       s = M::fma(Jl[i][2], y[2], s);
       s = M::fma(S.z[i][0], y[3], s);
+      s = M::fma(S.z[i][1], y[4], s);
+      s = M::fma(S.z[i][2], y[5], s);
     } else {
       s = S.z[i][0] * y[3];
+      s = M::fma(S.z[i][1], y[4], s);
+      s = M::fma(S.z[i][2], y[5], s);
     }
-    s = M::fma(S.z[i][1], y[4], s);
-    s = M::fma(S.z[i][2], y[5], s);
     dth[i] = s;
     mx = M::fmax(mx, M::fabs(s));
   });
@@ -489,7 +539,7 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     quat_from_frame<T>(S.W, qc);
     orientation_error<T>(P.tq, qc, P.angle_f32, eo);
     e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
-    dls_update<T>(S, e, P, dth);
+    dls_update<C, T>(S, e, P, dth);
     static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
     if (small_steps) {
       static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });

@@ -32,7 +32,7 @@ template <typename T> __global__ void k_dls(const T *in, T *out, IKParams<T> P) 
   for (int k = 0; k < 3; ++k) S.p[k] = in[(o++) * 64 + threadIdx.x];
   T e[6], d[NJ];
   for (int k = 0; k < 6; ++k) e[k] = in[(o++) * 64 + threadIdx.x];
-  dls_update<T>(S, e, P, d);
+  dls_update<KukaChain, T>(S, e, P, d);
   for (int j = 0; j < NJ; ++j) out[j * 64 + threadIdx.x] = d[j];
 }
 template <typename T> __global__ void k_rotate(const T *in, T *out) {
