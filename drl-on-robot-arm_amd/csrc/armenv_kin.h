@@ -487,8 +487,9 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
   });
   // Jacobian::MaxAngleDLS scale-back as a select (no branch: keeps the caller's update in one basic block)
   const bool over = mx > P.max_dtheta;
-  const T sc = P.max_dtheta * fast_rcp<T>(over ? mx : T(1));
-  static_for<0, NJ>([&](auto II) { constexpr int i = II; dth[i] = over ? dth[i] * sc : dth[i]; });
+  const T sc = over ? P.max_dtheta * fast_rcp<T>(over ? mx : T(1)) : T(1);
+  // one select on the factor instead of seven on the products: x * 1 is x, bit for bit
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; dth[i] = dth[i] * sc; });
 }
 
 // The arm move of one env step.  With FROM_ACTION the Cartesian target is built from the first FK:
