@@ -212,3 +212,17 @@ def test_td3_learner_matches_reference_golden():
             ref = g[f"{name}__{k.replace('.', '_')}"]
             assert np.abs(v.numpy() - ref).max() < 1e-5, (name, k)
     assert agent.total_it == 6
+
+
+def test_bench_defaults_match_the_profiled_launch_shape():
+    """bench.py reports roofline.traffic only for the launch shape the PMC passes measured (profiles/traffic.json); its
+    default steps per launch must be that shape, or the default bench line would silently carry traffic = null."""
+    import json
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    m = re.search(r'"--rollout-steps", type=int, default=(\d+)', src)
+    assert m, "bench.py: --rollout-steps default not found"
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["reach_rollout<f64,kuka>"]
+    assert t["steps_per_launch"] == int(m.group(1))
+    algo = (42 * t["steps_per_launch"] + 148) * 65536                 # DESIGN.md section 4: I/O 42 B per step + state 148 B per launch
+    assert abs(t["hbm_bytes_per_launch"] - algo) / algo < 0.02        # measured HBM traffic = algorithmic bytes: no wasted re-reads
