@@ -46,6 +46,46 @@ template <typename T> struct FKState {
   T pj[NJ][3];  // world joint pivots
 };
 
+// Compile-time structure of a built-in chain's FK.  fk() starts from W = I, and the first joints only rotate about
+// axes of that frame, so some entries of W are EXACT zeros or +-1 whatever the joint angles (KUKA: W after joint 1 is
+// [c -s 0; s c 0; 0 0 1]).  FkKinds propagates that through the chain at compile time -- kind 0 = run-time value,
+// 1 = exact zero, 2 = exactly +1, 3 = exactly -1 -- for W before each joint (Wk) and for the permuted frame A = W R_origin
+// the joint rotation acts on (Ak).  fk() then leaves out every multiplication by an exact zero and every multiplication by
+// one: x * 1 is x and acc + 0 is acc, so the values are the same (an exact-zero entry may come out as +0 where the full
+// arithmetic gives -0), and one FK loses ~25 of its 144 instructions -- four FKs per env step.
+template <class C> struct FkKinds {
+  int Wk[NJ + 1][9];
+  int Ak[NJ][9];
+  constexpr FkKinds() : Wk{}, Ak{} {
+    for (int i = 0; i < 9; ++i) Wk[0][i] = (i % 4 == 0) ? 2 : 1;
+    for (int j = 0; j < NJ; ++j) {
+      for (int c = 0; c < 3; ++c) {
+        const int k = C::perm[j][c], sg = C::sgn[j][c];
+        for (int r = 0; r < 3; ++r) {
+          const int w = Wk[j][3 * k + r];
+          Ak[j][3 * c + r] = (sg > 0 || w < 2) ? w : (w == 2 ? 3 : 2);
+        }
+      }
+      for (int r = 0; r < 3; ++r) {
+        const bool z = Ak[j][r] == 1 && Ak[j][3 + r] == 1;
+        Wk[j + 1][r] = z ? 1 : 0;
+        Wk[j + 1][3 + r] = z ? 1 : 0;
+        Wk[j + 1][6 + r] = Ak[j][6 + r];
+      }
+    }
+  }
+};
+// c * a + s * b with the rounding of fma(c, a, s * b), given the compile-time kinds of a and b
+template <int KA, int KB, typename T>
+AE_DEV T rot_term(T c, T a, T s, T b) {
+  using M = Mth<T>;
+  if constexpr (KA == 1 && KB == 1) return T(0);
+  else if constexpr (KA == 1) return KB == 2 ? s : (KB == 3 ? -s : s * b);
+  else if constexpr (KB == 1) return KA == 2 ? c : (KA == 3 ? -c : c * a);
+  else if constexpr (KA >= 2) return (KA == 2 ? c : -c) + (KB == 2 ? s : (KB == 3 ? -s : s * b));
+  else return M::fma(c, a, KB == 2 ? s : (KB == 3 ? -s : s * b));
+}
+
 // Forward kinematics.  Built-in chains: column j of (W * R_origin) is sgn[j] * W[:, perm[j]]
 // (register renaming + sign), the translation touches only the non-zero origin components, and
 // the joint rotation is a 2x2 rotation of two columns: 15 VALU ops + one sincos per joint.
@@ -81,7 +121,13 @@ AE_DEV void fk(const ChainDev<T> &ch, const T (&cq)[NJ], const T (&sq)[NJ], FKSt
         constexpr int k = KI;
         constexpr double t = C::xyz[j][k];
         if constexpr (t != 0.0) {
-          static_for<0, 3>([&](auto RI) { constexpr int r = RI; S.p[r] = M::fma(S.W[3 * k + r], T(t), S.p[r]); });
+          static_for<0, 3>([&](auto RI) {
+            constexpr int r = RI;
+            constexpr int kw = FkKinds<C>().Wk[j][3 * k + r];
+            if constexpr (kw == 0) S.p[r] = M::fma(S.W[3 * k + r], T(t), S.p[r]);
+            else if constexpr (kw == 2) S.p[r] = S.p[r] + T(t);
+            else if constexpr (kw == 3) S.p[r] = S.p[r] - T(t);
+          });
         }
       });
       static_for<0, 3>([&](auto CI) {
@@ -94,8 +140,15 @@ AE_DEV void fk(const ChainDev<T> &ch, const T (&cq)[NJ], const T (&sq)[NJ], FKSt
     const T sn = sq[j], cs = cq[j];
     static_for<0, 3>([&](auto RI) {
       constexpr int r = RI;
-      S.W[0 + r] = M::fma(cs, A[0 + r], sn * A[3 + r]);
-      S.W[3 + r] = M::fma(cs, A[3 + r], -(sn * A[0 + r]));
+      if constexpr (C::kGeneric) {
+        S.W[0 + r] = M::fma(cs, A[0 + r], sn * A[3 + r]);
+        S.W[3 + r] = M::fma(cs, A[3 + r], -(sn * A[0 + r]));
+      } else {
+        constexpr int k0 = FkKinds<C>().Ak[j][0 + r], k3 = FkKinds<C>().Ak[j][3 + r];
+        constexpr int k0n = k0 < 2 ? k0 : (k0 == 2 ? 3 : 2);   // kind of -A[0 + r]
+        S.W[0 + r] = rot_term<k0, k3, T>(cs, A[0 + r], sn, A[3 + r]);
+        S.W[3 + r] = rot_term<k3, k0n, T>(cs, A[3 + r], sn, -A[0 + r]);
+      }
       S.W[6 + r] = A[6 + r];
       S.z[j][r] = A[6 + r];
       S.pj[j][r] = S.p[r];
