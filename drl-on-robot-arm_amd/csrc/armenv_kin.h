@@ -405,7 +405,8 @@ AE_DEV void orientation_error(const T (&tq)[4], const T (&qc)[4], int angle_f32,
 // z_0 = sgn * e_m (m = C::perm[0][2]) and its Jacobian column [z_0 x r ; z_0] has three entries that are exact zeros
 // and one that is exactly +-1.  k0_kind(row) classifies row `row` of that column: 0 run-time value, 1 exact zero,
 // 2 exactly +1, 3 exactly -1.  Terms with a zero factor are left out and a unit factor becomes an add: the same bits
-// (x * 1 is x, acc + 0 is acc), 25 instructions per trip fewer.  Generic chains (run-time base pose) keep every term.
+// (x * 1 is x, acc + 0 is acc), 25 instructions per trip fewer (jj_term below).  Generic chains (run-time base pose) keep every
+// term.
 template <class C, bool G = C::kGeneric> struct Axis0 { static constexpr int m = 2, sg = 1; };
 template <class C> struct Axis0<C, false> { static constexpr int m = C::perm[0][2], sg = C::sgn[0][2]; };
 template <class C> constexpr int k0_kind(int row) {
@@ -414,10 +415,17 @@ template <class C> constexpr int k0_kind(int row) {
   if (row < 3) return row == m ? 1 : 0;
   return (row - 3 == m) ? (sg > 0 ? 2 : 3) : 1;
 }
-// acc + a * b for the k = 0 term of entry (r, c), with the compile-time knowledge above
-template <class C, typename T, int R, int CC>
-AE_DEV T k0_term(T a, T b, T acc) {
-  constexpr int ka = k0_kind<C>(R), kb = k0_kind<C>(CC);
+// the same for the later joints: their axes z_k = A[:,2] at joint k keep the exact zeros FkKinds knows about (KUKA:
+// z_1 = (-s0, c0, 0)); the linear part z_k x r_k is treated as run-time values
+template <class C, bool G = C::kGeneric> struct ZKind { static constexpr int of(int, int) { return 0; } };
+template <class C> struct ZKind<C, false> { static constexpr int of(int k, int r) { return FkKinds<C>().Ak[k][6 + r]; } };
+template <class C> constexpr int col_kind(int k, int row) {
+  if (k == 0) return k0_kind<C>(row);
+  return row < 3 ? 0 : ZKind<C>::of(k, row - 3);
+}
+template <class C, typename T, int K, int R, int CC>
+AE_DEV T jj_term(T a, T b, T acc) {
+  constexpr int ka = col_kind<C>(K, R), kb = col_kind<C>(K, CC);
   if constexpr (ka == 1 || kb == 1) return acc;
   else if constexpr (ka >= 2 && kb >= 2) return acc + ((ka == kb) ? T(1) : T(-1));
   else if constexpr (ka == 2) return acc + b;
@@ -426,7 +434,6 @@ AE_DEV T k0_term(T a, T b, T acc) {
   else if constexpr (kb == 3) return acc - a;
   else return Mth<T>::fma(a, b, acc);
 }
-
 template <class C, typename T>
 AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ]) {
   using M = Mth<T>;
@@ -446,9 +453,12 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
       Jl[0][(m + 1) % 3] = sg > 0 ? -r[(m + 2) % 3] : r[(m + 2) % 3];
       Jl[0][(m + 2) % 3] = sg > 0 ? r[(m + 1) % 3] : -r[(m + 1) % 3];
     } else {
-      Jl[i][0] = M::fma(S.z[i][1], r2, -(S.z[i][2] * r1));
-      Jl[i][1] = M::fma(S.z[i][2], r0, -(S.z[i][0] * r2));
-      Jl[i][2] = M::fma(S.z[i][0], r1, -(S.z[i][1] * r0));
+      // fma(z_a, r_b, -(z_c r_d)) = rot_term(r_b, z_a, r_d, -z_c): the kinds sit on the z factors
+      constexpr int kz0 = ZKind<C>::of(i, 0), kz1 = ZKind<C>::of(i, 1), kz2 = ZKind<C>::of(i, 2);
+      constexpr auto neg = [](int k) constexpr { return k < 2 ? k : (k == 2 ? 3 : 2); };
+      Jl[i][0] = rot_term<kz1, neg(kz2), T>(r2, S.z[i][1], r1, -S.z[i][2]);
+      Jl[i][1] = rot_term<kz2, neg(kz0), T>(r0, S.z[i][2], r2, -S.z[i][0]);
+      Jl[i][2] = rot_term<kz0, neg(kz1), T>(r1, S.z[i][0], r0, -S.z[i][1]);
     }
   });
   // A = J J^T + lambda I, lower triangle, A[r][c] with row r of J = (r<3 ? Jl[.][r] : z[.][r-3])
@@ -462,8 +472,7 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
         constexpr int k = KI;
         const T a = (r < 3) ? Jl[k < NL ? k : 0][r % 3] : S.z[k][r % 3];
         const T b = (c < 3) ? Jl[k < NL ? k : 0][c % 3] : S.z[k][c % 3];
-        if constexpr (k == 0) acc = k0_term<C, T, r, c>(a, b, acc);
-        else acc = M::fma(a, b, acc);
+        acc = jj_term<C, T, k, r, c>(a, b, acc);
       });
       A[r][c] = acc;
     });
@@ -527,9 +536,13 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
       s = Jl[i][0] * y[0];
       s = M::fma(Jl[i][1], y[1], s);
       s = M::fma(Jl[i][2], y[2], s);
-      s = M::fma(S.z[i][0], y[3], s);
-      s = M::fma(S.z[i][1], y[4], s);
-      s = M::fma(S.z[i][2], y[5], s);
+      static_for<0, 3>([&](auto RI) {
+        constexpr int r = RI;
+        constexpr int kz = ZKind<C>::of(i, r);
+        if constexpr (kz == 0) s = M::fma(S.z[i][r], y[3 + r], s);
+        else if constexpr (kz == 2) s = s + y[3 + r];
+        else if constexpr (kz == 3) s = s - y[3 + r];
+      });
     } else {
       s = S.z[i][0] * y[3];
       s = M::fma(S.z[i][1], y[4], s);
