@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 NJ = 7
-ABI_VERSION = 1
+ABI_VERSION = 2
 TASK_REACH, TASK_PUSH, TASK_PICK = 0, 1, 2
 ROBOT_KUKA, ROBOT_DIANA = 0, 1
 FK_AUTO, FK_GENERIC = 0, 1
@@ -36,11 +36,11 @@ class ArmEnvConfig(C.Structure):
         ("box_lo", C.c_double * 3), ("box_hi", C.c_double * 3), ("goal_lo", C.c_double * 3), ("goal_hi", C.c_double * 3),
         ("target_quat", C.c_double * 4), ("q_init", C.c_double * NJ),
         ("ik_lambda", C.c_double), ("ik_residual", C.c_double), ("ik_max_dtheta", C.c_double),
-        ("ik_max_iters", C.c_int32), ("ik_exit_mode", C.c_int32), ("ik_angle_f32", C.c_int32), ("reserved0", C.c_int32),
+        ("ik_max_iters", C.c_int32), ("ik_exit_mode", C.c_int32), ("ik_angle_f32", C.c_int32), ("fence_counters", C.c_int32),
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
-        ("pick_reserved", C.c_double),
+        ("fence_z", C.c_double),
         ("chain", ArmEnvChain),
     ]
 

@@ -253,7 +253,8 @@ class BatchedArmEnv:
     def counters(self):
         out = (C.c_uint64 * 8)()
         L.check(self._lib.armenv_counters(self._h, C.byref(out), self._stream()))
-        return dict(episodes=out[0], successes=out[1], env_steps=out[2], nonfinite=out[3], ik_updates=out[4])
+        return dict(episodes=out[0], successes=out[1], env_steps=out[2], nonfinite=out[3], ik_updates=out[4],
+                    limit_steps=out[5], low_flange_steps=out[6])
 
 
 class BatchedReachEnv(BatchedArmEnv):

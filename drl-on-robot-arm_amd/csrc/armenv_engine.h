@@ -4,7 +4,7 @@
 //
 // Data layout in HBM (N envs, T = f64 or f32 by ArmEnvConfig.precision), struct-of-arrays with the env index fastest
 // so that a wave's 64 lanes touch 64 consecutive elements of every array:
-//   q[7][N] T | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
+//   q[7][N] T | trig[14][N] T (cos q, sin q) | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
 //   last_len[N] i32 | last_success[N] u8 | counters[N/64][8] u64 (one row per wave) | totals[8] u64 | summary rows[N/64][8] f64 | push: aux[7][N] T | pick: aux[11][N] T
 // Caller-facing buffers keep the reference's array-of-struct shapes (action [N][3], obs [N][6|9]); a wave still
 // reads/writes one contiguous span of them.
@@ -138,7 +138,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
     const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_sum = take(64 * (size_t)((n + 63) / 64)), o_tmp = take(sizeof(T) * 32);
-    const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n);
+    const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n), o_trig = take(sizeof(T) * 2 * NJ * n);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
     char *b = static_cast<char *>(pool);
@@ -155,6 +155,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     summary_rows = reinterpret_cast<double *>(b + o_sum);
     T *tmp = reinterpret_cast<T *>(b + o_tmp);
     P.aux = Lane::kAuxRows ? reinterpret_cast<T *>(b + o_aux) : nullptr;
+    P.trig = reinterpret_cast<T *>(b + o_trig);
     P.push_success_dis = (T)cfg.push_success_dis;
     P.push_cube_half = (T)cfg.push_cube_half;
     P.push_eef_radius = (T)cfg.push_eef_radius;
@@ -188,6 +189,8 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     P.ik.exit_mode = cfg.ik_exit_mode;
     P.ik.angle_f32 = cfg.ik_angle_f32;
     P.ik.clamp_limits = cfg.clamp_joint_limits;
+    P.ik.fence = cfg.fence_counters;
+    P.fence_z = (T)cfg.fence_z;
     for (int j = 0; j < NJ; ++j) {
       double R[9];
       rpy_to_mat(cfg.chain.origin_rpy[j], R);

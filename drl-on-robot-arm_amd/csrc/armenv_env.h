@@ -21,6 +21,7 @@ template <typename T> struct EnvParams {
   uint8_t *last_success;
   unsigned long long *counters;   // [ceil(N / 64)][8]: one row per wave, summed by counters_sum_kernel on read
   T *aux;  // push: [7][N] = cube xyz, target xyz, d_last;  pick: [11][N] = the same + gripper state + hold offset xyz
+  T *trig; // [14][N] = cos q[7], sin q[7]: the pair every FK starts from, carried with q (see ReachLane::trig)
   int64_t n;
   // task constants
   T dv;
@@ -42,12 +43,13 @@ template <typename T> struct EnvParams {
   double push_rest_z, push_place_min, push_place_max;
   // pick task (rl_pick_env.py): gripper model
   T pick_gripper_length, pick_trigger_dis, pick_jaw_half;
+  T fence_z;   // parity fence: steps that end with the flange below this height are counted (ArmEnvConfig.fence_z)
   IKParams<T> ik;
   ChainDev<T> chain;
 };
 
 // Launch-end flush of a lane's event counts into the handle's counters.  Every wave owns one 64-byte row
-// counters[i >> 6][8] = {episodes, successes, env steps (row 0 only), non-finite, IK updates}; the wave sums its lanes
+// counters[i >> 6][8] = {episodes, successes, env steps (row 0 only), non-finite, IK updates, joint-limit steps, low-flange steps}; the wave sums its lanes
 // and ONE lane does a plain read-modify-write of the row -- launches on a stream are serialised, nobody else touches it.
 // Why not atomicAdd on one address: same-address atomics execute one at a time at the memory side of the fabric,
 // 12 ns each from anywhere on the chip (csrc/exp/launch_probe.hip: 4096 waves x 1 atomic = 50 us; per-wave rows =
@@ -60,14 +62,18 @@ AE_DEV uint32_t wave_sum(uint32_t v) {
   return s;
 }
 template <typename T>
-AE_DEV void flush_counts(const EnvParams<T> &P, int64_t i, uint32_t n_done, uint32_t n_succ, uint32_t n_bad, uint32_t n_upd) {
+AE_DEV void flush_counts(const EnvParams<T> &P, int64_t i, uint32_t n_done, uint32_t n_succ, uint32_t n_bad, uint32_t n_upd,
+                         uint32_t n_lim, uint32_t n_low) {
   unsigned long long *row = P.counters + 8 * (i >> 6);
   const uint32_t d = wave_sum(n_done), s = wave_sum(n_succ), b = wave_sum(n_bad), u = wave_sum(n_upd);
+  const uint32_t l = wave_sum(n_lim), z = wave_sum(n_low);
   if ((threadIdx.x & 63) == 0) {   // lane 0 of a launched wave is always a live env (i < N is a prefix)
     if (d) row[0] += d;
     if (s) row[1] += s;
     if (b) row[3] += b;
     row[4] += u;
+    if (l) row[5] += l;
+    if (z) row[6] += z;
   }
 }
 AE_DEV void flush_env_steps(unsigned long long *counters, int64_t i, unsigned long long env_steps) {
@@ -106,6 +112,13 @@ AE_DEV void prefetch_settle(ActionPrefetch &d, float (&out)[3]) {
   asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, %3\n\tv_accvgpr_read_b32 %1, %4\n\tv_accvgpr_read_b32 %2, %5"
                : "=v"(out[0]), "=v"(out[1]), "=v"(out[2]) : "a"(d.x), "a"(d.y), "a"(d.z) : "memory");
 }
+
+// The carried (cos q, sin q) pair is re-derived from q when an env's own step counter reaches a multiple of this (a power
+// of two; 0 = never).  See ReachLane::trig.
+#ifndef ARMENV_TRIG_REDERIVE
+#define ARMENV_TRIG_REDERIVE 512
+#endif
+constexpr int kTrigRederive = ARMENV_TRIG_REDERIVE;
 
 struct StepIO {
   const float *action;
@@ -258,6 +271,7 @@ template <class C, typename T> struct ReachLane {
       P.episode[i] = ep + 1u;
     }
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.q_init[j]; });
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = P.trig_init[j]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = g[k]; });
     P.step[i] = 0;
     P.ep_return[i] = T(0);
@@ -276,18 +290,22 @@ template <class C, typename T> struct ReachLane {
   }
 
   T q[NJ];
-  // (cos q, sin q) of the seven joints.  Re-derived from q at the start of every LAUNCH (load) and carried from step to
-  // step inside it: the IK already advances them by the angle-addition formulas with each update, so a step's first FK
-  // can start from the previous step's last.  A full sincos of seven joints was 328 of a step's 3 263 instructions.
-  // Consequence: armenv_step == armenv_rollout(1) bit for bit; a given sequence of launches is deterministic;
-  // armenv_rollout(T) and T step launches start their FKs from last-bit-different values (a re-derivation rounds
-  // differently from 3 T incremental rotations), which Bullet's 2 acos(w) orientation error, quantised at 3e-8 sqrt(k) rad
-  // near convergence, turns into ~1e-7 rad of joint angle: the noise floor of the algorithm (the CPU cross-check of the tests sits at 1e-6).
+  // (cos q, sin q) of the seven joints, part of the env's state (EnvParams::trig, [14][N] in HBM): set from q_init at a
+  // reset (EnvParams::trig_init) or from q by armenv_set_state, then only ever advanced by the IK's angle-addition updates
+  // (rotate_small), so a step's first FK starts from the previous step's last -- a full sincos of seven joints was 328 of a
+  // step's 3 263 instructions.  Because the pair travels with q through load / store, a trajectory is a pure function of
+  // (state, actions): armenv_rollout(T) and T armenv_step launches produce the same bits for any T (tested at T = 500).
+  // Round 1 re-derived the pair at every launch start instead; T-step launches and step launches then differed in the last
+  // bit of the pair, which Bullet's 2 acos(w) orientation error (quantised at 3e-8 sqrt(k) rad near convergence) amplified
+  // to ~1e-7 rad and, rarely, into a flipped IK update count.  The pair is re-derived from q whenever the env's own step
+  // counter reaches a multiple of 512 (never inside the reference's 501-step episodes), which bounds the accumulated
+  // rounding of the incremental rotations (~1e-16 each) for callers that run unbounded episodes.
   T trig[2 * NJ];
   float g[3];
   int32_t step;
   T ep_ret;
   uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;   // flushed to the handle's counters once per launch
+  uint32_t n_lim = 0, n_low = 0;                           // parity fence: steps the IK left the URDF limits / ended with the flange below fence_z
 
   AE_DEV void load(const EnvParams<T> &P, int64_t i) {
     const int64_t n = P.n;
@@ -295,7 +313,7 @@ template <class C, typename T> struct ReachLane {
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; g[k] = P.goal[(int64_t)k * n + i]; });
     step = P.step[i];
     ep_ret = P.ep_return[i];
-    derive_trig();
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig[(int64_t)j * n + i]; });
   }
   AE_DEV void derive_trig() {
     T c_[NJ], s_[NJ];
@@ -306,9 +324,10 @@ template <class C, typename T> struct ReachLane {
   AE_DEV void store(const EnvParams<T> &P, int64_t i) {
     const int64_t n = P.n;
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = trig[j]; });
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
-    flush_counts(P, i, n_done, n_succ, n_bad, n_upd);
+    flush_counts(P, i, n_done, n_succ, n_bad, n_upd, n_lim, n_low);
   }
 
   // RLReachEnv.step + _reward (rl_reach_env.py:219-319) with action a; writes row i of the caller's buffers.
@@ -322,10 +341,13 @@ template <class C, typename T> struct ReachLane {
     const int64_t n = P.n;
     FKState<T> S;
     T tgt[3];
-    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, nullptr, &trig);  // :237-257
+    if constexpr (kTrigRederive > 0) { if (step != 0 && (step & (kTrigRederive - 1)) == 0) derive_trig(); }
+    bool lim_hit = false;
+    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, nullptr, &trig, &lim_hit);  // :237-257
     if (prefetched) prefetch_settle(*prefetched, *next_action);
 
     n_upd += (uint32_t)updates;
+    if (P.ik.fence) { n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; }
     step += 1;                                                                    // :264
     const T dx = S.p[0] - (T)g[0], dy = S.p[1] - (T)g[1], dz = S.p[2] - (T)g[2];
     const T dist = M::sqrt(M::fma(dx, dx, M::fma(dy, dy, dz * dz)));              // :281
@@ -436,13 +458,13 @@ template <class C, typename T, bool PICK> struct CubeLane {
   static constexpr int kAuxRows = PICK ? 11 : 7, kAuxDim = PICK ? 12 : 8;
   static constexpr const char *kName = PICK ? "pick" : "push";
   T q[NJ];
-  T trig[2 * NJ];           // (cos q, sin q), re-derived at launch start and carried between steps: see ReachLane
+  T trig[2 * NJ];           // (cos q, sin q), carried with q in the env's state: see ReachLane
   T cube[3], target[3], d_last;
   T grip = T(0);            // pick: 0 open, 1 closed, 2 closed and holding the cube
   T off[3] = {T(0), T(0), T(0)};   // pick: cube - tip while held
   int32_t step;
   T ep_ret;
-  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;
+  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0, n_lim = 0, n_low = 0;
   float cur_obs[3];
   AE_DEV void refresh_obs(const EnvParams<T> &P) {
     FKState<T> S;
@@ -479,6 +501,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
       P.episode[i] = ep + 1u;
     }
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.q_init[j]; });
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = P.trig_init[j]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
     const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
     P.aux[(int64_t)6 * n + i] = M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
@@ -499,7 +522,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
     }
     step = P.step[i];
     ep_ret = P.ep_return[i];
-    derive_trig();
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig[(int64_t)j * n + i]; });
   }
   AE_DEV void derive_trig() {
     T c_[NJ], s_[NJ];
@@ -510,6 +533,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
   AE_DEV void store(const EnvParams<T> &P, int64_t i) {
     const int64_t n = P.n;
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = trig[j]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
     P.aux[(int64_t)6 * n + i] = d_last;
     if constexpr (PICK) {
@@ -518,7 +542,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
     }
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
-    flush_counts(P, i, n_done, n_succ, n_bad, n_upd);
+    flush_counts(P, i, n_done, n_succ, n_bad, n_upd, n_lim, n_low);
   }
 
   // stepSimulation (:349), simplified: sphere (tool, radius r, centre p) vs axis-aligned box (cube, half-size h)
@@ -599,10 +623,13 @@ template <class C, typename T, bool PICK> struct CubeLane {
     FKState<T> S;
     T tgt[3];
     T p0[3];
+    if constexpr (kTrigRederive > 0) { if (step != 0 && (step & (kTrigRederive - 1)) == 0) derive_trig(); }
     const T q7 = q[NJ - 1], c7 = trig[NJ - 1], s7 = trig[2 * NJ - 1];
-    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0, &trig);  // :322-347
+    bool lim_hit = false;
+    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0, &trig, &lim_hit);  // :322-347
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     n_upd += (uint32_t)updates;
+    if (P.ik.fence) { n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; }
     if constexpr (PICK) {
       q[NJ - 1] = q7;               // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
       trig[NJ - 1] = c7; trig[2 * NJ - 1] = s7;
@@ -914,7 +941,12 @@ __global__ __launch_bounds__(256) void set_state_kernel(EnvParams<T> P, const do
   if (i >= P.n) return;
   if (aux && P.aux)
     for (int k = 0; k < aux_rows; ++k) P.aux[(int64_t)k * P.n + i] = (T)aux[(int64_t)aux_dim * i + k];
-  if (q) static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = (T)q[7 * i + j]; });
+  if (q) {   // resetJointState: the carried (cos q, sin q) restart from the new angles
+    T qq[NJ], c_[NJ], s_[NJ];
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; qq[j] = (T)q[7 * i + j]; P.q[(int64_t)j * P.n + i] = qq[j]; });
+    sincos_all<T>(qq, c_, s_);
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = c_[j]; P.trig[(int64_t)(NJ + j) * P.n + i] = s_[j]; });
+  }
   if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = goal[3 * i + k]; });
   if (step) P.step[i] = step[i];
   if (episode) P.episode[i] = episode[i];

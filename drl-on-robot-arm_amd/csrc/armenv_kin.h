@@ -34,6 +34,7 @@ template <typename T> struct IKParams {
   int32_t exit_mode;
   int32_t angle_f32;
   int32_t clamp_limits;
+  int32_t fence;    // count the steps whose IK result leaves [lim_lo, lim_hi] (ArmEnvConfig.fence_counters)
   T lim_lo[NJ];
   T lim_hi[NJ];
 };
@@ -569,7 +570,7 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
 AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
                    const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr,
-                   T (*trig)[2 * NJ] = nullptr) {
+                   T (*trig)[2 * NJ] = nullptr, bool *limit_hit = nullptr) {
   using M = Mth<T>;
   // the residual test |p - tgt| > residual is evaluated on squares (no sqrt on the loop-carried critical path)
   const T res2 = P.residual * P.residual;
@@ -615,13 +616,23 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     }
     diff2_prev = diff2;
   }
-  if (P.clamp_limits) {
-    static_for<0, NJ>([&](auto II) {
-      constexpr int i = II;
-      q[i] = q[i] < P.lim_lo[i] ? P.lim_lo[i] : (q[i] > P.lim_hi[i] ? P.lim_hi[i] : q[i]);
-    });
-    sincos_all<T>(q, cq, sq);
-    fk<C, T>(ch, cq, sq, S);
+  // URDF joint limits (/root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7, fields 8-9).  The reference never passes
+  // them to the IK (rl_reach_env.py:103-107 are dead data, :244-250), so q may leave them; Bullet then pushes the joint
+  // back inside stepSimulation (:258) through a limit constraint this build does not model.  `hit` fences those steps
+  // (counted by the caller); with clamp_limits the result is projected onto the limits -- the hard-limit idealisation
+  // of that constraint -- and the frame recomputed, for the lanes that left them only (the others keep their bits).
+  if (P.clamp_limits || P.fence) {
+    bool hit = false;
+    static_for<0, NJ>([&](auto II) { constexpr int i = II; hit = hit | (q[i] < P.lim_lo[i]) | (q[i] > P.lim_hi[i]); });
+    if (limit_hit) *limit_hit = hit;
+    if (P.clamp_limits && hit) {
+      static_for<0, NJ>([&](auto II) {
+        constexpr int i = II;
+        q[i] = q[i] < P.lim_lo[i] ? P.lim_lo[i] : (q[i] > P.lim_hi[i] ? P.lim_hi[i] : q[i]);
+      });
+      sincos_all<T>(q, cq, sq);
+      fk<C, T>(ch, cq, sq, S);
+    }
   }
   if (trig) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; (*trig)[j] = cq[j]; (*trig)[NJ + j] = sq[j]; }); }
   return it;

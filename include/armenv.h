@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define ARMENV_NJ 7
-#define ARMENV_ABI_VERSION 1
+#define ARMENV_ABI_VERSION 2
 
 enum {
   ARMENV_OK = 0,
@@ -85,7 +85,10 @@ typedef struct ArmEnvConfig {
   double dv;               /* /root/reference/config.py:41 (reach 0.02); envs/rl_push_env.py:322 (push 0.08) */
   double reach_dis;        /* config.py:42 */
   int32_t max_steps;       /* config.py:51 ; done when step_counter > max_steps (rl_reach_env.py:299) */
-  int32_t clamp_joint_limits; /* 0 = reference behaviour (limits are dead data, rl_reach_env.py:103-107) */
+  int32_t clamp_joint_limits; /* 0 = reference behaviour (limits are dead data, rl_reach_env.py:103-107, never passed to the
+                                 IK at :244-250); 1 = project the IK result onto chain.limit_lo/hi (the URDF limits of
+                                 envs/bmirobot_joints_info_pybullet.txt:1-7 fields 8-9) -- the hard-limit idealisation of the
+                                 joint-limit constraint Bullet applies inside stepSimulation (:258) */
   double box_lo[3];        /* Cartesian clip, rl_reach_env.py:221-223 */
   double box_hi[3];
   double goal_lo[3];       /* target sampling box, rl_reach_env.py:65-70,180-182 */
@@ -100,7 +103,10 @@ typedef struct ArmEnvConfig {
   int32_t ik_max_iters;    /* 20 */
   int32_t ik_exit_mode;    /* 0 Bullet loop, 1 test-before-update */
   int32_t ik_angle_f32;    /* 1: orientation-error angle rounded through f32 as Bullet does */
-  int32_t reserved0;
+  int32_t fence_counters;  /* 1 (default): count the env steps on which this build's kinematic stepSimulation is known to
+                              differ from Bullet's -- the IK result lies outside the URDF joint limits (Bullet's limit
+                              constraint pushes back), or the step ends with the flange below fence_z (arm-table contact) --
+                              in armenv_counters out[5] / out[6].  Every parity claim is fenced by these two rates. */
 
   /* push task, /root/reference/envs/rl_push_env.py (the pick task, envs/rl_pick_env.py, shares all six) */
   double push_success_dis; /* 0.05  :422 (pick :425) */
@@ -115,7 +121,7 @@ typedef struct ArmEnvConfig {
   double pick_trigger_dis;    /* 0.006 :412 -- p.getClosestPoints distance that closes the gripper */
   double pick_jaw_half;       /* the closing gripper holds the cube when the cube centre is within this horizontal
                                  distance of the tool axis (default: push_cube_half) */
-  double pick_reserved;
+  double fence_z;             /* 0.05 */
 
   ArmEnvChain chain;
 } ArmEnvConfig;
@@ -199,13 +205,16 @@ int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len
                          void *stream);
 
 /* Totals since creation, copied to host (synchronises `stream`): out[0] episodes finished, out[1] successes,
- * out[2] env-steps executed, out[3] non-finite joint states seen, out[4] IK (DLS) updates applied, out[5..7] 0. */
+ * out[2] env-steps executed, out[3] non-finite joint states seen, out[4] IK (DLS) updates applied, out[5] env steps whose IK
+ * result left the URDF joint limits, out[6] env steps that ended with the flange below fence_z (the parity fence, see
+ * ArmEnvConfig.fence_counters), out[7] 0. */
 int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream);
 
 /* Logging summary computed on the device (no host sync; what main.py:130-160 prints/plots from one env): out_dev f64 [8] =
  * [sum over envs of the current distance to the goal (reach: |FK(q) - goal|, push: |cube - target|), max of it, sum of
  * the last finished episodes' returns, sum of their lengths, sum of their success flags, number of envs, 0, 0].
- * Wavefront shuffles reduce each wave's 64 envs; one atomic per wave and quantity reaches HBM. */
+ * Wavefront shuffles reduce each wave's 64 envs into one row per wave; a one-workgroup kernel folds the rows in a fixed order
+ * (no atomics: bitwise reproducible). */
 int armenv_summary(ArmEnv *env, double *out_dev, void *stream);
 
 /* Installs the TD3 actor (PolicyNet, /root/reference/algo/TD3/net_mlp.py:29-40; take_action

@@ -65,6 +65,8 @@ class OrcConfig(C.Structure):
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
+        ("clamp_joint_limits", C.c_int32), ("pad0", C.c_int32), ("lim_lo", C.c_double * NJ), ("lim_hi", C.c_double * NJ),
+        ("fence_z", C.c_double),
     ]
 
 
@@ -112,10 +114,14 @@ def make_chain(robot="kuka", base_xyz=(0, 0, 0), base_rpy=(0, 0, 0)):
     return ch
 
 
-def default_config(task="reach"):
+def default_config(task="reach", robot="kuka"):
     """Constants of RLReachEnv.__init__ (/root/reference/envs/rl_reach_env.py:44-125),
     config.py:41-42,51, and Bullet's IK defaults."""
     c = OrcConfig()
+    c.clamp_joint_limits = 0
+    c.lim_lo[:] = [-x for x in ROBOTS[robot]["limit"]]      # bmirobot_joints_info_pybullet.txt:1-7 fields 8-9 (symmetric)
+    c.lim_hi[:] = list(ROBOTS[robot]["limit"])
+    c.fence_z = 0.05
     c.task = {"reach": 0, "push": 1, "pick": 2}[task]
     c.dv = 0.02 if task == "reach" else 0.08
     c.reach_dis = 0.01
@@ -192,6 +198,14 @@ def ik(chain, cfg, q, tgt):
     out = np.empty_like(q); iters = np.empty(n, dtype=np.int32)
     lib().orc_ik_batch(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(q), _p(tgt), _p(out), _p(iters))
     return out, iters
+
+
+def fence_flags(chain, cfg, q, tgt):
+    """Per env: bit 0 = the (unclamped) IK result leaves the URDF limits, bit 1 = the flange ends below cfg.fence_z."""
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, NJ)
+    tgt = np.ascontiguousarray(tgt, dtype=np.float64).reshape(-1, 3)
+    lib().orc_fence_flags.restype = C.c_int
+    return np.array([lib().orc_fence_flags(C.byref(chain), C.byref(cfg), _p(q[i]), _p(tgt[i])) for i in range(q.shape[0])], dtype=np.int32)
 
 
 def philox(ctr, key):

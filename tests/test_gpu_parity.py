@@ -32,16 +32,13 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def _same_rollout_step(out, t, o, r, d, tol=2e-6):
-    """Row t of a multi-step rollout against the same step run as its own launch.  (cos q, sin q) are re-derived from q
-    at the start of every launch and advanced incrementally inside it, so a T-step launch and T one-step launches start
-    their FKs from values that differ in the last bit.  Bullet's orientation error 2 acos(w) is quantised at
-    3e-8 sqrt(k) rad near convergence (w = 1 - k 2^-53), which turns a last-bit difference into ~1e-7 rad of joint angle
-    -- the same noise floor the GPU / oracle comparisons have (1e-6): flags must be equal, outputs agree to that floor."""
+def _same_rollout_step(out, t, o, r, d):
+    """Row t of a multi-step rollout against the same step run as its own launch: the same bits.  (cos q, sin q) travel
+    with q in the env's state, so a trajectory is a pure function of (state, actions) however the steps are grouped into
+    launches (round 1 re-derived the pair at every launch start and the two agreed only to the IK's 1e-7 rad noise floor)."""
     assert torch.equal(out["done"][t], d), t
-    assert (out["obs"][t] - o).abs().max().item() <= tol, (t, (out["obs"][t] - o).abs().max().item())
-    assert (out["reward"][t] - r).abs().max().item() <= 20 * tol, t
-
+    assert torch.equal(out["obs"][t], o), (t, (out["obs"][t] - o).abs().max().item())
+    assert torch.equal(out["reward"][t], r), t
 
 
 def _actions(rng, n):
@@ -303,6 +300,112 @@ def test_step_teacher_forced_f32(envs, O, kuka):
     assert bad <= 0.002 * 20 * n, bad         # trip-count flips at the 1e-4 residual gate
 
 
+def _limit_fence_states(O, kuka, cfg, n, rng):
+    """Joint states that make the fence fire: perturbed init poses, a third of them with one joint parked just inside one
+    of its URDF limits (bmirobot_joints_info_pybullet.txt:1-7), a tenth driven down to z ~ 0.04 (below fence_z)."""
+    q = np.tile(np.array(O.INIT_Q), (n, 1)) + rng.uniform(-0.3, 0.3, (n, 7))
+    lim = np.array(O.KUKA["limit"])
+    k = n // 3
+    j = rng.integers(0, 7, k)
+    side = rng.choice([-1.0, 1.0], k)
+    q[np.arange(k), j] = side * (lim[j] - rng.uniform(0.0, 0.01, k))
+    low = np.arange(n - n // 10, n)
+    ql = np.tile(np.array(O.INIT_Q), (low.size, 1))
+    tgt = np.column_stack([rng.uniform(0.35, 0.6, low.size), rng.uniform(-0.2, 0.2, low.size), rng.uniform(0.03, 0.06, low.size)])
+    for _ in range(4):
+        ql, _ = O.ik(kuka, cfg, ql, tgt)
+    q[low] = ql
+    return q
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_joint_limit_clamp_and_parity_fence(envs, O, kuka, precision):
+    """N1 / R7.  clamp_joint_limits = 1 projects the IK result onto the URDF limits
+    (/root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7; the reference's own limit arrays, rl_reach_env.py:103-107,
+    are dead data) and is checked teacher-forced against the oracle's projection; the fence counters -- steps whose
+    IK result leaves the limits, steps that end with the flange below fence_z = 0.05 (rl_reach_env.py:258: Bullet's limit
+    constraint / arm-table contact act there, this build's stepSimulation is kinematic) -- against the oracle's flags."""
+    n = 4096
+    rng = np.random.default_rng(123)
+    cfg0, cfg1 = O.default_config(), O.default_config()
+    cfg1.clamp_joint_limits = 1
+    lim = np.array(O.KUKA["limit"])
+    free = _mk(envs, n, auto_reset=False, precision=precision)                            # reference behaviour
+    clamped = _mk(envs, n, auto_reset=False, precision=precision, clamp_joint_limits=1)
+    assert np.allclose(np.array(free.cfg.chain.limit_hi[:]), lim, atol=1e-11) and free.cfg.fence_counters == 1 and free.cfg.fence_z == 0.05
+    tol = 1e-6 if precision == 64 else 1e-4
+    n_lim = n_low = n_low1 = flips = 0
+    for rep in range(3):
+        q = _limit_fence_states(O, kuka, cfg0, n, rng)
+        a = _actions(rng, n)
+        st0, st1 = O.ReachState(n), O.ReachState(n)
+        for st in (st0, st1):
+            st.q[:] = q; st.goal[:] = np.float32([0.45, 0.1, 0.3])
+        p0, _ = O.fk(kuka, q)
+        tgt = np.clip(p0 + 0.02 * a.astype(np.float64), [0.2, -0.3, 0.0], [0.7, 0.3, 0.55])
+        flags0 = O.fence_flags(kuka, cfg0, q, tgt)
+        flags1 = O.fence_flags(kuka, cfg1, q, tgt)
+        for env in (free, clamped):
+            env.reset(); env.set_state(q=q, goal=st0.goal, step=st0.step)
+        c0, c1 = free.counters(), clamped.counters()
+        at = torch.from_numpy(a).to(DEV)
+        obs_f = _np(free.step(at)[0]).copy(); obs_c = _np(clamped.step(at)[0]).copy()
+        obs_r0, *_ = O.reach_step(kuka, cfg0, st0, a)
+        obs_r1, *_ = O.reach_step(kuka, cfg1, st1, a)
+        qf, qc = _np(free.get_state()["q"]), _np(clamped.get_state()["q"])
+        d0, d1 = np.abs(qf - st0.q).max(1), np.abs(qc - st1.q).max(1)
+        ok = (d0 < tol) & (d1 < tol)
+        flips += int((~ok).sum())
+        assert np.abs(obs_f - obs_r0)[ok].max() < max(tol, 2e-7) and np.abs(obs_c - obs_r1)[ok].max() < max(tol, 2e-7)
+        assert (np.abs(qc) <= lim + 1e-12).all()                                   # the projection holds for every env
+        hit = (flags0 & 1) != 0
+        assert np.array_equal(qf[~hit & ok], qc[~hit & ok])                        # envs inside the limits keep their bits
+        assert (np.abs(st0.q[hit]) > lim).any(axis=1).all() and (np.abs(st1.q) <= lim).all()
+        d0c, d1c = free.counters(), clamped.counters()
+        # a residual / limit comparison within rounding of its threshold may differ between the two implementations
+        slack = 2 if precision == 64 else 12
+        assert abs((d0c["limit_steps"] - c0["limit_steps"]) - int(hit.sum())) <= slack
+        assert abs((d1c["limit_steps"] - c1["limit_steps"]) - int(hit.sum())) <= slack
+        assert abs((d0c["low_flange_steps"] - c0["low_flange_steps"]) - int(((flags0 & 2) != 0).sum())) <= slack
+        assert abs((d1c["low_flange_steps"] - c1["low_flange_steps"]) - int(((flags1 & 2) != 0).sum())) <= slack
+        n_lim += int(hit.sum()); n_low += int(((flags0 & 2) != 0).sum())
+    assert n_lim >= 100 and n_low >= 100, (n_lim, n_low)                           # the test has teeth
+    assert flips <= (3 if precision == 64 else 0.01 * 3 * n), flips
+    # fence_counters = 0 switches the bookkeeping off
+    off = _mk(envs, 256, auto_reset=False, fence_counters=0)
+    off.reset(); off.set_state(q=q[:256], goal=st0.goal[:256], step=st0.step[:256]); off.step(at[:256].contiguous())
+    assert off.counters()["limit_steps"] == 0 and off.counters()["low_flange_steps"] == 0
+    for env in (free, clamped, off):
+        env.close()
+
+
+def test_clamp_applies_to_rollouts_and_ik_entry(envs, O, kuka):
+    """The projection inside the rollout kernel and the standalone armenv_ik entry: free-running 60 steps from states at the
+    limits never leaves them, and rollout == step launches bit for bit with the clamp on."""
+    n, T = 1024, 60
+    rng = np.random.default_rng(5)
+    cfg1 = O.default_config(); cfg1.clamp_joint_limits = 1
+    lim = np.array(O.KUKA["limit"])
+    q = _limit_fence_states(O, kuka, cfg1, n, rng)
+    acts = torch.from_numpy(np.stack([_actions(rng, n) for _ in range(T)])).to(DEV)
+    a, b = (_mk(envs, n, seed=2, clamp_joint_limits=1) for _ in range(2))
+    for env in (a, b):
+        env.reset(); env.set_state(q=q)
+    out = a.rollout(T, acts)
+    for t in range(T):
+        o, r, d, s = b.step(acts[t])
+        _same_rollout_step(out, t, o, r, d)
+    qa = _np(a.get_state()["q"])
+    assert (np.abs(qa) <= lim + 1e-12).all() and a.counters()["limit_steps"] > 0
+    assert torch.equal(a.get_state()["q"], b.get_state()["q"])
+    tgt = np.column_stack([rng.uniform(0.2, 0.7, n), rng.uniform(-0.3, 0.3, n), rng.uniform(0.0, 0.55, n)])
+    q_gpu, it_gpu = a.ik(torch.from_numpy(q), torch.from_numpy(tgt))
+    q_ref, it_ref = O.ik(kuka, cfg1, q, tgt)
+    same = _np(it_gpu) == it_ref
+    assert same.mean() > 0.995 and np.abs(_np(q_gpu) - q_ref)[same].max() < 1e-6 and (np.abs(_np(q_gpu)) <= lim + 1e-12).all()
+    a.close(); b.close()
+
+
 def test_reward_done_success_thresholds(envs, O, kuka):
     """Drive the branch of rl_reach_env.py:299-309 through the kernel: goals placed just inside / outside
     reach_dis of where the arm ends up, and step counters around max_steps (strict > and <)."""
@@ -484,31 +587,26 @@ def test_rlreachenv_compat_surface(envs, O, kuka):
 
 @pytest.mark.parametrize("precision", [64, 32])
 def test_rollout_external_actions_equals_step_calls(envs, precision):
-    """armenv_rollout with external actions against T armenv_step launches: the same trajectory (to the re-derivation of
-    (cos q, sin q) at launch boundaries), deterministic, and bit-identical for one-step launches."""
+    """armenv_rollout with external actions against T armenv_step launches: the same trajectory bit for bit (state and
+    counters included), whatever the launch grouping."""
     n, T = 4096 + 64 + 3, 37
     rng = np.random.default_rng(60)
     acts = torch.from_numpy(np.stack([_actions(rng, n) for _ in range(T)])).to(DEV)
     a = _mk(envs, n, seed=9, precision=precision, max_steps=20)       # short episodes: resets inside the rollout
     b = _mk(envs, n, seed=9, precision=precision, max_steps=20)
     a.reset(); b.reset()
-    tol = 2e-6 if precision == 64 else 5e-4
     out = a.rollout(T, acts, want_actions=True, want_terminal_obs=True)
     for t in range(T):
         o, r, d, s = b.step(acts[t], want_terminal_obs=True)
-        _same_rollout_step(out, t, o, r, d, tol)
+        _same_rollout_step(out, t, o, r, d)
         assert torch.equal(out["success"][t], s), t
-        assert (out["terminal_obs"][t] - b.terminal_obs).abs().max().item() <= tol, t
+        assert torch.equal(out["terminal_obs"][t], b.terminal_obs), t
     assert torch.equal(out["actions"], acts)
     sa, sb = a.get_state(), b.get_state()
     for k in sa:
-        if sa[k].is_floating_point():
-            assert (sa[k] - sb[k]).abs().max().item() <= (2e-5 if precision == 64 else 5e-3), k   # ep_return sums 10 |dp| per step
-        else:
-            assert torch.equal(sa[k], sb[k]), k
+        assert torch.equal(sa[k], sb[k]), k
     ca, cb = a.counters(), b.counters()
-    assert all(ca[k] == cb[k] for k in ("episodes", "successes", "env_steps", "nonfinite"))
-    assert abs(ca["ik_updates"] - cb["ik_updates"]) <= 1e-3 * ca["ik_updates"]   # a count flips when a residual sits on the threshold
+    assert all(ca[k] == cb[k] for k in ("episodes", "successes", "env_steps", "nonfinite", "ik_updates"))
     # the SAME launch sequence is deterministic, and a one-step rollout is the step kernel's arithmetic bit for bit
     c = _mk(envs, n, seed=9, precision=precision, max_steps=20); c.reset()
     out_c = c.rollout(T, acts, want_terminal_obs=True)
@@ -522,6 +620,96 @@ def test_rollout_external_actions_equals_step_calls(envs, precision):
     c.close(); d1.close(); d2.close()
     assert a.counters()["episodes"] >= n
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_rollout_500_equals_500_step_launches_bitwise(envs, precision):
+    """The benchmarked launch shape against the gym-style path over a whole reference episode and the reset after it
+    (501 steps, rl_reach_env.py:299): 6 x rollout(100) == one rollout(600) == 600 armenv_step launches, bit for bit."""
+    n, T = 2048, 600
+    gen = torch.Generator(device=DEV); gen.manual_seed(77)
+    acts = (torch.randn((T, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous()
+    a, b, c = (_mk(envs, n, seed=31, precision=precision) for _ in range(3))
+    for e in (a, b, c):
+        e.reset()
+    whole = {k: v.clone() for k, v in a.rollout(T, acts).items()}
+    parts = [{k: v.clone() for k, v in b.rollout(100, acts[k0:k0 + 100].contiguous()).items()} for k0 in range(0, T, 100)]
+    for k in ("obs", "reward", "done", "success"):
+        assert torch.equal(torch.cat([p[k] for p in parts]), whole[k]), k
+    for t in range(T):
+        o, r, d, s = c.step(acts[t])
+        assert torch.equal(whole["obs"][t], o) and torch.equal(whole["reward"][t], r) and torch.equal(whole["done"][t], d), t
+    sa, sb, sc = a.get_state(), b.get_state(), c.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]) and torch.equal(sa[k], sc[k]), k
+    assert a.counters() == b.counters() == c.counters()
+    assert a.counters()["episodes"] >= n          # every env finished its 501-step episode (or reached its goal) and was reset
+    for e in (a, b, c):
+        e.close()
+
+
+def _soak_vs_oracle(envs, O, kuka, n, precision, launches=6, R=100, seed=5):
+    """BASELINE config 2's launch shape -- armenv_rollout(100) launches, 501-step episodes, auto-reset, i.i.d. clipped
+    Gaussian actions -- free-running against the CPU oracle's reach_step_autoreset on the same actions (the loop of
+    /root/reference/main.py:108-128 with the env of rl_reach_env.py:132-319).  Returns per-step worst |obs difference|,
+    the fraction of envs within 1e-4 per step, and the episode / success totals of both sides."""
+    cfg = O.default_config()
+    e = _mk(envs, n, seed=seed, precision=precision)
+    st = O.ReachState(n)
+    O.reach_reset(kuka, cfg, st, seed=seed)
+    e.reset()
+    gen = torch.Generator(device=DEV); gen.manual_seed(9)
+    worst, within, rworst = [], [], []
+    tot = dict(ep_g=0, ep_o=0, su_g=0, su_o=0, flag_diff=0)
+    bufs = {}
+    for b in range(launches):
+        acts = (torch.randn((R, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous()
+        out = e.rollout(R, acts, out=bufs)
+        a_np = _np(acts)
+        obs_g, rew_g, done_g, succ_g = _np(out["obs"]), _np(out["reward"]), _np(out["done"]), _np(out["success"])
+        for t in range(R):
+            obs_o, rew_o, done_o, succ_o, _ = O.reach_step_autoreset(kuka, cfg, st, a_np[t], seed=seed, want_terminal=False)
+            d = np.abs(obs_g[t] - obs_o).max(1)
+            worst.append(d.max()); within.append((d < 1e-4).mean())
+            same = done_g[t] == done_o.astype(bool)
+            tot["flag_diff"] += int((~same).sum())
+            rworst.append(np.abs(rew_g[t].astype(np.float64) - rew_o)[same].max())
+            tot["ep_o"] += int(done_o.sum()); tot["su_o"] += int((done_o.astype(bool) & succ_o.astype(bool)).sum())
+        tot["ep_g"] += int(done_g.sum()); tot["su_g"] += int((done_g & succ_g).sum())
+    q = _np(e.get_state()["q"])
+    cnt = e.counters()
+    e.close()
+    return np.array(worst), np.array(within), np.array(rworst), tot, np.abs(q - st.q).max(1), cnt
+
+
+@pytest.mark.parametrize("n", [8192, 65536])
+def test_benchmarked_launch_shape_free_running_vs_oracle_f64(envs, O, kuka, n):
+    """The headline kernel at the headline shape under the oracle: 6 launches of rollout(100) --
+    a whole 501-step episode, its time-limit reset and 99 steps of the next one, plus every goal reached on the way --
+    at 8 192 envs and at BASELINE config 2's 65 536.  f64 engine: every env, every step within 1e-4 (north_star's
+    tolerance) on the observation and 1e-3 on the reward (= 10 x distance), identical done / success flags, equal episode and
+    success totals."""
+    worst, within, rworst, tot, dq, cnt = _soak_vs_oracle(envs, O, kuka, n, 64)
+    assert tot["flag_diff"] == 0, tot
+    assert tot["ep_g"] == tot["ep_o"] >= n and tot["su_g"] == tot["su_o"], tot
+    assert cnt["episodes"] == tot["ep_g"] and cnt["successes"] == tot["su_g"] and cnt["nonfinite"] == 0
+    assert worst.max() < 1e-4, (worst.max(), int(worst.argmax()))
+    assert within.min() == 1.0
+    assert rworst.max() < 1e-3, rworst.max()
+    assert (dq < 1e-4).mean() > 0.999, (dq < 1e-4).mean()      # joint angles after 600 free-running steps
+
+
+def test_benchmarked_launch_shape_free_running_vs_oracle_f32(envs, O, kuka):
+    """Same shape, f32 engine against the f64 oracle.  The f32 engine's stated tolerance is per step (1e-4 teacher-forced,
+    test_step_teacher_forced_f32); free-running, an IK update count that flips at the 1e-4 residual gate moves an env by up
+    to that residual, so the bound here is statistical: >= 99 % of the envs within 1e-4 at every step, nobody beyond 2e-3,
+    episode totals within 0.1 %."""
+    n = 8192
+    worst, within, rworst, tot, dq, cnt = _soak_vs_oracle(envs, O, kuka, n, 32)
+    assert within.min() > 0.99, within.min()
+    assert worst.max() < 2e-3, worst.max()
+    assert abs(tot["ep_g"] - tot["ep_o"]) <= 1e-3 * tot["ep_o"] and abs(tot["su_g"] - tot["su_o"]) <= max(3, 0.05 * tot["su_o"]), tot
+    assert cnt["nonfinite"] == 0
 
 
 def test_rollout_random_policy_matches_oracle(envs, O, kuka):
@@ -550,8 +738,8 @@ def test_rollout_random_policy_matches_oracle(envs, O, kuka):
     e2.reset()
     o1 = {k: v.clone() for k, v in e2.rollout(23, None, want_actions=True).items()}
     o2 = e2.rollout(T - 23, None, want_actions=True)
-    assert (torch.cat([o1["obs"], o2["obs"]]) - out["obs"]).abs().max().item() <= 2e-6     # launch boundary, see _same_rollout_step
-    assert (torch.cat([o1["actions"], o2["actions"]]) - out["actions"]).abs().max().item() <= 1e-7
+    assert torch.equal(torch.cat([o1["obs"], o2["obs"]]), out["obs"])      # launch grouping does not change a bit
+    assert torch.equal(torch.cat([o1["actions"], o2["actions"]]), out["actions"])
     e.close(); e2.close()
 
 

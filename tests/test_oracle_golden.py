@@ -350,3 +350,36 @@ def test_her_sampler_restatement_matches_reference(task):
     assert np.array_equal(out["actions"], g["actions"]) and np.array_equal(out["dones"], g["dones"])
     assert np.abs(out["rewards"].astype(np.float64) - g["rewards"]).max() < 1e-7      # -0.1 is not exact in f32
     assert 0.1 < g["dones"].mean() < 0.9
+
+
+def test_oracle_joint_limit_projection(O, kuka):
+    """clamp_joint_limits: the oracle's IK result projected onto the URDF limits of
+    /root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7 (fields 8-9, pinned by joint_info.json); results inside the
+    limits are untouched, and the fence flags mark exactly the calls whose unclamped result leaves them."""
+    info = golden_json("joint_info.json")
+    lim = np.array(O.KUKA["limit"])
+    rows = info["kuka"] if isinstance(info, dict) and "kuka" in info else None
+    if rows is not None:
+        for j, r in enumerate(rows[:7]):
+            lo = r.get("lower", r.get("jointLowerLimit")); hi = r.get("upper", r.get("jointUpperLimit"))
+            if lo is not None:
+                assert abs(lo + lim[j]) < 1e-9 and abs(hi - lim[j]) < 1e-9
+    cfg0, cfg1 = O.default_config(), O.default_config()
+    cfg1.clamp_joint_limits = 1
+    assert list(cfg0.lim_hi) == list(lim) and list(cfg0.lim_lo) == list(-lim) and cfg0.fence_z == 0.05
+    rng = np.random.default_rng(0)
+    n = 512
+    q = np.tile(np.array(O.INIT_Q), (n, 1)) + rng.uniform(-0.3, 0.3, (n, 7))
+    j = rng.integers(0, 7, n // 2)
+    q[np.arange(n // 2), j] = rng.choice([-1.0, 1.0], n // 2) * (lim[j] - rng.uniform(0, 0.01, n // 2))
+    p0, _ = O.fk(kuka, q)
+    tgt = np.clip(p0 + rng.normal(0, 0.014, (n, 3)), [0.2, -0.3, 0.0], [0.7, 0.3, 0.55])
+    q0, it0 = O.ik(kuka, cfg0, q, tgt)
+    q1, it1 = O.ik(kuka, cfg1, q, tgt)
+    out = (np.abs(q0) > lim).any(1)
+    assert out.sum() > 20 and np.array_equal(it0, it1)
+    assert np.array_equal(q1, np.clip(q0, -lim, lim)) and np.array_equal(q1[~out], q0[~out])
+    flags = O.fence_flags(kuka, cfg0, q, tgt)
+    assert np.array_equal((flags & 1) != 0, out)
+    p1, _ = O.fk(kuka, q0)
+    assert np.array_equal((flags & 2) != 0, p1[:, 2] < 0.05)
