@@ -39,48 +39,77 @@ def init_process_group(backend=None, device=None):
 
 class ReturnGatherer:
     """All-gathers a per-env f32 vector (episode returns) to every rank, off the step's critical path:
-    on GPUs the collective runs on a side stream that waits for the producer stream only."""
+    on GPUs the collective runs on a side stream that waits for the producer stream only.
+
+    Two (stage, out) slots alternate between launches, and a slot is not refilled before the collective that last used it
+    has completed: an asynchronous all-gather may still be reading `stage` / writing `out` when the next launch arrives
+    (round 1 had one slot and refilled it unconditionally -- a write-after-read hazard).  all_gather_into_tensor needs the
+    same n_local on every rank: `shard_range` gives uneven shards when world does not divide the env count, so the
+    constructor checks."""
 
     def __init__(self, n_local, device, world=None):
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.device = torch.device(device)
-        self.n_local = n_local
-        self.out = torch.zeros(self.world * n_local, dtype=torch.float32, device=self.device)
-        self.stage = torch.zeros(n_local, dtype=torch.float32, device=self.device)
+        self.n_local = int(n_local)
+        self.slots = [dict(stage=torch.zeros(self.n_local, dtype=torch.float32, device=self.device),
+                           out=torch.zeros(self.world * self.n_local, dtype=torch.float32, device=self.device), work=None)
+                      for _ in range(2)]
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
-        self._work = None
+        self.launches = 0
+        self._last = None
+        if self.world > 1 and dist.is_initialized():
+            host = dist.get_backend() != "nccl"
+            t = torch.tensor([self.n_local, -self.n_local], dtype=torch.int64, device="cpu" if host else self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if int(t[0]) != -int(t[1]):
+                raise ValueError("ReturnGatherer: every rank must own the same number of envs (pad the last shard)")
+
+    def _host_backend(self):
+        return self.side is not None and self.world > 1 and dist.get_backend() != "nccl"
 
     def launch(self, local_returns):
         """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs."""
-        if self.side is not None and self.world > 1 and dist.get_backend() != "nccl":
+        if tuple(local_returns.shape) != (self.n_local,):
+            raise ValueError(f"local_returns must have shape ({self.n_local},)")
+        slot = self.slots[self.launches & 1]
+        self.launches += 1
+        self._last = slot
+        if slot["work"] is not None:          # the collective that used this slot two launches ago
+            slot["work"].wait()
+            slot["work"] = None
+        if self._host_backend():
             # debugging path (several ranks sharing one GPU cannot use RCCL): stage through the host with gloo
             host = local_returns.detach().to("cpu", torch.float32)
             parts = [torch.empty_like(host) for _ in range(self.world)]
             dist.all_gather(parts, host)
-            self.out.copy_(torch.cat(parts))
+            slot["out"].copy_(torch.cat(parts))
             return
         if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            cur = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                self.stage.copy_(local_returns)
+                slot["stage"].copy_(local_returns)
+                # the producer's tensor is read on the side stream: keep the caching allocator from recycling it early
+                local_returns.record_stream(self.side)
                 if self.world > 1:
-                    self._work = dist.all_gather_into_tensor(self.out, self.stage, async_op=True)
+                    slot["work"] = dist.all_gather_into_tensor(slot["out"], slot["stage"], async_op=True)
                 else:
-                    self.out.copy_(self.stage)
+                    slot["out"].copy_(slot["stage"])
         else:
-            self.stage.copy_(local_returns)
+            slot["stage"].copy_(local_returns)
             if self.world > 1:
-                parts = [torch.empty_like(self.stage) for _ in range(self.world)]
-                dist.all_gather(parts, self.stage)
-                self.out.copy_(torch.cat(parts))
+                parts = [torch.empty_like(slot["stage"]) for _ in range(self.world)]
+                dist.all_gather(parts, slot["stage"])
+                slot["out"].copy_(torch.cat(parts))
             else:
-                self.out.copy_(self.stage)
+                slot["out"].copy_(slot["stage"])
 
     def result(self):
-        """Block until the last launched gather is complete; returns the [world * n_local] tensor."""
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
+        """Block until every launched gather is complete; returns the [world * n_local] tensor of the last one."""
+        for slot in self.slots:
+            if slot["work"] is not None:
+                slot["work"].wait()
+                slot["work"] = None
         if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
-        return self.out
+        return (self._last or self.slots[0])["out"]

@@ -115,7 +115,7 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->reach_dis = 0.01;
   c->max_steps = 500;
   c->clamp_joint_limits = 0;
-  c->fence_counters = 1;
+  c->fence_counters = 0;   // diagnostics off by default (costs ~6 % of a reach step when the limits are crossed as often as under the random policy)
   c->fence_z = 0.05;   // arm-table contact acts when the flange is driven to z <~ 0.05
   const double lo[3] = {0.2, -0.3, 0.0}, hi[3] = {0.7, 0.3, 0.55};
   for (int k = 0; k < 3; ++k) { c->box_lo[k] = lo[k]; c->box_hi[k] = hi[k]; c->goal_lo[k] = lo[k]; c->goal_hi[k] = hi[k]; }

@@ -5,7 +5,7 @@
 // Data layout in HBM (N envs, T = f64 or f32 by ArmEnvConfig.precision), struct-of-arrays with the env index fastest
 // so that a wave's 64 lanes touch 64 consecutive elements of every array:
 //   q[7][N] T | trig[14][N] T (cos q, sin q) | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
-//   last_len[N] i32 | last_success[N] u8 | counters[N/64][8] u64 (one row per wave) | totals[8] u64 | summary rows[N/64][8] f64 | push: aux[7][N] T | pick: aux[11][N] T
+//   last_len[N] i32 | last_success[N] u8 | counters[N/64][8] u64 (one row per wave) | totals[8] u64 | summary rows[N/64][8] f64 | EnvCold | push: aux[7][N] T | pick: aux[11][N] T
 // Caller-facing buffers keep the reference's array-of-struct shapes (action [N][3], obs [N][6|9]); a wave still
 // reads/writes one contiguous span of them.
 #pragma once
@@ -137,7 +137,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
-    const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_sum = take(64 * (size_t)((n + 63) / 64)), o_tmp = take(sizeof(T) * 32);
+    const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_sum = take(64 * (size_t)((n + 63) / 64)), o_cold = take(sizeof(EnvCold<T>));
     const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n), o_trig = take(sizeof(T) * 2 * NJ * n);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
@@ -153,15 +153,20 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     P.counters = reinterpret_cast<unsigned long long *>(b + o_cnt);
     counter_totals = reinterpret_cast<unsigned long long *>(b + o_tot);
     summary_rows = reinterpret_cast<double *>(b + o_sum);
-    T *tmp = reinterpret_cast<T *>(b + o_tmp);
+    EnvCold<T> *cold_dev = reinterpret_cast<EnvCold<T> *>(b + o_cold);
+    P.cold = cold_dev;
     P.aux = Lane::kAuxRows ? reinterpret_cast<T *>(b + o_aux) : nullptr;
     P.trig = reinterpret_cast<T *>(b + o_trig);
     P.push_success_dis = (T)cfg.push_success_dis;
     P.push_cube_half = (T)cfg.push_cube_half;
     P.push_eef_radius = (T)cfg.push_eef_radius;
-    P.push_rest_z = cfg.push_rest_z;
-    P.push_place_min = cfg.push_place_min;
-    P.push_place_max = cfg.push_place_max;
+    P.push_rest_z = (T)cfg.push_rest_z;
+    EnvCold<T> K{};
+    K.push_rest_z = cfg.push_rest_z;
+    K.push_place_min = cfg.push_place_min;
+    K.push_place_max = cfg.push_place_max;
+    K.seed = cfg.seed;
+    K.env_id0 = cfg.env_id_offset;
     P.pick_gripper_length = (T)cfg.pick_gripper_length;
     P.pick_trigger_dis = (T)cfg.pick_trigger_dis;
     P.pick_jaw_half = (T)cfg.pick_jaw_half;
@@ -174,13 +179,20 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     P.env_id0 = cfg.env_id_offset;
     for (int k = 0; k < 3; ++k) {
       P.box_lo[k] = (T)cfg.box_lo[k]; P.box_hi[k] = (T)cfg.box_hi[k];
-      P.goal_lo[k] = cfg.goal_lo[k]; P.goal_hi[k] = cfg.goal_hi[k];
+      K.goal_lo[k] = cfg.goal_lo[k]; K.goal_hi[k] = cfg.goal_hi[k];
     }
+    double lim_min = 1e300;
     for (int j = 0; j < NJ; ++j) {
-      P.q_init[j] = (T)cfg.q_init[j];
-      P.ik.lim_lo[j] = (T)cfg.chain.limit_lo[j];
-      P.ik.lim_hi[j] = (T)cfg.chain.limit_hi[j];
+      K.q_init[j] = (T)cfg.q_init[j];
+      K.lim[j] = (T)cfg.chain.limit_lo[j];
+      K.lim[NJ + j] = (T)cfg.chain.limit_hi[j];
+      // no joint can be outside [lower, upper] while max |q| <= min(-lower, upper) (as T: the values the kernel compares with)
+      const double a = -(double)K.lim[j], b2 = (double)K.lim[NJ + j];
+      lim_min = std::fmin(lim_min, std::fmin(a, b2));
     }
+    P.ik.lim = cold_dev->lim;
+    P.ik.lim_min = (T)(lim_min > 0.0 ? lim_min : -1.0);
+    if ((double)P.ik.lim_min > lim_min) P.ik.lim_min = std::nextafter(P.ik.lim_min, (T)0);   // the cast must not round up
     for (int k = 0; k < 4; ++k) P.ik.tq[k] = (T)cfg.target_quat[k];
     P.ik.lambda = (T)cfg.ik_lambda;
     P.ik.residual = (T)cfg.ik_residual;
@@ -203,12 +215,10 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
       for (int k = 0; k < 9; ++k) P.chain.base_R[k] = (T)R[k];
       for (int k = 0; k < 3; ++k) P.chain.base_p[k] = (T)cfg.chain.base_xyz[k];
     }
-    hipLaunchKernelGGL((init_consts_kernel<C, T>), dim3(1), dim3(64), 0, 0, P, tmp);
+    HIP_TRY(hipMemcpy(cold_dev, &K, sizeof K, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((init_consts_kernel<C, T>), dim3(1), dim3(64), 0, 0, P, cold_dev);
     HIP_TRY(hipGetLastError());
-    T host_c[3 + 2 * NJ];
-    HIP_TRY(hipMemcpy(host_c, tmp, sizeof host_c, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 3; ++k) P.p_init[k] = host_c[k];
-    P.trig_init = tmp + 3;
+    HIP_TRY(hipDeviceSynchronize());
     kname = std::string(Lane::kName) + "_step<" + (sizeof(T) == 8 ? "f64" : "f32") + "," + C::kName + ">";
     return ARMENV_OK;
   }

@@ -9,6 +9,20 @@
 using namespace armenv;
 
 
+// Handle constants that only the rare paths of a step read -- the in-place reset of a finished env and the joint-limit
+// handling -- kept in device memory behind EnvParams::cold instead of the kernel-argument segment: as arguments they are
+// loaded into scalar registers at kernel entry and stay live across the IK loop, whose own f64 constants then have to be
+// rematerialised (two s_mov each) or spilled to VGPR lanes on every trip.
+template <typename T> struct EnvCold {
+  T q_init[NJ];
+  T p_init[3];          // FK(q_init), computed on the device at create time (init_consts_kernel)
+  T trig_init[2 * NJ];  // cos(q_init)[7], sin(q_init)[7] from the device's own sincos_all
+  T lim[2 * NJ];        // URDF joint limits: lower[7], upper[7]
+  double goal_lo[3], goal_hi[3];
+  double push_rest_z, push_place_min, push_place_max;
+  uint64_t seed, env_id0;
+};
+
 template <typename T> struct EnvParams {
   // state
   T *q;
@@ -30,17 +44,12 @@ template <typename T> struct EnvParams {
   int32_t auto_reset;
   T box_lo[3];
   T box_hi[3];
-  double goal_lo[3];
-  double goal_hi[3];
-  T q_init[NJ];
-  T p_init[3];  // FK(q_init), computed on the device at create time
-  const T *trig_init;  // device: cos(q_init)[7], sin(q_init)[7] from the device's own sincos_all (same bits as a launch start computes);
-                       // read only by a lane that resets in place, so it stays out of the kernel's scalar registers
-  uint64_t seed;
+  const EnvCold<T> *cold;   // device memory: reset / limit constants (see EnvCold)
+  uint64_t seed;            // Philox key and global index of env 0: the fused policy's noise reads them every step
   uint64_t env_id0;
   // push task (rl_push_env.py): simplified pusher model + reward constants
   T push_success_dis, push_cube_half, push_eef_radius;
-  double push_rest_z, push_place_min, push_place_max;
+  T push_rest_z;            // pick: a held cube never sinks below its rest height (placement constants: EnvCold)
   // pick task (rl_pick_env.py): gripper model
   T pick_gripper_length, pick_trigger_dis, pick_jaw_half;
   T fence_z;   // parity fence: steps that end with the flange below this height are counted (ArmEnvConfig.fence_z)
@@ -134,11 +143,12 @@ struct StepIO {
 template <typename T>
 AE_DEV void sample_goal(const EnvParams<T> &P, int64_t i, uint32_t episode, float (&g)[3]) {
   double u0, u1, u2, u3;
-  philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 0u, u0, u1);
-  philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, 1u, u2, u3);
-  g[0] = (float)(P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u0);
-  g[1] = (float)(P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u1);
-  g[2] = (float)(P.goal_lo[2] + (P.goal_hi[2] - P.goal_lo[2]) * u2);
+  const EnvCold<T> &K = *P.cold;
+  philox_pair(K.seed, K.env_id0 + (uint64_t)i, episode, 0u, u0, u1);
+  philox_pair(K.seed, K.env_id0 + (uint64_t)i, episode, 1u, u2, u3);
+  g[0] = (float)(K.goal_lo[0] + (K.goal_hi[0] - K.goal_lo[0]) * u0);
+  g[1] = (float)(K.goal_lo[1] + (K.goal_hi[1] - K.goal_lo[1]) * u1);
+  g[2] = (float)(K.goal_lo[2] + (K.goal_hi[2] - K.goal_lo[2]) * u2);
 }
 
 template <typename T>
@@ -155,18 +165,18 @@ AE_DEV void store_obs9(float *obs, int64_t i, const T (&p)[3], const T (&c)[3], 
   static_for<0, 3>([&](auto KI) { constexpr int k = KI; o[k] = (float)p[k]; o[3 + k] = (float)c[k]; o[6 + k] = (float)t[k]; });
 }
 
-// FK(q_init) once per handle, with the same device code the step uses.
+// FK(q_init) and (cos, sin)(q_init) once per handle, with the same device code the step uses; written into the handle's EnvCold.
 template <class C, typename T>
-__global__ void init_consts_kernel(EnvParams<T> P, T *out) {
+__global__ void init_consts_kernel(EnvParams<T> P, EnvCold<T> *cold) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   T q[NJ];
-  static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = P.q_init[i]; });
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = cold->q_init[i]; });
   FKState<T> S;
   T cq[NJ], sq[NJ];
   sincos_all<T>(q, cq, sq);
   fk<C, T>(P.chain, cq, sq, S);
-  out[0] = S.p[0]; out[1] = S.p[1]; out[2] = S.p[2];
-  static_for<0, NJ>([&](auto II) { constexpr int i = II; out[3 + i] = cq[i]; out[3 + NJ + i] = sq[i]; });
+  cold->p_init[0] = S.p[0]; cold->p_init[1] = S.p[1]; cold->p_init[2] = S.p[2];
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; cold->trig_init[i] = cq[i]; cold->trig_init[NJ + i] = sq[i]; });
 }
 
 // Optional per-wave timeline (make timeline; csrc/exp/run_timeline.py): wall-clock stamps at kernel entry, after
@@ -270,12 +280,12 @@ template <class C, typename T> struct ReachLane {
       sample_goal(P, i, ep, g);
       P.episode[i] = ep + 1u;
     }
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.q_init[j]; });
-    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = P.trig_init[j]; });
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.cold->q_init[j]; });
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = P.cold->trig_init[j]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = g[k]; });
     P.step[i] = 0;
     P.ep_return[i] = T(0);
-    if (obs) store_obs6<T>(obs, i, P.p_init, g);
+    if (obs) store_obs6<T>(obs, i, P.cold->p_init, g);
   }
 
   // distance the logging summary reports: |FK(q) - goal|
@@ -341,7 +351,7 @@ template <class C, typename T> struct ReachLane {
     const int64_t n = P.n;
     FKState<T> S;
     T tgt[3];
-    if constexpr (kTrigRederive > 0) { if (step != 0 && (step & (kTrigRederive - 1)) == 0) derive_trig(); }
+    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) derive_trig(); }
     bool lim_hit = false;
     const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, nullptr, &trig, &lim_hit);  // :237-257
     if (prefetched) prefetch_settle(*prefetched, *next_action);
@@ -371,24 +381,25 @@ template <class C, typename T> struct ReachLane {
     io.success[i] = succ ? 1 : 0;
     if (io.terminal_obs) store_obs6<T>(io.terminal_obs, i, S.p, g);
 
-    if (done) {
+    if (__builtin_expect(done, 0)) {
       P.last_return[i] = ep_ret;
       P.last_len[i] = step;
       P.last_success[i] = succ ? 1 : 0;
       n_done += 1;
       if (succ) n_succ += 1;
     }
-    if (done && P.auto_reset) {
+    if (__builtin_expect(done && P.auto_reset, 0)) {
       const uint32_t ep = P.episode[i];
       sample_goal(P, i, ep, g);
       P.episode[i] = ep + 1u;
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
-      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
-      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig_init[j]; });
+      const EnvCold<T> &K = *P.cold;
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
+      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = K.trig_init[j]; });
       step = 0;
       ep_ret = T(0);
-      store_obs6<T>(io.obs, i, P.p_init, g);
-      cur_obs[0] = (float)P.p_init[0]; cur_obs[1] = (float)P.p_init[1]; cur_obs[2] = (float)P.p_init[2];
+      store_obs6<T>(io.obs, i, K.p_init, g);
+      cur_obs[0] = (float)K.p_init[0]; cur_obs[1] = (float)K.p_init[1]; cur_obs[2] = (float)K.p_init[2];
     } else {
       store_obs6<T>(io.obs, i, S.p, g);                                           // :319
       cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
@@ -416,31 +427,32 @@ template <class C, typename T> struct ReachLane {
 //   pick: seven draws per try (x, y, yaw, x_t, y_t, z_t, yaw_t), target anywhere in the workspace box, 3-D distance.
 template <bool PICK, typename T>
 AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&cube)[3], T (&target)[3]) {
-  double cx = 0, cy = 0, tx = 0, ty = 0, tz = P.push_rest_z;
+  const EnvCold<T> &K = *P.cold;
+  double cx = 0, cy = 0, tx = 0, ty = 0, tz = K.push_rest_z;
   constexpr uint32_t kBlocks = PICK ? 4u : 3u;
   for (uint32_t t = 0; t < 1000u; ++t) {
     double u0, u1, u2, u3, u4, u5;
-    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, kBlocks * t + 0u, u0, u1);
-    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, kBlocks * t + 1u, u2, u3);
-    philox_pair(P.seed, P.env_id0 + (uint64_t)i, episode, kBlocks * t + 2u, u4, u5);
-    cx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u0;
-    cy = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u1;
-    tx = P.goal_lo[0] + (P.goal_hi[0] - P.goal_lo[0]) * u3;
-    ty = P.goal_lo[1] + (P.goal_hi[1] - P.goal_lo[1]) * u4;
+    philox_pair(K.seed, K.env_id0 + (uint64_t)i, episode, kBlocks * t + 0u, u0, u1);
+    philox_pair(K.seed, K.env_id0 + (uint64_t)i, episode, kBlocks * t + 1u, u2, u3);
+    philox_pair(K.seed, K.env_id0 + (uint64_t)i, episode, kBlocks * t + 2u, u4, u5);
+    cx = K.goal_lo[0] + (K.goal_hi[0] - K.goal_lo[0]) * u0;
+    cy = K.goal_lo[1] + (K.goal_hi[1] - K.goal_lo[1]) * u1;
+    tx = K.goal_lo[0] + (K.goal_hi[0] - K.goal_lo[0]) * u3;
+    ty = K.goal_lo[1] + (K.goal_hi[1] - K.goal_lo[1]) * u4;
     const double dx = cx - tx, dy = cy - ty;
     double d;
     if constexpr (PICK) {
-      tz = P.goal_lo[2] + (P.goal_hi[2] - P.goal_lo[2]) * u5;      // 7th draw (u6, the target yaw) is unused
-      const double dz = P.push_rest_z - tz;
+      tz = K.goal_lo[2] + (K.goal_hi[2] - K.goal_lo[2]) * u5;      // 7th draw (u6, the target yaw) is unused
+      const double dz = K.push_rest_z - tz;
       d = ::sqrt(::fma(dx, dx, ::fma(dy, dy, dz * dz)));
     } else {
       d = ::sqrt(::fma(dx, dx, dy * dy));   // both rest at the same z
       (void)u5;
     }
     (void)u2;
-    if (d >= P.push_place_min && d <= P.push_place_max) break;
+    if (d >= K.push_place_min && d <= K.push_place_max) break;
   }
-  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = (T)P.push_rest_z;
+  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = (T)K.push_rest_z;
   target[0] = (T)tx; target[1] = (T)ty; target[2] = (T)tz;
 }
 
@@ -500,15 +512,15 @@ template <class C, typename T, bool PICK> struct CubeLane {
       cube_sample<PICK, T>(P, i, ep, cube, target);
       P.episode[i] = ep + 1u;
     }
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.q_init[j]; });
-    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = P.trig_init[j]; });
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.cold->q_init[j]; });
+    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = P.cold->trig_init[j]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
     const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
     P.aux[(int64_t)6 * n + i] = M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
     if constexpr (PICK) static_for<7, 11>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = T(0); });   // gripper open (:235-238)
     P.step[i] = 0;
     P.ep_return[i] = T(0);
-    if (obs) store_obs9<T>(obs, i, P.p_init, cube, target);
+    if (obs) store_obs9<T>(obs, i, P.cold->p_init, cube, target);
   }
 
   AE_DEV void load(const EnvParams<T> &P, int64_t i) {
@@ -592,7 +604,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
       cube[0] = tip[0] + off[0];
       cube[1] = tip[1] + off[1];
       const T z = tip[2] + off[2];
-      cube[2] = z < (T)P.push_rest_z ? (T)P.push_rest_z : z;
+      cube[2] = z < P.push_rest_z ? P.push_rest_z : z;
       return;
     }
     if (grip == T(0)) {
@@ -623,7 +635,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
     FKState<T> S;
     T tgt[3];
     T p0[3];
-    if constexpr (kTrigRederive > 0) { if (step != 0 && (step & (kTrigRederive - 1)) == 0) derive_trig(); }
+    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) derive_trig(); }
     const T q7 = q[NJ - 1], c7 = trig[NJ - 1], s7 = trig[2 * NJ - 1];
     bool lim_hit = false;
     const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0, &trig, &lim_hit);  // :322-347
@@ -665,25 +677,26 @@ template <class C, typename T, bool PICK> struct CubeLane {
     io.done[i] = done ? 1 : 0;
     io.success[i] = succ ? 1 : 0;
     if (io.terminal_obs) store_obs9<T>(io.terminal_obs, i, S.p, cube, target);
-    if (done) {
+    if (__builtin_expect(done, 0)) {
       P.last_return[i] = ep_ret;
       P.last_len[i] = step;
       P.last_success[i] = succ ? 1 : 0;
       n_done += 1;
       if (succ) n_succ += 1;
     }
-    if (done && P.auto_reset) {
+    if (__builtin_expect(done && P.auto_reset, 0)) {
       const uint32_t ep = P.episode[i];
       cube_sample<PICK, T>(P, i, ep, cube, target);
       P.episode[i] = ep + 1u;
       d_last = dist_ct();                                                         // :243-245
       if constexpr (PICK) { grip = T(0); off[0] = off[1] = off[2] = T(0); }
-      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = P.q_init[j]; });
-      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig_init[j]; });
+      const EnvCold<T> &K = *P.cold;
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
+      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = K.trig_init[j]; });
       step = 0;
       ep_ret = T(0);
-      store_obs9<T>(io.obs, i, P.p_init, cube, target);
-      cur_obs[0] = (float)P.p_init[0]; cur_obs[1] = (float)P.p_init[1]; cur_obs[2] = (float)P.p_init[2];
+      store_obs9<T>(io.obs, i, K.p_init, cube, target);
+      cur_obs[0] = (float)K.p_init[0]; cur_obs[1] = (float)K.p_init[1]; cur_obs[2] = (float)K.p_init[2];
     } else {
       store_obs9<T>(io.obs, i, S.p, cube, target);                               // :308
       cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];

@@ -34,9 +34,14 @@ template <typename T> struct IKParams {
   int32_t exit_mode;
   int32_t angle_f32;
   int32_t clamp_limits;
-  int32_t fence;    // count the steps whose IK result leaves [lim_lo, lim_hi] (ArmEnvConfig.fence_counters)
-  T lim_lo[NJ];
-  T lim_hi[NJ];
+  int32_t fence;    // count the steps whose IK result leaves the URDF limits (ArmEnvConfig.fence_counters)
+  // URDF joint limits: lim[0..6] lower, lim[7..13] upper, in DEVICE MEMORY (EnvCold) -- 28 scalar registers the IK loop
+  // needs for its own constants otherwise (measured: +70 instructions per trip from s_mov rematerialisation and
+  // v_readlane spills with the limits held as kernel arguments).  lim_min = min over joints of min(-lower, upper) (or -1
+  // when a joint's range does not straddle 0): no joint can be outside its limits while max |q_j| <= lim_min, so the
+  // per-step test is six v_max and one compare, and the table is read only by waves that hold a lane beyond it.
+  const T *lim;
+  T lim_min;
 };
 
 // World frame of a link: W holds the rotation as three column vectors W[3*col + row].
@@ -622,17 +627,20 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
   // (counted by the caller); with clamp_limits the result is projected onto the limits -- the hard-limit idealisation
   // of that constraint -- and the frame recomputed, for the lanes that left them only (the others keep their bits).
   if (P.clamp_limits || P.fence) {
+    T m = M::fabs(q[0]);
+    static_for<1, NJ>([&](auto II) { constexpr int i = II; m = M::fmax(m, M::fabs(q[i])); });
     bool hit = false;
-    static_for<0, NJ>([&](auto II) { constexpr int i = II; hit = hit | (q[i] < P.lim_lo[i]) | (q[i] > P.lim_hi[i]); });
-    if (limit_hit) *limit_hit = hit;
-    if (P.clamp_limits && hit) {
-      static_for<0, NJ>([&](auto II) {
-        constexpr int i = II;
-        q[i] = q[i] < P.lim_lo[i] ? P.lim_lo[i] : (q[i] > P.lim_hi[i] ? P.lim_hi[i] : q[i]);
-      });
-      sincos_all<T>(q, cq, sq);
-      fk<C, T>(ch, cq, sq, S);
+    if (__builtin_expect(m > P.lim_min, 0)) {
+      T lo[NJ], hi[NJ];
+      static_for<0, NJ>([&](auto II) { constexpr int i = II; lo[i] = P.lim[i]; hi[i] = P.lim[NJ + i]; });
+      static_for<0, NJ>([&](auto II) { constexpr int i = II; hit = hit | (q[i] < lo[i]) | (q[i] > hi[i]); });
+      if (P.clamp_limits && hit) {
+        static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = q[i] < lo[i] ? lo[i] : (q[i] > hi[i] ? hi[i] : q[i]); });
+        sincos_all<T>(q, cq, sq);
+        fk<C, T>(ch, cq, sq, S);
+      }
     }
+    if (limit_hit) *limit_hit = hit;
   }
   if (trig) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; (*trig)[j] = cq[j]; (*trig)[NJ + j] = sq[j]; }); }
   return it;

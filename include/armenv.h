@@ -103,10 +103,11 @@ typedef struct ArmEnvConfig {
   int32_t ik_max_iters;    /* 20 */
   int32_t ik_exit_mode;    /* 0 Bullet loop, 1 test-before-update */
   int32_t ik_angle_f32;    /* 1: orientation-error angle rounded through f32 as Bullet does */
-  int32_t fence_counters;  /* 1 (default): count the env steps on which this build's kinematic stepSimulation is known to
-                              differ from Bullet's -- the IK result lies outside the URDF joint limits (Bullet's limit
-                              constraint pushes back), or the step ends with the flange below fence_z (arm-table contact) --
-                              in armenv_counters out[5] / out[6].  Every parity claim is fenced by these two rates. */
+  int32_t fence_counters;  /* 1: count the env steps on which this build's kinematic stepSimulation is known to differ from
+                              Bullet's -- the IK result lies outside the URDF joint limits (Bullet's limit constraint pushes
+                              back), or the step ends with the flange below fence_z (arm-table contact) -- in
+                              armenv_counters out[5] / out[6].  Every parity claim is fenced by these two rates (bench.py
+                              reports them for its workload).  0 (default): no bookkeeping in the step. */
 
   /* push task, /root/reference/envs/rl_push_env.py (the pick task, envs/rl_pick_env.py, shares all six) */
   double push_success_dis; /* 0.05  :422 (pick :425) */

@@ -161,51 +161,101 @@ def g10_config_fields():
               open(os.path.join(OUT, "config_fields.json"), "w"), indent=1)
 
 
+def _reference_env_class(fname, methods, module_funcs=()):
+    """The named methods of the env class in /root/reference/<fname> (plus module-level helper functions), compiled from
+    the module's AST into a synthetic class -- the module itself cannot be imported (it imports pybullet / gym).  Returns
+    (class, constants of __init__'s plain `self.x = <literal>` assignments, globals dict whose `p` the caller stubs)."""
+    import types
+    tree = ast.parse(open(os.path.join(REF, fname)).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef))
+    fns = {f.name: f for f in cls.body if isinstance(f, ast.FunctionDef)}
+    consts = {}
+    for st in ast.walk(fns["__init__"]):
+        if (isinstance(st, ast.Assign) and len(st.targets) == 1 and isinstance(st.targets[0], ast.Attribute)
+                and isinstance(st.targets[0].value, ast.Name) and st.targets[0].value.id == "self"):
+            try:
+                consts[st.targets[0].attr] = ast.literal_eval(st.value)
+            except ValueError:
+                pass
+    body = [f for f in tree.body if isinstance(f, ast.FunctionDef) and f.name in module_funcs]
+    body.append(ast.ClassDef(name="Env", bases=[], keywords=[], body=[fns[m] for m in methods], decorator_list=[]))
+    mod = ast.fix_missing_locations(ast.Module(body=body, type_ignores=[]))
+    sys.path.insert(0, REF)
+    from config import opt                       # the reference's own config object (importable: torch + numpy only)
+    g = {"np": np, "random": random, "opt": opt, "p": types.SimpleNamespace()}
+    exec(compile(mod, fname, "exec"), g)
+    return g["Env"], consts, g
+
+
 def g5_reward_truth():
-    max_steps, reach_dis = 500, 0.01   # config.py:51, :42
+    """EXECUTES RLReachEnv._reward (/root/reference/envs/rl_reach_env.py:267-319, extracted from the module's AST) with a
+    stub `p` that hands it a flange position and a target position, for step counters and distances around the
+    thresholds of :299-309.  The row's distance is the one the reference computed (float64 tuple minus float32 array, :281)."""
+    import types
+    Env, consts, g = _reference_env_class("envs/rl_reach_env.py", ["_reward"])
+    from config import opt
     rows = []
+    target = np.array([0.45, 0.10, 0.30], dtype=np.float32)
     for step in (1, 250, 499, 500, 501, 502):
-        for d in (0.0, 0.005, 0.0099, 0.01, 0.0101, 0.05, 0.3):
-            # envs/rl_reach_env.py:299-309
-            if step > max_steps:
-                r, done, succ = -d * 10, True, False
-            elif d < reach_dis:
-                r, done, succ = 0.0, True, True
-            else:
-                r, done, succ = -d * 10, False, False
-            rows.append({"step_counter": step, "distance": d, "reward": r, "done": done, "success": succ})
-    json.dump({"max_steps": max_steps, "reach_dis": reach_dis, "rows": rows,
-               "source": "envs/rl_reach_env.py:299-309"},
+        for d in (0.0, 0.005, 0.0099, 0.0099999, 0.01, 0.0100001, 0.0101, 0.05, 0.3):
+            robot = (float(target[0]) + d, float(target[1]), float(target[2]))
+            g["p"].getLinkState = lambda body, link, _r=robot: (None, None, None, None, _r, (0.0, 0.0, 0.0, 1.0))
+            g["p"].getBasePositionAndOrientation = lambda body, _t=target: (tuple(float(x) for x in _t), (0.0, 0.0, 0.0, 1.0))
+            env = Env()
+            env.__dict__.update(consts)
+            env.__dict__.update(kuka_id=0, object_id=1, num_joints=7, step_counter=step,
+                                max_steps_one_episode=opt.max_steps_one_episode)
+            random.seed(0)
+            obs, reward, done, succ = env._reward()
+            assert obs.dtype == np.float32 and obs.shape == (6,)
+            rows.append({"step_counter": step, "robot": list(robot), "target": [float(x) for x in target],
+                         "distance": float(env.distance), "reward": float(reward), "reward_is_int_zero": isinstance(reward, int),
+                         "done": bool(done), "success": bool(succ), "obs": [float(x) for x in obs]})
+    json.dump({"max_steps": int(opt.max_steps_one_episode), "reach_dis": float(opt.reach_dis), "rows": rows,
+               "numpy": np.__version__,
+               "source": "RLReachEnv._reward (envs/rl_reach_env.py:267-319) executed from its AST with a stub pybullet"},
               open(os.path.join(OUT, "reward_truth.json"), "w"), indent=1)
 
 
 def g7_push_reward_truth():
-    """(cube, target, d_last, step_counter) -> (reward, done, is_success, new d_last) of envs/rl_push_env.py:387-432,
-    evaluated with explicit dtypes: object_state/target_state are float32 (:378-384), their norm is float32 (:400),
-    comparisons against Python floats happen in float64 (numpy 1.x scalar promotion, the reference's era)."""
-    max_steps = 500
+    """EXECUTES RLPushEnv._reward with _get_obs / _is_success / goal_distance (/root/reference/envs/rl_push_env.py:38-41,
+    258-308, 368-445, extracted from the module's AST) with a stub `p` that hands it flange, cube and target positions.
+    Rows: (cube, target, d_last, step_counter) -> (reward, done, info['is_success'], new d_last).  The float32 / float64
+    mix is whatever the reference's expressions produce under the numpy running this script (recorded in the fixture;
+    numpy >= 2 keeps float32 scalar x Python number in float32, numpy 1.x -- the reference's era -- promoted it to float64:
+    the two differ by one float32 rounding of the timeout reward, < 2e-6, and not at all in the flags)."""
+    Env, consts, g = _reference_env_class("envs/rl_push_env.py", ["_reward", "_get_obs", "_is_success"], ["goal_distance"])
+    from config import opt
     rows = []
     target = np.array([0.45, 0.10, 0.01])
+    robot = (0.53, 0.0, 0.05)
     for step in (1, 499, 500, 501):
         for off, d_last in ((0.2300, 0.2300), (0.2300, 0.2300 + 5e-6), (0.2300, 0.2312), (0.2200, 0.2300),
-                            (0.0501, 0.0600), (0.0499, 0.0600), (0.05, 0.07), (0.0, 0.03)):
+                            (0.0501, 0.0600), (0.0499, 0.0600), (0.05, 0.07), (0.0500001, 0.07), (0.0499999, 0.07), (0.0, 0.03)):
             cube = target + np.array([off, 0.0, 0.0])
-            d_cur = float(np.linalg.norm(cube - target))                       # :388 (f64 obs)
-            test = d_cur - d_last                                              # :390-392
-            if abs(test) < 1e-5:
-                test = 0.01                                                    # :393-394
-            dt32 = np.linalg.norm(cube.astype(np.float32) - target.astype(np.float32))   # :400, float32
-            assert dt32.dtype == np.float32
-            if step > max_steps:
-                reward, done = float(np.float32(-dt32 * np.float32(50))), True  # :418-420
-            elif float(dt32) < 0.05:
-                reward, done = 100.0, True                                     # :422-424
-            else:
-                reward, done = -test * 100, False                              # :427-428
-            succ = bool(d_cur < 0.05)                                          # :430-432, 442-445
-            rows.append({"cube": cube.tolist(), "target": target.tolist(), "d_last": d_last, "step_counter": step,
-                         "reward": reward, "done": done, "success": succ, "d_new": d_cur})
-    json.dump({"max_steps": max_steps, "rows": rows, "source": "envs/rl_push_env.py:387-432"},
+            poses = {1: tuple(cube), 2: tuple(target)}
+            g["p"].getLinkState = lambda body, link, computeLinkVelocity=0: (None, None, None, None, robot, (0.0, 0.0, 0.0, 1.0),
+                                                                              (0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+            g["p"].getBasePositionAndOrientation = lambda body, _p=poses: (_p[body], (0.0, 0.0, 0.0, 1.0))
+            g["p"].getEulerFromQuaternion = lambda q: (0.0, 0.0, 0.0)
+            g["p"].getBaseVelocity = lambda body: ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+            env = Env()
+            env.__dict__.update(consts)
+            # the reference keeps the previous step's positions (:243-245, :396-397); a previous cube at d_last from the target
+            env.__dict__.update(kuka_id=0, object_id=1, target_object_id=2, num_joints=7, step_counter=step,
+                                max_steps_one_episode=opt.max_steps_one_episode,
+                                last_object_pos=target + np.array([d_last, 0.0, 0.0]), last_target_pos=target.copy())
+            random.seed(0)
+            obs, reward, done, info = env._reward()
+            assert obs.shape == (9,) and obs.dtype == np.float64
+            d_prev = float(np.linalg.norm(env.__dict__["distance_last"]))
+            rows.append({"cube": cube.tolist(), "target": target.tolist(), "d_last": d_prev, "step_counter": step,
+                         "reward": float(reward), "done": bool(done), "success": bool(info["is_success"] > 0.5),
+                         "is_success_dtype": str(np.asarray(info["is_success"]).dtype),
+                         "d_new": float(env.distance_current), "obs": [float(x) for x in obs]})
+    json.dump({"max_steps": int(opt.max_steps_one_episode), "rows": rows, "numpy": np.__version__,
+               "source": "RLPushEnv._reward / _get_obs / _is_success (envs/rl_push_env.py:258-308,368-445) executed from "
+                         "their AST with a stub pybullet"},
               open(os.path.join(OUT, "push_reward_truth.json"), "w"), indent=1)
 
 

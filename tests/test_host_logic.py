@@ -186,7 +186,8 @@ def test_create_fails_loudly_without_gpu():
 def test_product_never_imports_oracle():
     """The product package must not reference oracle/ in any form."""
     pkg = os.path.join(ROOT, "drl-on-robot-arm_amd")
-    for dp, _, fns in os.walk(pkg):
+    for dp, dns, fns in os.walk(pkg):
+        dns[:] = [d for d in dns if d != "build"]          # build/ holds objects and A/B scratch builds, never product source
         for fn in fns:
             if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
                 txt = open(os.path.join(dp, fn)).read()

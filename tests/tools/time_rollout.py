@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Kernel-time probe for A/B work on the rollout / step kernels (HIP events, steady clocks, no oracle):
+  [ARMENV_LIB=<other build>] python tests/tools/time_rollout.py [--task reach] [--envs 65536] [--T 100] [--launches 20]
+      [--pre 0] [--precision 64] [--set key=value ...] [--step-api]
+Prints one line: us per env-step-batch (kernel time per step), IK updates per env-step, episodes finished in the timed part.
+--pre N runs N steps first (N >= 501 puts the envs past their first time-limit reset, i.e. desynchronised episodes)."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "drl-on-robot-arm_amd"))
+import torch
+from armenv import envs
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--task", default="reach"); ap.add_argument("--envs", type=int, default=65536)
+ap.add_argument("--T", type=int, default=100); ap.add_argument("--launches", type=int, default=20)
+ap.add_argument("--pre", type=int, default=0); ap.add_argument("--precision", type=int, default=64)
+ap.add_argument("--set", nargs="*", default=[]); ap.add_argument("--step-api", action="store_true")
+ap.add_argument("--policy", default="external")
+a = ap.parse_args()
+dev = "cuda:0"
+Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv, pick=envs.BatchedPickEnv)[a.task]
+kw = {}
+for kv in a.set:
+    k, v = kv.split("="); kw[k] = float(v) if "." in v else int(v)
+n, T = a.envs, a.T
+sig, clip = (0.686, 0.7) if a.task == "reach" else (0.392, 1e9)
+gen = torch.Generator(device=dev); gen.manual_seed(1000)
+S = max(T, min(1000, (1 << 30) // (12 * n)))
+pool = (torch.randn((S, n, 3), device=dev, generator=gen) * sig).clamp_(-clip, clip)
+# warm the clocks on a scratch handle
+w = Env(n, device=dev, seed=99, precision=a.precision); w.set_policy("random"); w.reset()
+t0 = time.time(); b = {}
+while time.time() - t0 < 0.2:
+    w.rollout(100, None, out=b); torch.cuda.synchronize()
+w.close(); del b
+e = Env(n, device=dev, seed=0, precision=a.precision, **kw)
+if a.policy != "external":
+    e.set_policy(a.policy)
+e.reset()
+cur = [0]
+def nxt(r):
+    if cur[0] + r > S: cur[0] = 0
+    x = pool[cur[0]:cur[0] + r]; cur[0] += r; return x
+bufs = {}
+def run(steps):
+    if a.step_api:
+        for _ in range(steps): e.step(nxt(1)[0])
+    else:
+        for _ in range(steps // T): e.rollout(T, nxt(T) if a.policy == "external" else None, out=bufs)
+run(a.pre - a.pre % T if not a.step_api else a.pre)
+run(2 * T)
+torch.cuda.synchronize()
+c0 = e.counters()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(a.launches * T); e1.record(); torch.cuda.synchronize()
+c1 = e.counters()
+steps = a.launches * T
+print("%s lib=%s task=%s n=%d T=%d pre=%d %s: %.3f us/step  %.3f G env-steps/s  updates/env-step %.3f  episodes %d  limit %.2e low %.2e" % (
+    "step-api" if a.step_api else "rollout", os.path.basename(os.environ.get("ARMENV_LIB", "current")), a.task, n, T, a.pre, " ".join(a.set),
+    e0.elapsed_time(e1) * 1e3 / steps, n * steps / (e0.elapsed_time(e1) * 1e-3) / 1e9,
+    (c1["ik_updates"] - c0["ik_updates"]) / (n * steps), c1["episodes"] - c0["episodes"],
+    (c1.get("limit_steps", 0) - c0.get("limit_steps", 0)) / (n * steps), (c1.get("low_flange_steps", 0) - c0.get("low_flange_steps", 0)) / (n * steps)))
