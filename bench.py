@@ -15,14 +15,21 @@ MI355X ramps for ~30 ms, tests/tools/clock_ramp.py).  Two launch shapes run the 
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
                  beside the headline and reported under "step_api".
 Rank 0 prints ONE JSON line.
-The CPU oracle is timed beside it (rank 0, N=1 only) on a bounded sample -- as a baseline, never as
-the thing measured.
+The CPU oracle is timed beside it (rank 0, N=1 only) on a bounded sample -- one thread, then every core the process may
+use -- as a baseline, never as the thing measured.  A short extra leg on a second handle with the parity-fence counters on
+reports how often the workload crosses the URDF joint limits / drives the flange below z = 0.05 (where Bullet's
+stepSimulation does something this kinematic engine does not: DESIGN.md section 2).
+
+The driver runs `--steps 20 --warmup 5`: ONE 20-step launch in the timed region.  Everything but the C call is prepared
+before the clock starts (armenv's bind_rollout), and profiles/traffic.json holds the PMC traffic of that launch shape too.
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+os.environ.setdefault("OMP_PROC_BIND", "close")   # cpu_baseline: OpenMP threads pinned (read when libgomp starts, i.e. at `import torch`)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "drl-on-robot-arm_amd")):
@@ -38,37 +45,52 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X f64 vector (FMA = 2 flop), 1/2 of the 157.3 TF f32 vector peak
 # algorithmic bytes: caller I/O per env-step, and state read+written once per launch
 IO_BYTES = 12 + 24 + 4 + 1 + 1                 # action in; obs, reward, done, success out
-STATE_BYTES = {64: 2 * (56 + 8) + 12 + 2 * 4, 32: 2 * (28 + 4) + 12 + 2 * 4}   # q, ep_return r+w; goal r; step r+w
+# q, (cos q, sin q), ep_return read + written; goal read; step read + written
+STATE_BYTES = {64: 2 * (56 + 112 + 8) + 12 + 2 * 4, 32: 2 * (28 + 56 + 4) + 12 + 2 * 4}
 # algorithmic flops of the f64/f32 reach step: per IK update and per FK-only exit trip
 FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + residual + per-step sincos/reward
 
 
-def cpu_baseline(precision, seconds=12.0):
-    """Oracle (C, fp64, OpenMP over envs) on the same workload: 65 536 envs, same action distribution."""
+def cpu_baseline(precision, seconds=8.0):
+    """Oracle (C, fp64, gcc -O3 -march=native, OpenMP over envs) on the same workload -- same action distribution, auto-reset --
+    timed twice on a bounded sample: ONE thread (8 192 envs) and every core this process may use (65 536 envs;
+    `cores` = affinity mask capped by the cgroup CPU quota, oracle.usable_cores)."""
     from oracle import oracle as O
     O.build()
     chain, cfg = O.make_chain("kuka"), O.default_config()
-    n = ENVS_PER_GPU
-    st = O.ReachState(n)
-    O.reach_reset(chain, cfg, st, seed=0)
+    cores = O.usable_cores()
     rng = np.random.default_rng(0)
-    # i.i.d. actions per step like the device pool (a short cycle of action arrays would pin the envs in a corner of the box)
-    A = np.clip(rng.standard_normal((256, n, 3), dtype=np.float32) * np.float32(0.686), -0.7, 0.7)
-    O.reach_step_autoreset(chain, cfg, st, A[0], seed=0, want_terminal=False)   # warm-up
-    t0 = time.perf_counter(); k = 0
-    while True:
-        O.reach_step_autoreset(chain, cfg, st, A[k % 256], seed=0, want_terminal=False)
-        k += 1
-        dt = time.perf_counter() - t0
-        if (dt >= seconds and k >= 3) or k >= 2000:
-            break
+
+    def leg(n, threads, budget):
+        O.set_num_threads(threads)
+        st = O.ReachState(n)
+        O.reach_reset(chain, cfg, st, seed=0)
+        # i.i.d. actions per step like the device pool (a short cycle of action arrays would pin the envs in a corner of the box)
+        A = np.clip(rng.standard_normal((64, n, 3), dtype=np.float32) * np.float32(0.686), -0.7, 0.7)
+        O.reach_step_autoreset(chain, cfg, st, A[0], seed=0, want_terminal=False)   # warm-up
+        t0 = time.perf_counter(); k = 0
+        while True:
+            O.reach_step_autoreset(chain, cfg, st, A[k % 64], seed=0, want_terminal=False)
+            k += 1
+            dt = time.perf_counter() - t0
+            if (dt >= budget and k >= 3) or k >= 5000:
+                break
+        return n * k / dt, k, dt
+
+    v1, k1, d1 = leg(8192, 1, seconds * 0.6)
+    va, ka, da = leg(ENVS_PER_GPU, cores["usable"], seconds)
     try:                      # BASELINE.md section 3, row B2: the metric's own "PyBullet CPU path", only if it exists here
         import pybullet  # noqa: F401
         pyb = "installed (not timed by this script)"
     except Exception as e:    # expected: the wheel is not in the image and there is no network
         pyb = "unavailable: %s" % e
-    return {"value": n * k / dt, "unit": "env-steps/s", "cores": O.num_threads(), "kind": "port",
-            "sample": f"{k} steps x {n} envs of the same reach workload in {dt:.1f}s, C oracle fp64, OpenMP",
+    return {"value": va, "unit": "env-steps/s", "cores": cores["usable"], "kind": "port",
+            "sample": f"{ka} steps x {ENVS_PER_GPU} envs of the same reach workload in {da:.1f}s on {cores['usable']} threads "
+                      f"(C oracle fp64, gcc -O3 -march=native, OpenMP, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
+            "threads_1": {"value": v1, "unit": "env-steps/s", "cores": 1,
+                          "sample": f"{k1} steps x 8192 envs in {d1:.1f}s on one thread"},
+            "parallel_efficiency": va / (v1 * cores["usable"]),
+            "host": {"affinity_cpus": cores["affinity"], "cgroup_cpu_quota": cores["cgroup_quota"], "os_cpu_count": os.cpu_count()},
             "pybullet": pyb}
 
 
@@ -109,6 +131,39 @@ def step_api_graph(env, pool, next_actions, n, k2, dev):
     return {"value": n * k3 / w3, "unit": "env-steps/s", "steps": k3, "steps_per_graph": G,
             "avg_launch_us": e0.elapsed_time(e1) * 1e3 / k3}
 
+def parity_fence(Env, n, dev, args, pool):
+    """The same workload on a second handle with the fence counters on (ArmEnvConfig.fence_counters): the share of env
+    steps whose IK result lies outside the URDF joint limits (Bullet's limit constraint would push back inside
+    stepSimulation, /root/reference/envs/rl_reach_env.py:258) or that end with the flange below z = 0.05 (arm-table
+    contact).  On those steps this engine's kinematic stepSimulation is known to differ from Bullet's; counted over the
+    second half of the leg (steady state: past the first time-limit resets), with the cost of the bookkeeping."""
+    T = 100
+    k = max(2, args.fence_steps // T)
+    S = pool.shape[0]
+    out, res = {}, {}
+    for fence in (1, 0):
+        e = Env(n, device=dev, seed=0, precision=args.precision, fence_counters=fence)
+        e.reset()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for j in range(k):
+            if j == k // 2:
+                c0 = e.counters(); ev0.record()
+            lo = (j * T) % (S - T + 1)
+            e.rollout(T, pool[lo:lo + T], out=out)
+        ev1.record(); torch.cuda.synchronize(dev)
+        c1 = e.counters()
+        res[fence] = (c0, c1, ev0.elapsed_time(ev1))
+        e.close()
+    c0, c1, ms_on = res[1]
+    steps = c1["env_steps"] - c0["env_steps"]
+    return {"limit_step_rate": (c1["limit_steps"] - c0["limit_steps"]) / steps,
+            "low_flange_step_rate": (c1["low_flange_steps"] - c0["low_flange_steps"]) / steps,
+            "fence_z": 0.05, "env_steps_counted": steps, "steps_before_counting": (k // 2) * T,
+            "bookkeeping_cost_frac": ms_on / res[0][2] - 1.0,
+            "meaning": "share of env steps on which Bullet's stepSimulation (joint-limit constraint / arm-table contact) "
+                       "acts and this kinematic engine's does not; parity claims hold outside them"}
+
+
 def prewarm_device(Env, n, dev, precision, ms):
     """Bring the GPU to its steady clocks with the same kind of work on a scratch handle (in-kernel random policy, outputs
     discarded).  From idle the first ~3 000 steps (30 ms) of the headline workload run 10-25 % slower than the rest
@@ -141,6 +196,12 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--gather-every", type=int, default=100, help="steps between episode-return all-gathers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--state-digest", action="store_true",
+                    help="add config.state_digest: per rank, the sha256 of the joint angles of its envs right after the timed "
+                         "region (tests: rank shards reproduce the single-handle trajectory)")
+    ap.add_argument("--fence-steps", type=int, default=1200,
+                    help="length of the extra parity-fence leg (second handle, fence_counters=1; 0 = skip): how often this "
+                         "workload leaves the URDF joint limits / drives the flange below z = 0.05")
     ap.add_argument("--task", default="reach", choices=["reach", "push", "pick"],
                     help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768); "
                          "pick = the next-row env (SURVEY.md section 8f.4)")
@@ -208,35 +269,55 @@ def main():
         cursor[0] += r
         return a
 
-    def run(k):
-        """exactly k env steps of every env of this rank"""
+    def do_gather():
+        gather.launch(env.episode_stats()[0])
+
+    def plan(k):
+        """The launches of exactly k env steps of every env of this rank, prepared up front (buffers, pointers, the
+        positions of the logging all-gathers): what remains for the timed region is one C call per launch.
+        Multi-rank runs fire the episode-return all-gather every --gather-every steps AND at least once per region."""
+        ops, gathers = [], 0
         if args.mode == "step":
             for i in range(k):
-                env.step(next_actions(1)[0])
+                a = next_actions(1)[0]
+                ops.append(lambda a=a: env.step(a))
                 if world > 1 and (i + 1) % args.gather_every == 0:
-                    gather.launch(env.episode_stats()[0])
-            return k
-        done_steps, launches = 0, 0
-        while done_steps < k:
-            r = min(R, k - done_steps)
-            a_in = None if args.policy != "external" else next_actions(r)
-            env.rollout(r, a_in, out=bufs if r == R else None)
-            done_steps += r; launches += 1
-            if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
-                gather.launch(env.episode_stats()[0])
+                    ops.append(do_gather); gathers += 1
+        else:
+            done_steps = 0
+            while done_steps < k:
+                r = min(R, k - done_steps)
+                a_in = None if args.policy != "external" else next_actions(r)
+                launch, _ = env.bind_rollout(r, a_in, out=bufs if r == R else None)
+                ops.append(launch)
+                done_steps += r
+                if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
+                    ops.append(do_gather); gathers += 1
+        if world > 1 and gathers == 0:
+            ops.append(do_gather); gathers = 1
+        launches = sum(1 for o in ops if o is not do_gather)
+        return ops, launches, gathers
+
+    def run(k):
+        ops, launches, gathers = plan(k)
+        for op in ops:
+            op()
         return launches
 
     def timed(k):
+        ops, launches, gathers = plan(k)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
+        c0 = env.counters()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0 = env.counters()
         t0 = time.perf_counter()
         ev0.record()
-        launches = run(k)
+        for op in ops:
+            op()
         ev1.record()
+        ev1.synchronize()            # spin on the event: the stream's work is done when it returns
         torch.cuda.synchronize(dev)
         if world > 1:
             gather.result()
@@ -245,24 +326,32 @@ def main():
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
         c1 = env.counters()
-        return wall, ev0.elapsed_time(ev1), launches, {k_: c1[k_] - c0[k_] for k_ in c1}
+        return wall, ev0.elapsed_time(ev1), launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}
 
     prewarm_device(Env, n, dev, args.precision, args.prewarm_ms)
     run(args.warmup)
-    wall, gpu_ms, launches, dc = timed(args.steps)
+    wall, gpu_ms, launches, gathers, dc = timed(args.steps)
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
     counters = env.counters()
+    digests = None
+    if args.state_digest:
+        import hashlib
+        mine = hashlib.sha256(env.get_state()["q"].cpu().numpy().tobytes()).hexdigest()
+        digests = [mine]
+        if world > 1:
+            digests = [None] * world
+            dist.all_gather_object(digests, mine)
 
     step_api = None
     if args.mode == "rollout" and world == 1 and args.policy == "external":
         args.mode = "step"                      # the gym-style one-launch-per-step path, timed beside the headline
         k2 = min(args.steps, 500)
         run(10)
-        w2, g2, _, _ = timed(k2)
+        w2, g2, _, _, _ = timed(k2)
         step_api = {"value": n * k2 / w2, "unit": "env-steps/s", "steps": k2, "avg_launch_us": g2 * 1e3 / k2,
                     "kernel": env.kernel_name}
         # the same launches replayed from a hipGraph (50 armenv_step calls per graph): host launch cost removed
@@ -305,18 +394,21 @@ def main():
             st_b += 2 * (7 if args.task == "push" else 11) * (args.precision // 8) - 12
         algo = (io_b * steps_per_launch + st_b) * n   # bytes one launch moves, algorithmically
         achieved = algo / (launch_us * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from separate rocprofv3 --pmc passes (profiles/README.md)
-        if os.path.exists(tpath):
+        # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md), one entry per launch shape:
+        # "<kernel>|policy=<p>|T=<steps per launch>|N=<envs>"; only an exact match is reported
+        traffic, traffic_key = None, "%s|policy=%s|T=%d|N=%d" % (kernel, args.policy, int(steps_per_launch), n)
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and steps_per_launch == int(steps_per_launch):
             try:
-                tj = json.load(open(tpath)).get(kernel, {})
-                # measured per launch at one launch shape: only valid for the same steps per launch and batch size
-                if tj.get("steps_per_launch") == steps_per_launch and tj.get("envs", ENVS_PER_GPU) == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(traffic_key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         updates = dc["ik_updates"] / max(1, dc["env_steps"])
         flops = (updates * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n * steps_per_launch
+        vpeak = F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3
+        valu = {"bound": "valu", "achieved": flops / (launch_us * 1e-6) / 1e12, "peak": vpeak, "unit": "TFLOP/s",
+                "frac": flops / (launch_us * 1e-6) / 1e12 / vpeak, "ik_updates_per_env_step": updates,
+                "algo_flops_per_launch": flops}
         pol_txt = {"external": "random policy %s pre-generated in HBM as an i.i.d. [steps, N, 3] pool, step() throughput only",
                    "random": "random policy %s generated in-kernel (Philox)",
                    "actor": "TD3 actor forward (exact f32 MFMA) + exploration noise %s fused into the step kernel",
@@ -333,17 +425,19 @@ def main():
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
-                       "steps_per_launch": steps_per_launch, "device_prewarm_ms": args.prewarm_ms,
-                       "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps (logging only)"
+                       "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
+                       "gathers_in_timed_region": gathers, "state_digest": digests,
+                       "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps and at least once per "
+                                      "timed region (logging only)"
                                       % (world, "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: debug)", args.gather_every)
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo},
-            # the path is VALU-bound, not HBM-bound: the same launch against the f64 vector peak
-            "roofline_valu": {"achieved": flops / (launch_us * 1e-6) / 1e12, "peak": F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3,
-                              "unit": "TFLOP/s", "ik_updates_per_env_step": updates,
-                              "frac": flops / (launch_us * 1e-6) / 1e12 / (F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_key": traffic_key,
+                         "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
+                         # the bound that BINDS: 29 flop/B puts the path right of
+                         # the ridge -- the same launch against the f64 (f32) vector peak
+                         "binding_bound": "valu", "valu": valu},
+            "roofline_valu": valu,
             "episodes_finished": counters["episodes"], "nonfinite_states": counters["nonfinite"],
         }
         if args.policy.startswith("actor"):
@@ -360,6 +454,8 @@ def main():
             line["step_api"] = step_api
         if in_kernel:
             line["in_kernel_policy"] = in_kernel
+        if world == 1 and args.fence_steps > 0:
+            line["parity_fence"] = parity_fence(Env, n, dev, args, pool)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.precision)
         print(json.dumps(line), flush=True)

@@ -152,6 +152,15 @@ class BatchedArmEnv:
         """`steps` env steps of all envs in one kernel launch (the inner loop of main.py:108-128).
         actions: float32 [steps, N, 3] on the device, or None to use the fused policy (set_policy).
         Returns a dict of [steps, N, ...] tensors: obs, reward, done, success (+ actions, terminal_obs)."""
+        launch, out = self.bind_rollout(steps, actions, out, want_actions, want_terminal_obs, stream=self._stream())
+        launch()
+        return out
+
+    def bind_rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, stream=None):
+        """Everything `rollout` does except the launch: argument checks, output buffers, pointer and stream resolution.
+        Returns (launch, out): `launch()` enqueues the T-step kernel with one ctypes call into armenv_rollout (on the
+        stream that was current at bind time, or `stream`), `out` is the dict `rollout` returns.  For callers that issue
+        the same launch repeatedly or want nothing but the C call on their critical path (bench.py's timed region)."""
         n, dev, T = self.num_envs, self.device, int(steps)
         if actions is not None:
             if actions.device != dev or actions.dtype != torch.float32 or tuple(actions.shape) != (T, n, 3) \
@@ -171,11 +180,18 @@ class BatchedArmEnv:
         succ = buf("success_u8", (T, n), torch.uint8)
         acts = buf("actions", (T, n, 3), torch.float32) if want_actions else None
         term = buf("terminal_obs", (T, n, self.obs_dim), torch.float32) if want_terminal_obs else None
-        L.check(self._lib.armenv_rollout(self._h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(succ),
-                                         _ptr(acts), _ptr(term), self._stream()))
         out["done"] = done.view(torch.bool)
         out["success"] = succ.view(torch.bool)
-        return out
+        fn, h = self._lib.armenv_rollout, self._h
+        args = (h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(succ), _ptr(acts), _ptr(term),
+                stream if stream is not None else self._stream())
+        keep = (actions, obs, rew, done, succ, acts, term)     # the closure keeps the tensors alive
+
+        def launch(_fn=fn, _args=args, _check=L.check, _keep=keep):
+            rc = _fn(*_args)
+            if rc:
+                _check(rc)
+        return launch, out
 
     # ------------------------------------------------------------------ engine calls the reference makes
     def fk(self, q):

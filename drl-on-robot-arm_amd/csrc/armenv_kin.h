@@ -587,20 +587,20 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
   // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced
   // incrementally, otherwise cos/sin are recomputed from q
   const bool small_steps = P.max_dtheta <= T(0.7854);
+  // The loop is written rotated -- FK of the start pose and the target ahead of it, the FK of each updated pose at its
+  // bottom -- so that the target's inputs (action, dv, the workspace box: 14 scalar registers) are dead across the trips.
+  fk<C, T>(ch, cq, sq, S);
+  if constexpr (FROM_ACTION) {
+    if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
+    static_for<0, 3>([&](auto KI) {
+      constexpr int k = KI;
+      T v = M::fma(a[k], dv, START_F32 ? (T)(float)S.p[k] : S.p[k]);
+      v = v < box_lo[k] ? box_lo[k] : v;   // clip_val, rl_reach_env.py:225-230
+      v = v > box_hi[k] ? box_hi[k] : v;
+      tgt[k] = v;
+    });
+  }
   for (;; ++it) {
-    fk<C, T>(ch, cq, sq, S);
-    if constexpr (FROM_ACTION) {
-      if (it == 0) {
-        if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
-        static_for<0, 3>([&](auto KI) {
-          constexpr int k = KI;
-          T v = M::fma(a[k], dv, START_F32 ? (T)(float)S.p[k] : S.p[k]);
-          v = v < box_lo[k] ? box_lo[k] : v;   // clip_val, rl_reach_env.py:225-230
-          v = v > box_hi[k] ? box_hi[k] : v;
-          tgt[k] = v;
-        });
-      }
-    }
     T e[6];
     e[0] = tgt[0] - S.p[0];
     e[1] = tgt[1] - S.p[1];
@@ -620,6 +620,7 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
       sincos_all<T>(q, cq, sq);
     }
     diff2_prev = diff2;
+    fk<C, T>(ch, cq, sq, S);
   }
   // URDF joint limits (/root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7, fields 8-9).  The reference never passes
   // them to the IK (rl_reach_env.py:103-107 are dead data, :244-250), so q may leave them; Bullet then pushes the joint

@@ -20,7 +20,27 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "build", "liboracle.so")
+
+
+def _host_tag():
+    """The oracle is compiled -march=native: one object per host CPU model (the build container and the GPU box differ)."""
+    import hashlib
+    model = flags = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and not model:
+                model = ln.split(":", 1)[1].strip()
+            if ln.startswith("flags") and not flags:
+                flags = ln.split(":", 1)[1].strip()
+            if model and flags:
+                break
+    except OSError:
+        pass
+    return hashlib.sha1((model + "|" + flags).encode()).hexdigest()[:10]
+
+
+_TAG = _host_tag()
+_SO = os.path.join(_HERE, "build", f"liboracle-{_TAG}.so")
 
 NJ = 7
 H = 1.57079632679      # the URDF text value, not math.pi/2
@@ -74,7 +94,7 @@ def build(force=False):
     """Compile the oracle with gcc (no GPU, no reference sources involved)."""
     src = os.path.join(_HERE, "armenv_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-s", "-C", _HERE, f"TAG={_TAG}"] + (["-B"] if force else []))
     return _SO
 
 
@@ -300,6 +320,31 @@ def actor_forward(sd, states, action_bound):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(C.c_int(int(n)))
+
+
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one
+    (a container with 128 visible CPUs and a quota of 16 runs 128 OpenMP threads at 1/8 speed each)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.999)))
+    return dict(affinity=n, cgroup_quota=quota, usable=eff)
 
 
 def reach_outcome(cfg, dist, step_counter):

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Turns the raw rocprofv3 outputs of profiles/collect.sh (gpurun_out/prof/) into the summaries kept in profiles/:
-  r01_kernel_stats_<config>.csv   --stats tables, armenv kernels only
-  r01_bench_<config>.json         the bench.py line of the same run
-  r01_pmc_default_bench_f64.json  per-launch means of every counter for the rollout / step kernels of the default bench
-  r01_pmc_actor_f16x3.json        same for the fused f16x3 actor rollout kernel
+"""Turns the raw rocprofv3 outputs of profiles/collect.sh (gpurun_out/prof/) into the summaries kept in profiles/
+(ROUND = r02 unless given as argv[1]):
+  <round>_kernel_stats_<config>.csv   --stats tables, armenv kernels only (config "driver" = `bench.py --steps 20 --warmup 5`)
+  <round>_bench_<config>.json         the bench.py line of the same run
+  <round>_pmc_default_bench_f64.json  per-launch means of every counter for the rollout / step kernels of the default bench
+  <round>_pmc_actor_f16x3.json        same for the fused f16x3 actor rollout kernel
+  <round>_pmc_push_pick.json          VALU instructions / wave cycles of the push and pick rollout kernels (32 768 envs)
   traffic.json                    HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; gfx950 reports
-                                  half of the fetched bytes, MI355X_MICROARCH.md HBM section) -- read by bench.py
+                                  half of the fetched bytes, MI355X_MICROARCH.md HBM section) -- read by bench.py; one entry
+                                  per launch shape, keyed "<kernel>|policy=<p>|T=<steps per launch>|N=<envs>"
 Only launches with the full step count are averaged (the warm-up launch of a different length is dropped by taking the
 most frequent duration class: launches whose duration is within 30 % of the median)."""
 import collections
@@ -15,10 +18,12 @@ import json
 import os
 import shutil
 import statistics
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def short(name):
@@ -69,32 +74,37 @@ def main():
     for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):
         cfg = os.path.basename(f)[: -len("_kernel_stats.csv")]
         rows = [l for i, l in enumerate(open(f)) if i == 0 or any(s in l for s in ("env_", "actor_", "her_", "index_episodes"))]
-        open(os.path.join(DST, f"r01_kernel_stats_{cfg}.csv"), "w").writelines(rows)
+        open(os.path.join(DST, f"{ROUND}_kernel_stats_{cfg}.csv"), "w").writelines(rows)
         b = os.path.join(SRC, f"{cfg}_bench.json")
         if os.path.exists(b) and open(b).read().strip().startswith("{"):
-            shutil.copy(b, os.path.join(DST, f"r01_bench_{cfg}.json"))
+            shutil.copy(b, os.path.join(DST, f"{ROUND}_bench_{cfg}.json"))
     default = pmc(sorted(glob.glob(os.path.join(SRC, "pmc[0-9]_counters.csv"))), short)
-    json.dump(default, open(os.path.join(DST, "r01_pmc_default_bench_f64.json"), "w"), indent=1)
+    if default:
+        json.dump(default, open(os.path.join(DST, f"{ROUND}_pmc_default_bench_f64.json"), "w"), indent=1)
     actor = pmc(sorted(glob.glob(os.path.join(SRC, "pmc_actor*_counters.csv"))), short)
-    json.dump(actor, open(os.path.join(DST, "r01_pmc_actor_f16x3.json"), "w"), indent=1)
+    if actor:
+        json.dump(actor, open(os.path.join(DST, f"{ROUND}_pmc_actor_f16x3.json"), "w"), indent=1)
+    pp = {t: pmc([f], short) for t in ("push", "pick") for f in glob.glob(os.path.join(SRC, f"pmc_{t}_counters.csv"))}
+    if pp:
+        json.dump(pp, open(os.path.join(DST, f"{ROUND}_pmc_push_pick.json"), "w"), indent=1)
+    # HBM traffic per launch shape
+    tpath = os.path.join(DST, "traffic.json")
     traffic = {}
-    names = {"rollout": "reach_rollout<f64,kuka>", "step": "reach_step<f64,kuka>"}
-    spl = 50
-    try:   # steps per rollout launch of the profiled default bench
-        spl = int(json.load(open(os.path.join(SRC, "default_bench.json")))["config"]["steps_per_launch"])
-    except Exception:
-        pass
-    steps = {"rollout": spl, "step": 1}
-    for k, name in names.items():
-        if k in default and "FETCH_SIZE" in default[k] and "WRITE_SIZE" in default[k]:
-            fe, wr = default[k]["FETCH_SIZE"]["mean_per_launch"], default[k]["WRITE_SIZE"]["mean_per_launch"]
-            traffic[name] = {"hbm_bytes_per_launch": (2 * fe + wr) * 1024, "fetch_size_kb_raw": fe, "write_size_kb_raw": wr,
-                             "steps_per_launch": steps[k]}
-    traffic["_note"] = ("FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over `bench.py --steps 500 --warmup 50` "
-                        "(KiB per launch, mean over launches, N=65536; profiles/collect.sh + aggregate.py). "
-                        "hbm_bytes_per_launch = 2*FETCH + WRITE: FETCH doubled per the gfx950 note in MI355X_MICROARCH.md "
-                        "(HBM section).")
-    json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
+    shapes = {"": 100, "_T20": 20}    # suffix of the pmc3 / pmc4 passes -> steps per rollout launch (profiles/collect.sh B100 / B20)
+    for suf, T in shapes.items():
+        d = pmc(sorted(glob.glob(os.path.join(SRC, f"pmc[34]{suf}_counters.csv"))), short)
+        for k, T_k, name in (("rollout", T, "reach_rollout<f64,kuka>"), ("step", 1, "reach_step<f64,kuka>")):
+            if k in d and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k]:
+                fe, wr = d[k]["FETCH_SIZE"]["mean_per_launch"], d[k]["WRITE_SIZE"]["mean_per_launch"]
+                key = "%s|policy=external|T=%d|N=65536" % (name, T_k)
+                traffic[key] = {"hbm_bytes_per_launch": (2 * fe + wr) * 1024, "fetch_size_kb_raw": fe, "write_size_kb_raw": wr,
+                                "launches_averaged": d[k]["FETCH_SIZE"]["launches"], "round": ROUND}
+    traffic["_note"] = ("FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over bench.py (KiB per launch, mean over "
+                        "launches, N=65536; profiles/collect.sh + aggregate.py). hbm_bytes_per_launch = 2*FETCH + WRITE: FETCH "
+                        "doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section).  Keys: "
+                        "<kernel>|policy=<p>|T=<steps per launch>|N=<envs>; bench.py reports `roofline.traffic` only for an "
+                        "exact match of its own launch shape (T=20 is the driver's `--steps 20`).")
+    json.dump(traffic, open(tpath, "w"), indent=1)
     print(json.dumps(traffic, indent=1))
     for k in ("rollout", "step"):
         if k in default:
@@ -103,6 +113,9 @@ def main():
             print(k, {c: g(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")})
     if "rollout" in actor:
         print("actor rollout", {c: v["mean_per_launch"] for c, v in actor["rollout"].items() if not c.startswith("_")}, actor["rollout"]["_meta"])
+    for t, d in pp.items():
+        if "rollout" in d:
+            print(t, {c: v["mean_per_launch"] for c, v in d["rollout"].items() if not c.startswith("_")})
 
 
 if __name__ == "__main__":

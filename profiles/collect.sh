@@ -1,7 +1,7 @@
 #!/bin/bash
-# Collects the round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
+# Collects a round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only)
-# Writes under gpurun_out/prof/; profiles/aggregate.py turns the PMC passes into the JSON summaries kept in profiles/.
+# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r02_*).
 # PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
 set -u
 REPO=$(pwd)
@@ -12,17 +12,18 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 stats() {   # name, bench args...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
   find "$OUT/$name" -name '*kernel_stats.csv' -exec cp {} "$OUT/${name}_kernel_stats.csv" \;
   grep -h "^{\"metric\"" "$OUT/$name.log" | tail -1 > "$OUT/${name}_bench.json"
 }
 if [ "$MODE" = "all" ]; then
-stats default                                   # the headline command (with cpu_baseline)
-stats actor_f16x3 --policy actor_f16x3 --steps 1000 --no-cpu-baseline
-stats actor_f32 --policy actor --steps 500 --no-cpu-baseline
+stats driver --steps 20 --warmup 5               # the driver's own command (with cpu_baseline and the parity-fence leg)
+stats default                                     # bench.py defaults: 5 000 steps, 100 per launch
+stats actor_f16x3 --policy actor_f16x3 --steps 1000 --no-cpu-baseline --fence-steps 0
+stats actor_f32 --policy actor --steps 500 --no-cpu-baseline --fence-steps 0
 stats push32768 --task push --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
 stats pick32768 --task pick --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
-stats f32engine --precision 32 --steps 1000 --no-cpu-baseline
+stats f32engine --precision 32 --steps 1000 --no-cpu-baseline --fence-steps 0
 fi
 # one small counter set per pass: a set the hardware cannot collect in one pass makes rocprofv3 abort and then hang in its
 # signal handler (FETCH_SIZE + WRITE_SIZE + GRBM_GUI_ACTIVE did), hence the timeouts
@@ -31,18 +32,26 @@ pmc() {   # name, counters..., then -- bench args
   local ctrs=()
   while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
   shift
-  timeout 240 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
+  timeout 300 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
   find "$OUT/$name" -name '*counter_collection.csv' -exec cp {} "$OUT/${name}_counters.csv" \;
 }
-if [ "${1:-all}" = "all" ]; then
-pmc pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES -- --steps 500 --warmup 50 --no-cpu-baseline
-pmc pmc2 SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- --steps 500 --warmup 50 --no-cpu-baseline
+B100="--steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0"
+B20="--steps 200 --warmup 20 --rollout-steps 20 --no-cpu-baseline --fence-steps 0"    # the driver's launch shape, ten launches
+if [ "$MODE" = "all" ]; then
+pmc pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES -- $B100
+pmc pmc2 SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- $B100
+pmc pmc5 GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- $B100
 fi
-pmc pmc3 FETCH_SIZE -- --steps 500 --warmup 50 --no-cpu-baseline
-pmc pmc4 WRITE_SIZE -- --steps 500 --warmup 50 --no-cpu-baseline
-pmc pmc5 GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- --steps 500 --warmup 50 --no-cpu-baseline
-pmc pmc_actor SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- --policy actor_f16x3 --steps 200 --no-cpu-baseline
-pmc pmc_actor2 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- --policy actor_f16x3 --steps 200 --no-cpu-baseline
+pmc pmc3 FETCH_SIZE -- $B100
+pmc pmc4 WRITE_SIZE -- $B100
+pmc pmc3_T20 FETCH_SIZE -- $B20
+pmc pmc4_T20 WRITE_SIZE -- $B20
+if [ "$MODE" = "all" ]; then
+pmc pmc_actor SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- --policy actor_f16x3 --steps 200 --no-cpu-baseline --fence-steps 0
+pmc pmc_actor2 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- --policy actor_f16x3 --steps 200 --no-cpu-baseline --fence-steps 0
+pmc pmc_push SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- --task push --envs-per-gpu 32768 --steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0
+pmc pmc_pick SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- --task pick --envs-per-gpu 32768 --steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0
+fi
 # keep only the summaries (the raw trees are large)
 find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 ls -la "$OUT"
