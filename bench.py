@@ -29,18 +29,47 @@ import os
 import sys
 import time
 
-os.environ.setdefault("OMP_PROC_BIND", "close")   # cpu_baseline: OpenMP threads pinned (read when libgomp starts, i.e. at `import torch`)
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "drl-on-robot-arm_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 import numpy as np
+
+ENVS_PER_GPU = 65536
+
+
+def _cpu_leg(n, threads, budget):
+    """One timed leg of the CPU oracle: `n` envs, `threads` OpenMP threads, about `budget` seconds.  Runs in a child process
+    of its own (no torch, OMP_PROC_BIND=close set before libgomp starts) so that thread pinning never touches the process
+    that drives the GPU."""
+    from oracle import oracle as O
+    O.build()
+    chain, cfg = O.make_chain("kuka"), O.default_config()
+    O.set_num_threads(threads)
+    rng = np.random.default_rng(0)
+    st = O.ReachState(n)
+    O.reach_reset(chain, cfg, st, seed=0)
+    # i.i.d. actions per step like the device pool (a short cycle of action arrays would pin the envs in a corner of the box)
+    A = np.clip(rng.standard_normal((64, n, 3), dtype=np.float32) * np.float32(0.686), -0.7, 0.7)
+    O.reach_step_autoreset(chain, cfg, st, A[0], seed=0, want_terminal=False)   # warm-up
+    t0 = time.perf_counter(); k = 0
+    while True:
+        O.reach_step_autoreset(chain, cfg, st, A[k % 64], seed=0, want_terminal=False)
+        k += 1
+        dt = time.perf_counter() - t0
+        if (dt >= budget and k >= 3) or k >= 5000:
+            break
+    return {"value": n * k / dt, "steps": k, "seconds": dt, "threads": O.num_threads()}
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--cpu-leg":      # child of cpu_baseline(): python bench.py --cpu-leg N THREADS SECONDS
+    print(json.dumps(_cpu_leg(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))))
+    sys.exit(0)
+
 import torch
 import torch.distributed as dist
 
-ENVS_PER_GPU = 65536
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X f64 vector (FMA = 2 flop), 1/2 of the 157.3 TF f32 vector peak
 # algorithmic bytes (DESIGN.md section 4): caller I/O per env-step, and state read+written once per launch
@@ -54,42 +83,33 @@ FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + resid
 def cpu_baseline(precision, seconds=8.0):
     """Oracle (C, fp64, gcc -O3 -march=native, OpenMP over envs) on the same workload -- same action distribution, auto-reset --
     timed twice on a bounded sample: ONE thread (8 192 envs) and every core this process may use (65 536 envs;
-    `cores` = affinity mask capped by the cgroup CPU quota, oracle.usable_cores)."""
+    `cores` = affinity mask capped by the cgroup CPU quota, oracle.usable_cores).  Each leg is a child process."""
+    import subprocess
     from oracle import oracle as O
     O.build()
-    chain, cfg = O.make_chain("kuka"), O.default_config()
     cores = O.usable_cores()
-    rng = np.random.default_rng(0)
 
     def leg(n, threads, budget):
-        O.set_num_threads(threads)
-        st = O.ReachState(n)
-        O.reach_reset(chain, cfg, st, seed=0)
-        # i.i.d. actions per step like the device pool (a short cycle of action arrays would pin the envs in a corner of the box)
-        A = np.clip(rng.standard_normal((64, n, 3), dtype=np.float32) * np.float32(0.686), -0.7, 0.7)
-        O.reach_step_autoreset(chain, cfg, st, A[0], seed=0, want_terminal=False)   # warm-up
-        t0 = time.perf_counter(); k = 0
-        while True:
-            O.reach_step_autoreset(chain, cfg, st, A[k % 64], seed=0, want_terminal=False)
-            k += 1
-            dt = time.perf_counter() - t0
-            if (dt >= budget and k >= 3) or k >= 5000:
-                break
-        return n * k / dt, k, dt
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", str(n), str(threads), str(budget)],
+                           env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError("cpu_baseline child failed: " + r.stderr[-1000:])
+        return json.loads(r.stdout.strip().splitlines()[-1])
 
-    v1, k1, d1 = leg(8192, 1, seconds * 0.6)
-    va, ka, da = leg(ENVS_PER_GPU, cores["usable"], seconds)
+    one = leg(8192, 1, seconds * 0.6)
+    full = leg(ENVS_PER_GPU, cores["usable"], seconds)
     try:                      # BASELINE.md section 3, row B2: the metric's own "PyBullet CPU path", only if it exists here
         import pybullet  # noqa: F401
         pyb = "installed (not timed by this script)"
     except Exception as e:    # expected: the wheel is not in the image and there is no network
         pyb = "unavailable: %s" % e
-    return {"value": va, "unit": "env-steps/s", "cores": cores["usable"], "kind": "port",
-            "sample": f"{ka} steps x {ENVS_PER_GPU} envs of the same reach workload in {da:.1f}s on {cores['usable']} threads "
-                      f"(C oracle fp64, gcc -O3 -march=native, OpenMP, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
-            "threads_1": {"value": v1, "unit": "env-steps/s", "cores": 1,
-                          "sample": f"{k1} steps x 8192 envs in {d1:.1f}s on one thread"},
-            "parallel_efficiency": va / (v1 * cores["usable"]),
+    return {"value": full["value"], "unit": "env-steps/s", "cores": full["threads"], "kind": "port",
+            "sample": f"{full['steps']} steps x {ENVS_PER_GPU} envs of the same reach workload in {full['seconds']:.1f}s on "
+                      f"{full['threads']} threads (C oracle fp64, gcc -O3 -march=native, OpenMP, OMP_PROC_BIND=close)",
+            "threads_1": {"value": one["value"], "unit": "env-steps/s", "cores": 1,
+                          "sample": f"{one['steps']} steps x 8192 envs in {one['seconds']:.1f}s on one thread"},
+            "parallel_efficiency": full["value"] / (one["value"] * full["threads"]),
             "host": {"affinity_cpus": cores["affinity"], "cgroup_cpu_quota": cores["cgroup_quota"], "os_cpu_count": os.cpu_count()},
             "pybullet": pyb}
 
@@ -304,33 +324,43 @@ def main():
             op()
         return launches
 
+    host_us = {}
+
     def timed(k):
         ops, launches, gathers = plan(k)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(); ev1.record()   # torch creates the HIP event at its first record(): 40 us that do not belong to the region
         torch.cuda.synchronize(dev)
         c0 = env.counters()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
+        p = time.perf_counter
+        t0 = p()
         ev0.record()
+        ta = p()
         for op in ops:
             op()
+        tb = p()
         ev1.record()
+        tc = p()
         ev1.synchronize()            # spin on the event: the stream's work is done when it returns
-        torch.cuda.synchronize(dev)
+        td = p()
         if world > 1:
             gather.result()
             torch.cuda.synchronize(dev)
             dist.barrier()
         torch.cuda.synchronize(dev)
-        wall = time.perf_counter() - t0
+        wall = p() - t0
+        host_us.update(event0_record=(ta - t0) * 1e6, enqueue=(tb - ta) * 1e6, event1_record=(tc - tb) * 1e6,
+                       wait_for_gpu=(td - tc) * 1e6, closing_syncs=(t0 + wall - td) * 1e6)
         c1 = env.counters()
         return wall, ev0.elapsed_time(ev1), launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}
 
     prewarm_device(Env, n, dev, args.precision, args.prewarm_ms)
     run(args.warmup)
     wall, gpu_ms, launches, gathers, dc = timed(args.steps)
+    host_us_main = dict(host_us)
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -427,6 +457,9 @@ def main():
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
                        "gathers_in_timed_region": gathers, "state_digest": digests,
+                       # where the wall clock of the timed region went on the host (us): recording the two HIP events,
+                       # enqueueing the launches, waiting for the GPU, the closing synchronisations
+                       "host_us": host_us_main,
                        "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps and at least once per "
                                       "timed region (logging only)"
                                       % (world, "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: debug)", args.gather_every)
