@@ -236,15 +236,30 @@ AE_DEV void glds16(const void *src_base, unsigned voff, unsigned lds_dst) {
                : "memory");
 }
 
-// fragment f = 2 tile + (0 hi | 1 lo) of k-step ks -> ring slot ks mod R
-AE_DEV void actor_ring_fill_one(const ActorParamsH &H, uint4 *ring, int ks, int f) {
+// A wave-uniform 64-bit value as an OPAQUE pair of scalar registers.  A pointer read straight from the kernel-argument
+// segment is rematerialisable: under scalar-register pressure the compiler re-reads it where it is used, and inside the
+// k-loop of actor_forward_wg_f16x3 it did so with a VECTOR load from the argument segment followed by s_waitcnt vmcnt(0)
+// -- a compiler-made VMEM wait that drains the ring's DMA queue (found by tests/test_isa_guard.py).  An opaque value can
+// only be kept in SGPRs or parked in a VGPR lane (v_readlane: no memory, no wait).
+AE_DEV uint64_t scalar_opaque(uint64_t v) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// fragment f = 2 tile + (0 hi | 1 lo) of k-step ks -> ring slot ks mod R; w2h / w2l: byte addresses of the packed W2 hi / lo
+AE_DEV void actor_ring_fill_one(uint64_t w2h, uint64_t w2l, uint4 *ring, int ks, int f) {
   const unsigned voff = (threadIdx.x & 63u) * 16u;
   const unsigned base = (unsigned)(uintptr_t)ring + (unsigned)(actor_region(ks) * 16 * 64 * 16);
-  const uint64_t a = (uint64_t)(uintptr_t)(((f & 1) ? H.W2L : H.W2H) + (ks * 8 + (f >> 1)) * 64);
+  const uint64_t a = ((f & 1) ? w2l : w2h) + (uint64_t)(unsigned)((ks * 8 + (f >> 1)) * 64) * sizeof(half8);
   // wave-uniform by construction; readfirstlane tells the compiler so (the asm wants SGPR operands)
   const uint64_t au = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
   glds16(reinterpret_cast<const void *>(au), voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)(f * 1024))));
+}
+AE_DEV void actor_ring_fill_one(const ActorParamsH &H, uint4 *ring, int ks, int f) {
+  actor_ring_fill_one((uint64_t)(uintptr_t)H.W2H, (uint64_t)(uintptr_t)H.W2L, ring, ks, f);
 }
 // the whole k-step: wave w takes f = w, w + nw, ... (four each when all four waves of the workgroup are live)
 AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int ks, int nw) {
@@ -275,6 +290,8 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
   const unsigned voff16 = (threadIdx.x & 63u) * 16u;
   uint64_t fill_src[4];
   unsigned fill_dst[4];
+  // bases for the ragged-workgroup refill inside the k-loop (nw < 4: the last workgroup of a batch that is not a multiple of 256)
+  const uint64_t w2h_base = scalar_opaque((uint64_t)(uintptr_t)H.W2H), w2l_base = scalar_opaque((uint64_t)(uintptr_t)H.W2L);
   {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     static_for<0, 4>([&](auto FI) {
@@ -386,8 +403,10 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
             if (nw == 4)
               glds16(reinterpret_cast<const void *>(fill_src[fi] + (uint64_t)(unsigned)kf * (8u * 64u * 16u)), voff16,
                      fill_dst[fi] + (unsigned)actor_region(kf) * (16u * 64u * 16u));
-            else if (m == 1)
-              actor_ring_fill(H, ring, kf, nw);
+            else if (m == 1) {
+              const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+              for (int f = wave; f < 16; f += nw) actor_ring_fill_one(w2h_base, w2l_base, ring, kf, f);
+            }
           }
         }
         // slots 8..23: one LDS read each of k-step ks + 1's fragments; odd k-steps: half of the relu / split of a pair

@@ -61,7 +61,7 @@ template <typename T> struct EnvParams {
 // counters[i >> 6][8] = {episodes, successes, env steps (row 0 only), non-finite, IK updates, joint-limit steps, low-flange steps}; the wave sums its lanes
 // and ONE lane does a plain read-modify-write of the row -- launches on a stream are serialised, nobody else touches it.
 // Why not atomicAdd on one address: same-address atomics execute one at a time at the memory side of the fabric,
-// 12 ns each from anywhere on the chip (csrc/exp/launch_probe.hip: 4096 waves x 1 atomic = 50 us; per-wave rows =
+// 12 ns each from anywhere on the chip (tests/tools/exp/launch_probe.hip: 4096 waves x 1 atomic = 50 us; per-wave rows =
 // nothing), and the kernel cannot complete before they have.  One atomic per wave was 12 us of every 24 us
 // armenv_step launch at 65536 envs.
 // wave_sum: a count v of b significant bits costs b ballots + popcounts on the scalar unit, no cross-lane data moves.
@@ -179,7 +179,7 @@ __global__ void init_consts_kernel(EnvParams<T> P, EnvCold<T> *cold) {
   static_for<0, NJ>([&](auto II) { constexpr int i = II; cold->trig_init[i] = cq[i]; cold->trig_init[NJ + i] = sq[i]; });
 }
 
-// Optional per-wave timeline (make timeline; csrc/exp/run_timeline.py): wall-clock stamps at kernel entry, after
+// Optional per-wave timeline (make timeline; tests/tools/exp/run_timeline.py): wall-clock stamps at kernel entry, after
 // the state loads, after the IK loop and at exit, plus IK update count and placement.  Off in the product build.
 #ifdef ARMENV_TIMELINE
 static __device__ unsigned long long *g_timeline;   // [16 launches][waves][8]

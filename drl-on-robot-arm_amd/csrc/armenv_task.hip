@@ -19,7 +19,7 @@ EngineBase *ARMENV_CAT(armenv_make_engine_, ARMENV_TU_TASK, ARMENV_TU_PREC)(cons
   return make_task_engine<ARMENV_LANE(ARMENV_TU_TASK), ARMENV_REAL(ARMENV_TU_PREC)>(cfg);
 }
 
-// debug entry points of the instrumented build (csrc/exp/run_timeline.py); they address this unit's copies of the stamps
+// debug entry points of the instrumented build (tests/tools/exp/run_timeline.py); they address this unit's copies of the stamps
 extern "C" {
 #ifdef ARMENV_TIMELINE
 int armenv_dbg_set_timeline(unsigned long long *buf_dev) {

@@ -1,0 +1,112 @@
+"""Mechanical guards on the gfx950 code objects of libarmenv.so (no GPU: llvm-objdump on the built library).
+
+The kernels lean on three hand-made patterns that live outside hipcc's own hazard / waitcnt bookkeeping; each has
+produced silently wrong results or a hidden stall at least once.  The parity suite on the GPU is the
+functional guard; these tests pin the STRUCTURE, so that a compiler update or a change in register pressure that breaks
+an assumption fails here, on the CPU, before any number is wrong:
+
+  1. no scratch in the env-step kernels and the rollout kernels without a fused actor (every per-lane array must stay in
+     registers: a runtime subscript or a spill would show up as private-segment use);
+  2. the rollout's action prefetch (armenv_env.h prefetch_issue / prefetch_settle): three global_load_dword straight into
+     accumulation registers, settled by s_waitcnt vmcnt(0) + three v_accvgpr_read after the IK -- NOTHING else may touch
+     those three AGPRs in between (the compiler believes they are defined at the issue; a copy or a spill ahead of the wait
+     would move stale data);
+  3. the f16x3 actor's k-loop (armenv_actor.h actor_forward_wg_f16x3): between the first and the last
+     v_mfma_f32_32x32x16_f16 of a kernel the only memory instructions are the ring's own direct-to-LDS loads -- a
+     compiler-generated VMEM load or scratch access there forces s_waitcnt vmcnt(0) and drains the DMA queue.
+"""
+import os
+import re
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+import isa  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(isa.LIB):
+        pytest.skip("libarmenv.so is not built")
+    rows = isa.all_kernels()
+    assert len(rows) > 100
+    return rows
+
+
+def _env_kernels(rows, pred):
+    return [(sn, md, ins) for sn, _, md, ins in rows if pred(sn)]
+
+
+def test_every_kernel_variant_is_present(kernels):
+    names = {sn for sn, *_ in kernels}
+    for task in ("reach", "push", "pick"):
+        for prec in ("f64", "f32"):
+            for chain in ("kuka", "diana", "generic"):
+                assert f"{task}_step_{prec}_{chain}" in names
+                for p in range(4):
+                    assert f"{task}_rollout_{prec}_{chain}_p{p}" in names
+
+
+def test_no_scratch_in_step_and_unfused_rollout_kernels(kernels):
+    sel = _env_kernels(kernels, lambda sn: re.search(r"_(step|reset)_f(64|32)_", sn) or re.search(r"_rollout_f(64|32)_\w+_p[01]$", sn)
+                       or sn.startswith(("fk_", "ik_")))
+    assert len(sel) >= 3 * 2 * 3 * 3
+    for sn, md, ins in sel:
+        assert md["scratch"] == 0, (sn, md)            # (vgpr_spill_count may be > 0: spills into AGPRs, not memory)
+        assert not [i.text for i in ins if i.mnem.startswith("scratch_")], sn
+
+
+def _prefetch_triples(ins):
+    """[(index, [a_x, a_y, a_z])] of three consecutive global_load_dword into AGPRs from one address at offsets 0 / 4 / 8"""
+    out = []
+    for k in range(len(ins) - 2):
+        t = ins[k:k + 3]
+        if all(i.mnem == "global_load_dword" for i in t):
+            m = [re.match(r"(a\d+), (v\[\d+:\d+\]), off(?: offset:(\d+))?$", i.ops) for i in t]
+            if all(m) and len({x.group(2) for x in m}) == 1 and [int(x.group(3) or 0) for x in m] == [0, 4, 8]:
+                out.append((k, [x.group(1) for x in m]))
+    return out
+
+
+def test_action_prefetch_agprs_are_touched_by_nothing_else(kernels):
+    sel = _env_kernels(kernels, lambda sn: re.search(r"_rollout_f(64|32)_\w+_p0$", sn))
+    assert len(sel) == 18
+    for sn, md, ins in sel:
+        triples = _prefetch_triples(ins)
+        assert len(triples) == 1, (sn, triples)
+        k0, regs = triples[0]
+        users = [(k, i) for k, i in enumerate(ins) if any(re.search(r"\b%s\b" % r, i.ops) for r in regs)]
+        loads = [k for k, i in users if i.mnem == "global_load_dword"]
+        reads = [k for k, i in users if i.mnem == "v_accvgpr_read_b32"]
+        assert loads == [k0, k0 + 1, k0 + 2], (sn, [i.text for _, i in users])
+        assert len(reads) == 3 and reads == list(range(reads[0], reads[0] + 3)), (sn, [i.text for _, i in users])
+        assert len(users) == 6, (sn, [i.text for _, i in users])            # no copy, no spill, no other use
+        assert [ins[k].ops.split(", ")[1] for k in reads] == regs, sn
+        # the settle: the wait sits immediately in front of the three reads, and the reads come after the loads
+        assert ins[reads[0] - 1].mnem == "s_waitcnt" and "vmcnt(0)" in ins[reads[0] - 1].ops, (sn, ins[reads[0] - 1].text)
+        assert reads[0] > k0 + 2, sn
+
+
+def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
+    sel = [(sn, md, ins) for sn, _, md, ins in kernels if any(i.mnem == "v_mfma_f32_32x32x16_f16" for i in ins)]
+    assert len(sel) == 18 + 2             # the fused-actor rollout of every (task, precision, chain) + the two standalone actors
+    for sn, md, ins in sel:
+        m = [k for k, i in enumerate(ins) if i.mnem == "v_mfma_f32_32x32x16_f16"]
+        assert len(m) == 48, (sn, len(m))                        # two unrolled k-steps of 24
+        body = ins[m[0]:m[-1] + 1]
+        mem = [i for i in body if isa.classify(i.mnem) == "vmem"]
+        assert mem and all(i.mnem == "global_load_lds_dwordx4" for i in mem), (sn, sorted({i.mnem for i in mem}))
+        # every vmcnt wait inside the loop is one of the hand-placed drains in front of a barrier
+        waits = [k for k, i in enumerate(body) if i.mnem == "s_waitcnt" and "vmcnt" in i.ops]
+        for k in waits:
+            assert "vmcnt(0)" in body[k].ops and body[k + 1].mnem == "s_barrier", (sn, body[k].text, body[k + 1].text)
+
+
+def test_register_budget_of_the_headline_kernels(kernels):
+    """One wave per SIMD by design (512 registers per lane): the f64 step / external-rollout kernels use the whole VGPR file
+    and park the overflow in AGPRs, never in scratch; the f32 engine's step kernel fits two waves per SIMD."""
+    by = {sn: md for sn, _, md, _ in kernels}
+    assert by["reach_rollout_f64_kuka_p0"]["vgpr"] <= 512 and by["reach_rollout_f64_kuka_p0"]["scratch"] == 0
+    assert by["reach_step_f32_kuka"]["vgpr"] <= 256
+    assert by["reach_rollout_f64_kuka_p0"]["lds"] == 0 and by["reach_step_f64_kuka"]["lds"] == 0

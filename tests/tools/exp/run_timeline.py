@@ -1,7 +1,7 @@
 import sys, os, ctypes as C
 import numpy as np, torch
 ROOT=os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT,'..','..'))
+sys.path.insert(0, os.path.join(ROOT,'..','..','..','drl-on-robot-arm_amd'))
 from armenv import _lib as L
 L.LIB_PATH=os.path.join(ROOT,'libarmenv_tl.so')
 from armenv import envs
