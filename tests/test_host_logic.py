@@ -215,15 +215,19 @@ def test_td3_learner_matches_reference_golden():
     assert agent.total_it == 6
 
 
-def test_bench_defaults_match_the_profiled_launch_shape():
-    """bench.py reports roofline.traffic only for the launch shape the PMC passes measured (profiles/traffic.json); its
-    default steps per launch must be that shape, or the default bench line would silently carry traffic = null."""
+def test_bench_launch_shapes_have_measured_traffic():
+    """bench.py reports roofline.traffic only for a launch shape the PMC passes measured (profiles/traffic.json, keyed
+    "<kernel>|policy=<p>|T=<steps per launch>|N=<envs>"): both its default shape (--rollout-steps) and the driver's
+    (`--steps 20`: one 20-step launch) must be there, or the bench line would silently carry traffic = null -- and the
+    measured HBM traffic must equal the algorithmic bytes (no wasted re-reads)."""
     import json
     import re
     src = open(os.path.join(ROOT, "bench.py")).read()
     m = re.search(r'"--rollout-steps", type=int, default=(\d+)', src)
     assert m, "bench.py: --rollout-steps default not found"
-    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["reach_rollout<f64,kuka>"]
-    assert t["steps_per_launch"] == int(m.group(1))
-    algo = (42 * t["steps_per_launch"] + 148) * 65536                 # DESIGN.md section 4: I/O 42 B per step + state 148 B per launch
-    assert abs(t["hbm_bytes_per_launch"] - algo) / algo < 0.02        # measured HBM traffic = algorithmic bytes: no wasted re-reads
+    tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for T in (int(m.group(1)), 20):
+        t = tr["reach_rollout<f64,kuka>|policy=external|T=%d|N=65536" % T]
+        # DESIGN.md section 4: caller I/O 42 B per step + state (q, cos/sin q, ep_return r+w, goal r, step r+w) 372 B per launch
+        algo = (42 * T + 372) * 65536
+        assert abs(t["hbm_bytes_per_launch"] - algo) / algo < 0.02, (T, t["hbm_bytes_per_launch"], algo)
