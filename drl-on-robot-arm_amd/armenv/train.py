@@ -39,8 +39,9 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
         out = env.rollout(rollout_steps, None, out=bufs, want_actions=True, want_terminal_obs=True)
         obs = out["obs"][-1]
         store.add_rollout(obs0, out, starts_at_reset=(it == 0))    # traj.store_step / add_trajectory (main.py:128-129)
-        if not ready:                                             # replay_buffer.size() >= minimal_episodes, main.py:135
-            ready = store.size() >= minimal_episodes
+        # replay_buffer.size() >= minimal_episodes (main.py:135), re-checked every iteration: the ring window can lose its
+        # complete episodes again, and the sampler then returns inert all-zero batches that must not be trained on
+        ready = store.size() >= minimal_episodes
         if ready:
             for _ in range(updates):                              # main.py:136-138
                 if use_graphs:     # HER batch written straight into the captured update's static buffers
@@ -85,8 +86,7 @@ def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batc
         out = env.rollout(rollout_steps, None, out=bufs, want_actions=True, want_terminal_obs=True)
         obs = out["obs"][-1]
         store.add_rollout(obs0, out, starts_at_reset=(it == 0))
-        if not ready:
-            ready = store.size() >= minimal_episodes
+        ready = store.size() >= minimal_episodes         # re-checked every iteration, see train_reach
         if ready:
             for _ in range(updates):
                 if use_graphs:     # HER batch written straight into the captured update's static buffers

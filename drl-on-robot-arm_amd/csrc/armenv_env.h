@@ -273,12 +273,14 @@ template <class C, typename T> struct ReachLane {
   // RLReachEnv.reset (rl_reach_env.py:132-217) of env i; goal_in (nullable) f32 [N][3].
   static AE_DEV void reset_env(const EnvParams<T> &P, int64_t i, const float *goal_in, float *obs) {
     float g[3];
+    // episode[i] counts the resets of env i, whoever chose the goal: it indexes the env's Philox goal draws AND keys the
+    // fused policy's exploration noise (policy_noise), so an env reset with caller goals must not replay its noise sequence
+    const uint32_t ep = P.episode[i];
+    P.episode[i] = ep + 1u;
     if (goal_in) {
       g[0] = goal_in[3 * i]; g[1] = goal_in[3 * i + 1]; g[2] = goal_in[3 * i + 2];
     } else {
-      const uint32_t ep = P.episode[i];
       sample_goal(P, i, ep, g);
-      P.episode[i] = ep + 1u;
     }
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * P.n + i] = P.cold->q_init[j]; });
     static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = P.cold->trig_init[j]; });
@@ -505,12 +507,12 @@ template <class C, typename T, bool PICK> struct CubeLane {
   static AE_DEV void reset_env(const EnvParams<T> &P, int64_t i, const float *goal_in, float *obs) {
     const int64_t n = P.n;
     T cube[3], target[3];
+    const uint32_t ep = P.episode[i];          // counts every reset of the env (see ReachLane::reset_env)
+    P.episode[i] = ep + 1u;
     if (goal_in) {
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = (T)goal_in[6 * i + k]; target[k] = (T)goal_in[6 * i + 3 + k]; });
     } else {
-      const uint32_t ep = P.episode[i];
       cube_sample<PICK, T>(P, i, ep, cube, target);
-      P.episode[i] = ep + 1u;
     }
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = P.cold->q_init[j]; });
     static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = P.cold->trig_init[j]; });

@@ -80,8 +80,11 @@ __global__ __launch_bounds__(256) void her_sample_kernel(HerArgs A) {
       return;
     }
     double u0, u1, u2, u3;
-    philox_pair(A.seed, (uint64_t)b, (uint32_t)A.draw, 0u, u0, u1);
-    philox_pair(A.seed, (uint64_t)b, (uint32_t)A.draw, 1u, u2, u3);
+    // the sampler's own Philox key: with the env's key, (batch slot b, draw d) would read exactly the uniforms that chose the
+    // goal of env b in episode d whenever a caller seeds both with the same number (armenv.train does)
+    const uint64_t key = A.seed ^ 0x5DEECE66D1CE4E5Bull;
+    philox_pair(key, (uint64_t)b, (uint32_t)A.draw, 0u, u0, u1);
+    philox_pair(key, (uint64_t)b, (uint32_t)A.draw, 1u, u2, u3);
     ep = (int32_t)(u0 * (double)E);                         // random.sample(buffer, 1)      rl_utils.py:126
     const int32_t L = A.episodes[3 * ep + 2];
     st = (int32_t)(u1 * (double)L);                         // np.random.randint(length)     :127

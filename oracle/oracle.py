@@ -276,6 +276,7 @@ def reach_reset_with_goal(chain, cfg, st, goal):
     g = np.ascontiguousarray(goal, dtype=np.float32).reshape(st.n, 3)
     lib().orc_reach_reset_with_goal(C.byref(chain), C.byref(cfg), C.c_int64(st.n), _p(g), _p(st.q), _p(st.goal),
                                     _p(st.step), _p(obs))
+    st.episode += 1          # episode counts every reset of an env, whoever chose the goal (it keys the exploration noise)
     st.ep_return[:] = 0
     return obs
 
@@ -414,6 +415,7 @@ def push_reset_with_goal(chain, cfg, st, goal6):
     obs = np.zeros((st.n, 9), dtype=np.float32)
     g = np.ascontiguousarray(goal6, dtype=np.float32).reshape(st.n, 6)
     lib().orc_push_reset_with_goal(C.byref(chain), C.byref(cfg), C.c_int64(st.n), _p(g), _p(st.q), _p(st.aux), _p(st.step), _p(obs))
+    st.episode += 1
     st.ep_return[:] = 0
     return obs
 
@@ -473,6 +475,7 @@ def pick_reset_with_goal(chain, cfg, st, goal6):
     obs = np.zeros((st.n, 9), dtype=np.float32)
     g = np.ascontiguousarray(goal6, dtype=np.float32).reshape(st.n, 6)
     lib().orc_pick_reset_with_goal(C.byref(chain), C.byref(cfg), C.c_int64(st.n), _p(g), _p(st.q), _p(st.aux), _p(st.step), _p(obs))
+    st.episode += 1
     st.ep_return[:] = 0
     return obs
 

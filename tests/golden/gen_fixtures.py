@@ -382,6 +382,55 @@ def g8_td3_train():
     np.savez(os.path.join(OUT, "td3_train_seed0.npz"), **out)
 
 
+def g11_ddpg_datd3_take_action():
+    """G11: the consumer contract of the other two agents the reference runs on these envs (north_star: algo/{DDPG,TD3,DATD3}
+    consume the env unchanged).  Produced by importing the reference's agents and calling their own take_action one state
+    at a time (algo/DDPG/DDPG_mlp.py:76-91, algo/DATD3/DATD3_mlp.py:88-109):
+      ddpg_take_action_seed0.npz   actor weights, 256 states, actions
+      datd3_take_action_seed0.npz  both actors' and both critics' weights, 256 states, actions, q1, q2, which actor won"""
+    sys.path.insert(0, REF)
+    import torch
+    from algo.DDPG.DDPG_mlp import DDPG_MLP
+    from algo.DATD3.DATD3_mlp import DATD3_MLP
+    rng = np.random.default_rng(11)
+    lo = np.array([0.2, -0.3, 0.0, 0.2, -0.3, 0.0]); hi = np.array([0.7, 0.3, 0.55, 0.7, 0.3, 0.55])
+    states = (lo + (hi - lo) * rng.random((256, 6))).astype(np.float32)
+    cpu = torch.device("cpu")
+    torch.manual_seed(0)
+    ddpg = DDPG_MLP(6, 3, 0.7, device=cpu)
+    acts = np.stack([ddpg.take_action(s) for s in states])
+    out = {"states": states, "actions": acts.astype(np.float32), "action_bound": np.float32(0.7)}
+    out.update({"actor_" + k.replace(".", "_"): v.detach().numpy().copy() for k, v in ddpg.actor.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, "ddpg_take_action_seed0.npz"), **out)
+    torch.manual_seed(0)
+    agent = DATD3_MLP(6, 3, 0.7, device=cpu)
+    # freshly initialised critics differ by a near-constant offset over this small observation box (critic1 always wins):
+    # widen both output layers and move critic2's output bias by the median gap, so that `action1 if q1 >= q2 else action2`
+    # takes both branches across the states, some of them by a narrow margin
+    with torch.no_grad():
+        for c in (agent.critic1, agent.critic2):
+            torch.nn.init.normal_(c.fc3.weight, std=0.5)
+            c.fc3.bias.zero_()
+        sb = torch.from_numpy(states)
+        gap = agent.critic1(sb, agent.actor1(sb)) - agent.critic2(sb, agent.actor2(sb))
+        agent.critic2.fc3.bias += gap.median()
+    acts, q1s, q2s, pick = [], [], [], []
+    for s in states:
+        st = torch.tensor([s], dtype=torch.float)
+        with torch.no_grad():
+            a1, a2 = agent.actor1(st), agent.actor2(st)
+            q1, q2 = float(agent.critic1(st, a1)), float(agent.critic2(st, a2))
+        a = agent.take_action(s)
+        acts.append(a); q1s.append(q1); q2s.append(q2)
+        pick.append(0 if np.array_equal(a, a1.numpy().flatten()) else 1)
+    out = {"states": states, "actions": np.stack(acts).astype(np.float32), "q1": np.float32(q1s), "q2": np.float32(q2s),
+           "picked_actor": np.int32(pick), "action_bound": np.float32(0.7)}
+    for name in ("actor1", "actor2", "critic1", "critic2"):
+        out.update({name + "_" + k.replace(".", "_"): v.detach().numpy().copy() for k, v in getattr(agent, name).state_dict().items()})
+    assert 20 < sum(pick) < 236, sum(pick)        # both branches taken
+    np.savez_compressed(os.path.join(OUT, "datd3_take_action_seed0.npz"), **out)
+
+
 if __name__ == "__main__":
-    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements(); g10_config_fields()
+    g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements(); g10_config_fields(); g11_ddpg_datd3_take_action()
     print("fixtures written to", OUT)

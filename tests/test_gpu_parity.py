@@ -854,8 +854,7 @@ def test_push_trajectory_autoreset_and_rollout(envs, O, kuka):
     O.push_reset(kuka, cfg, st, seed=8)
     g = st.aux[:, :6].astype(np.float32)
     g[:16] = np.float32([0.5, 0.0, 0.01, 0.5, 0.07, 0.01])            # cube 7 cm from its target, pushed along +y
-    obs_r = O.push_reset_with_goal(kuka, cfg, st, g)
-    st.episode[:] = 1
+    obs_r = O.push_reset_with_goal(kuka, cfg, st, g)            # episode: 1 (Philox reset) -> 2 (reset with goals), as on the device
     for x in (e, r_env, e2):
         x.reset(); x.reset(goal=torch.from_numpy(g))
     acts = []
@@ -1322,6 +1321,29 @@ def test_rollout_fused_actor_matches_oracle(envs, O, kuka):
     e.close()
 
 
+def test_exploration_noise_is_fresh_after_every_kind_of_reset(envs):
+    """The fused policy's noise is keyed by (env, episode, step); `episode` counts EVERY reset of an env -- Philox goals,
+    caller goals (armenv_reset_with_goal: the N=1 classes' path) and in-place auto-resets alike -- so no episode replays
+    the exploration sequence of the one before.  The same call sequence on a second handle is reproduced."""
+    n = 256
+    goal = torch.rand(n, 3) * torch.tensor([0.5, 0.6, 0.55]) + torch.tensor([0.2, -0.3, 0.0])
+    runs = []
+    for rep in range(2):
+        e = _mk(envs, n, seed=4, auto_reset=False)
+        e.set_policy("random")
+        seqs = []
+        for ep in range(3):
+            e.reset(goal=goal)
+            seqs.append(e.rollout(6, None, want_actions=True)["actions"].clone())
+        assert _np(e.get_state()["episode"]).tolist() == [3] * n
+        e.close()
+        runs.append(seqs)
+    a, b, c = runs[0]
+    assert not torch.equal(a, b) and not torch.equal(b, c) and not torch.equal(a, c)
+    assert (a - b).abs().mean().item() > 0.1                      # independent draws, not a shifted copy
+    assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
+
+
 def test_set_policy_errors(envs):
     from armenv import ArmEnvError
     g, sd = _golden_actor()
@@ -1627,6 +1649,96 @@ def test_device_summary_matches_host_reduction(envs, O, kuka):
     sp = pe.summary()
     assert abs(float(sp["mean_distance"]) - np.linalg.norm(aux[:, :3] - aux[:, 3:6], axis=1).mean()) < 1e-12
     pe.close()
+
+
+# ------------------------------------------------------------------------------ the other consumers: DDPG, DATD3 (north_star)
+
+def _sd_from(g, prefix):
+    return {k: torch.from_numpy(g[f"{prefix}_{k.replace('.', '_')}"]) for k in
+            ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+
+
+def test_ddpg_actor_through_the_fused_policy(envs, O, kuka):
+    """DDPG_MLP.take_action (algo/DDPG/DDPG_mlp.py:76-91) is the TD3 PolicyNet: the reference agent's own actions (golden
+    G11, produced by importing algo.DDPG) come out of the fused MFMA actor -- exact f32 and f16x3 -- within 1e-5, and a fused
+    rollout driven by those weights follows the oracle."""
+    g = golden_npz("ddpg_take_action_seed0.npz")
+    sd = _sd_from(g, "actor")
+    states = torch.from_numpy(g["states"]).to(DEV)
+    for kind in ("actor", "actor_f16x3"):
+        e = _mk(envs, 256, seed=3)
+        e.set_policy(kind, action_bound=float(g["action_bound"]), noise_sigma=0.0, noise_clip=0.7, actor_state_dict=sd)
+        a = _np(e.actor_forward(states))
+        assert np.abs(a - g["actions"]).max() < 1e-5, (kind, np.abs(a - g["actions"]).max())
+        e.close()
+    # fused rollout with DDPG's actor and the run() exploration noise against the oracle's actor + noise restatement
+    n, T = 256, 30
+    cfg = O.default_config()
+    e = _mk(envs, n, seed=12)
+    e.set_policy("actor", action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7, actor_state_dict=sd)
+    st = O.ReachState(n)
+    obs0 = _np(e.reset()).copy()
+    O.reach_reset(kuka, cfg, st, seed=12)
+    out = e.rollout(T, None, want_actions=True)
+    ref = O.reach_rollout(kuka, cfg, st, T, None, seed=12, actor={k: v.numpy() for k, v in sd.items()}, bound=0.7, obs0=obs0)
+    assert np.abs(_np(out["actions"]) - ref["actions"]).max() < 1e-4
+    assert np.abs(_np(out["obs"]) - ref["obs"]).max() < 1e-4 and np.array_equal(_np(out["done"]), ref["done"].astype(bool))
+    e.close()
+
+
+def test_datd3_is_an_external_action_consumer(envs, O, kuka):
+    """DATD3_MLP.take_action (algo/DATD3/DATD3_mlp.py:88-109: two actors, the critics' arg-max) has no fused form in the
+    rollout kernel: it consumes the env through armenv_step with external actions.  The batched policy on the device
+    reproduces the reference agent's own choices (golden G11), and a 40-step loop policy -> step -> obs follows the oracle
+    driven with the same actions."""
+    from armenv.policies import DATD3Policy
+    g = golden_npz("datd3_take_action_seed0.npz")
+    pol = DATD3Policy(6, 3, float(g["action_bound"]), device=DEV).load(*[_sd_from(g, k) for k in ("actor1", "actor2", "critic1", "critic2")])
+    a, q1, q2 = pol.take_action(torch.from_numpy(g["states"]).to(DEV), return_q=True)
+    clear = np.abs(g["q1"] - g["q2"]) > 1e-4
+    assert np.abs(_np(a) - g["actions"])[clear].max() < 1e-5 and np.abs(_np(q1) - g["q1"]).max() < 1e-4
+    n, T = 512, 40
+    cfg = O.default_config()
+    e = _mk(envs, n, seed=21)
+    st = O.ReachState(n)
+    obs = e.reset()
+    O.reach_reset(kuka, cfg, st, seed=21)
+    picked = np.zeros(2, dtype=np.int64)
+    for t in range(T):
+        a, q1, q2 = pol.take_action(obs, return_q=True)
+        assert a.dtype == torch.float32 and a.is_contiguous() and tuple(a.shape) == (n, 3)
+        picked += np.bincount(_np(q1 < q2).astype(np.int64), minlength=2)
+        obs, rew, done, succ = e.step(a)
+        obs_r, rew_r, done_r, succ_r, _ = O.reach_step_autoreset(kuka, cfg, st, _np(a), seed=21)
+        assert np.abs(_np(obs) - obs_r).max() < 1e-5 and np.array_equal(_np(done), done_r.astype(bool)), t
+    assert picked.min() > 0                     # both actors were chosen along the way
+    with pytest.raises(Exception):              # and there is no fused form to install
+        e.set_policy("datd3")
+    e.close()
+
+
+def test_td3_learner_golden_on_the_gpu(monkeypatch):
+    """G8 on cuda:0: the reference's six TD3_MLP.train() updates reproduced by armenv.td3.TD3 with
+    every network on the device.  The target-policy noise of the golden run came from torch's CPU generator; the test
+    feeds the same stream (randn on the CPU, moved to the device) so that losses and parameters are comparable."""
+    from armenv.td3 import TD3
+    g = golden_npz("td3_train_seed0.npz")
+    torch.manual_seed(0)
+    agent = TD3(6, 3, 0.7, device="cpu")          # same initial parameters as the reference's constructor order ...
+    init = [{k: v.clone() for k, v in n.state_dict().items()} for n in (agent.actor, agent.critic, agent.target_actor, agent.target_critic)]
+    agent = TD3(6, 3, 0.7, device=DEV)            # ... moved into a learner that lives on the GPU
+    for n_, sd in zip((agent.actor, agent.critic, agent.target_actor, agent.target_critic), init):
+        n_.load_state_dict(sd)
+    monkeypatch.setattr(torch, "randn_like", lambda t: torch.randn(t.shape, dtype=t.dtype).to(t.device))
+    torch.manual_seed(123)
+    for i, want in enumerate(g["losses"]):
+        b = {k: torch.from_numpy(g[f"b{i}_{k}"]).to(DEV) for k in ("states", "actions", "next_states", "rewards", "dones")}
+        loss = float(agent.train(b))
+        assert abs(loss - want) < 2e-5 * max(1.0, abs(want)), (i, loss, want)
+    for name, net in (("actor", agent.actor), ("critic", agent.critic), ("target_actor", agent.target_actor), ("target_critic", agent.target_critic)):
+        for k, v in net.state_dict().items():
+            assert v.device.type == "cuda"
+            assert np.abs(_np(v) - g[f"{name}__{k.replace('.', '_')}"]).max() < 2e-5, (name, k)
 
 
 def _run_bench(argv, nproc=1, timeout=900):

@@ -231,3 +231,31 @@ def test_bench_launch_shapes_have_measured_traffic():
         # caller I/O 42 B per step + state (q, cos/sin q, ep_return r+w, goal r, step r+w) 372 B per launch
         algo = (42 * T + 372) * 65536
         assert abs(t["hbm_bytes_per_launch"] - algo) / algo < 0.02, (T, t["hbm_bytes_per_launch"], algo)
+
+
+def _sd(g, prefix):
+    import torch
+    return {k: torch.from_numpy(g[f"{prefix}_{k.replace('.', '_')}"]) for k in
+            ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+
+
+def test_ddpg_and_datd3_take_action_match_reference_golden():
+    """G11: the batched take_action of armenv.policies against vectors produced by calling the reference's own
+    DDPG_MLP.take_action / DATD3_MLP.take_action one state at a time (algo/DDPG/DDPG_mlp.py:76-91,
+    algo/DATD3/DATD3_mlp.py:88-109).  DATD3: the arg-max over (critic1(s, a1), critic2(s, a2)) picks the same actor as the
+    reference wherever the two Q values are not within rounding of each other, and both branches occur."""
+    import torch
+    from conftest import golden_npz
+    from armenv.policies import DATD3Policy, DDPGPolicy
+    g = golden_npz("ddpg_take_action_seed0.npz")
+    pol = DDPGPolicy(6, 3, float(g["action_bound"]), device="cpu").load(_sd(g, "actor"))
+    a = pol.take_action(torch.from_numpy(g["states"])).numpy()
+    assert np.abs(a - g["actions"]).max() < 1e-6
+    g = golden_npz("datd3_take_action_seed0.npz")
+    pol = DATD3Policy(6, 3, float(g["action_bound"]), device="cpu").load(*[_sd(g, n) for n in ("actor1", "actor2", "critic1", "critic2")])
+    a, q1, q2 = pol.take_action(torch.from_numpy(g["states"]), return_q=True)
+    assert np.abs(q1.numpy() - g["q1"]).max() < 1e-5 and np.abs(q2.numpy() - g["q2"]).max() < 1e-5
+    clear = np.abs(g["q1"] - g["q2"]) > 1e-4
+    assert clear.sum() >= 250 and 100 < g["picked_actor"][clear].sum() < 156
+    assert np.abs(a.numpy() - g["actions"])[clear].max() < 1e-6
+    assert np.array_equal((q1 < q2).numpy()[clear], g["picked_actor"][clear].astype(bool))
