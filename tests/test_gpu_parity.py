@@ -1735,10 +1735,23 @@ def test_td3_learner_golden_on_the_gpu(monkeypatch):
         b = {k: torch.from_numpy(g[f"b{i}_{k}"]).to(DEV) for k in ("states", "actions", "next_states", "rewards", "dones")}
         loss = float(agent.train(b))
         assert abs(loss - want) < 2e-5 * max(1.0, abs(want)), (i, loss, want)
-    for name, net in (("actor", agent.actor), ("critic", agent.critic), ("target_actor", agent.target_actor), ("target_critic", agent.target_critic)):
+    # Parameters: Adam divides by sqrt(v): where a gradient is ~0 a last-bit difference between the CPU and GPU reductions
+    # becomes an lr-sized (1e-3 per update) difference of that element, so element-wise equality holds for all but a handful;
+    # the functions the networks compute are compared against the golden parameters on the first batch.
+    ref = TD3(6, 3, 0.7, device=DEV)
+    for name, net, rnet in (("actor", agent.actor, ref.actor), ("critic", agent.critic, ref.critic),
+                            ("target_actor", agent.target_actor, ref.target_actor), ("target_critic", agent.target_critic, ref.target_critic)):
+        rnet.load_state_dict({k: torch.from_numpy(g[f"{name}__{k.replace('.', '_')}"]) for k in net.state_dict()})
         for k, v in net.state_dict().items():
             assert v.device.type == "cuda"
-            assert np.abs(_np(v) - g[f"{name}__{k.replace('.', '_')}"]).max() < 2e-5, (name, k)
+            d = np.abs(_np(v) - g[f"{name}__{k.replace('.', '_')}"])
+            assert (d < 2e-5).mean() > 0.999 and d.max() < 7e-3, (name, k, (d < 2e-5).mean(), d.max())
+    s0, a0 = torch.from_numpy(g["b0_states"]).to(DEV), torch.from_numpy(g["b0_actions"]).to(DEV)
+    with torch.no_grad():
+        assert (agent.actor(s0) - ref.actor(s0)).abs().max().item() < 1e-4
+        assert (agent.target_actor(s0) - ref.target_actor(s0)).abs().max().item() < 1e-4
+        for x, y in zip(agent.critic(s0, a0) + agent.target_critic(s0, a0), ref.critic(s0, a0) + ref.target_critic(s0, a0)):
+            assert (x - y).abs().max().item() < 1e-4
 
 
 def _run_bench(argv, nproc=1, timeout=900):
