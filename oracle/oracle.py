@@ -293,7 +293,7 @@ def reach_step(chain, cfg, st, action):
     return obs, rew, done, succ, iters
 
 
-def reach_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, want_terminal=True):
+def reach_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, want_terminal=True, iters=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 6), dtype=np.float32); rew = np.zeros(n)
@@ -302,7 +302,7 @@ def reach_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, want_termina
     lib().orc_reach_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
                                    _p(st.q), _p(st.goal), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a),
                                    _p(obs), _p(rew), _p(done), _p(succ), _p(term),
-                                   _p(st.last_return), _p(st.last_len), _p(st.last_success))
+                                   _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters))
     return obs, rew, done, succ, term
 
 
@@ -431,14 +431,14 @@ def push_step(chain, cfg, st, action):
     return obs, rew, done, succ, iters
 
 
-def push_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0):
+def push_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, iters=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
     done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); term = np.zeros((n, 9), dtype=np.float32)
     lib().orc_push_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
                                   _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a), _p(obs),
-                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success))
+                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters))
     return obs, rew, done, succ, term
 
 
@@ -491,12 +491,12 @@ def pick_step(chain, cfg, st, action):
     return obs, rew, done, succ, iters
 
 
-def pick_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0):
+def pick_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, iters=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
     done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); term = np.zeros((n, 9), dtype=np.float32)
     lib().orc_pick_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
                                   _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a), _p(obs),
-                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success))
+                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters))
     return obs, rew, done, succ, term
