@@ -313,6 +313,12 @@ template <class C, typename T> struct ReachLane {
   // counter reaches a multiple of 512 (never inside the reference's 501-step episodes), which bounds the accumulated
   // rounding of the incremental rotations (~1e-16 each) for callers that run unbounded episodes.
   T trig[2 * NJ];
+  // The link frames of the current pose.  A step's IK leaves FK(q) of the pose it ends with (the frame _reward reads);
+  // that is also the frame the NEXT step starts from, so inside a rollout launch it is carried over instead of being
+  // recomputed from the same (cos q, sin q): 120 of a step's ~3 300 instructions, the same bits.  Invalid after load and
+  // after an in-place reset.
+  FKState<T> S;
+  bool have_S = false;
   float g[3];
   int32_t step;
   T ep_ret;
@@ -351,11 +357,11 @@ template <class C, typename T> struct ReachLane {
   AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
                     float (*next_action)[3] = nullptr) {
     const int64_t n = P.n;
-    FKState<T> S;
     T tgt[3];
-    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) derive_trig(); }
+    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) { derive_trig(); have_S = false; } }
     bool lim_hit = false;
-    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, nullptr, &trig, &lim_hit);  // :237-257
+    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, nullptr, &trig, &lim_hit, have_S);  // :237-257
+    have_S = true;
     if (prefetched) prefetch_settle(*prefetched, *next_action);
 
     n_upd += (uint32_t)updates;
@@ -398,6 +404,7 @@ template <class C, typename T> struct ReachLane {
       const EnvCold<T> &K = *P.cold;
       static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
       static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = K.trig_init[j]; });
+      have_S = false;
       step = 0;
       ep_ret = T(0);
       store_obs6<T>(io.obs, i, K.p_init, g);
@@ -474,6 +481,8 @@ template <class C, typename T, bool PICK> struct CubeLane {
   T q[NJ];
   T trig[2 * NJ];           // (cos q, sin q), carried with q in the env's state: see ReachLane
   T cube[3], target[3], d_last;
+  FKState<T> S;             // link frames of the current pose, carried from step to step (push only): see ReachLane::S
+  bool have_S = false;
   T grip = T(0);            // pick: 0 open, 1 closed, 2 closed and holding the cube
   T off[3] = {T(0), T(0), T(0)};   // pick: cube - tip while held
   int32_t step;
@@ -634,13 +643,14 @@ template <class C, typename T, bool PICK> struct CubeLane {
 
   AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
                     float (*next_action)[3] = nullptr) {
-    FKState<T> S;
     T tgt[3];
     T p0[3];
-    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) derive_trig(); }
+    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) { derive_trig(); have_S = false; } }
     const T q7 = q[NJ - 1], c7 = trig[NJ - 1], s7 = trig[2 * NJ - 1];
     bool lim_hit = false;
-    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0, &trig, &lim_hit);  // :322-347
+    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0, &trig, &lim_hit, have_S);  // :322-347
+    // pick restores joint 7 below, so the exit frame's orientation is not the next step's: only push carries the frame over
+    have_S = !PICK;
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     n_upd += (uint32_t)updates;
     if (P.ik.fence) { n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; }
@@ -695,6 +705,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
       const EnvCold<T> &K = *P.cold;
       static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
       static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = K.trig_init[j]; });
+      have_S = false;
       step = 0;
       ep_ret = T(0);
       store_obs9<T>(io.obs, i, K.p_init, cube, target);
@@ -842,6 +853,8 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
       else { ao[0] = an[0]; ao[1] = an[1]; ao[2] = an[2]; }
     }
     const uint32_t before = L.n_done;
+    // the fused actor needs the whole register file between two env steps: the link frames are not carried across it
+    if constexpr (kActor) L.have_S = false;
     if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
       L.env_step(P, i, a, io, &an_next, &an);
     } else {

@@ -575,7 +575,7 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
 AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
                    const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr,
-                   T (*trig)[2 * NJ] = nullptr, bool *limit_hit = nullptr) {
+                   T (*trig)[2 * NJ] = nullptr, bool *limit_hit = nullptr, bool frame_valid = false) {
   using M = Mth<T>;
   // the residual test |p - tgt| > residual is evaluated on squares (no sqrt on the loop-carried critical path)
   const T res2 = P.residual * P.residual;
@@ -589,7 +589,8 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
   const bool small_steps = P.max_dtheta <= T(0.7854);
   // The loop is written rotated -- FK of the start pose and the target ahead of it, the FK of each updated pose at its
   // bottom -- so that the target's inputs (action, dv, the workspace box: 14 scalar registers) are dead across the trips.
-  fk<C, T>(ch, cq, sq, S);
+  // frame_valid: S already is FK of (cq, sq) -- the exit FK of the caller's previous step (the same inputs give the same bits).
+  if (!frame_valid) fk<C, T>(ch, cq, sq, S);
   if constexpr (FROM_ACTION) {
     if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
     static_for<0, 3>([&](auto KI) {

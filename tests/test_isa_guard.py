@@ -69,23 +69,49 @@ def _prefetch_triples(ins):
     return out
 
 
-def test_action_prefetch_agprs_are_touched_by_nothing_else(kernels):
+def _reachable_before(ins, start, stop):
+    """Indices of the instructions that can execute after ins[start] without having passed ins[stop] (control-flow walk:
+    fall-through and branch targets; out-of-line cold blocks included)."""
+    by_addr = {i.addr: k for k, i in enumerate(ins)}
+    seen, todo = set(), [start]
+    while todo:
+        k = todo.pop()
+        if k in seen or k == stop or k >= len(ins):
+            continue
+        seen.add(k)
+        i = ins[k]
+        if i.mnem in ("s_endpgm",) or i.mnem.startswith("s_setpc"):
+            continue
+        t = isa.branch_target(i)
+        if t is not None and t in by_addr:
+            todo.append(by_addr[t])
+        if i.mnem != "s_branch":
+            todo.append(k + 1)
+    return seen
+
+
+def test_action_prefetch_agprs_are_untouched_between_issue_and_settle(kernels):
     sel = _env_kernels(kernels, lambda sn: re.search(r"_rollout_f(64|32)_\w+_p0$", sn))
     assert len(sel) == 18
     for sn, md, ins in sel:
         triples = _prefetch_triples(ins)
         assert len(triples) == 1, (sn, triples)
         k0, regs = triples[0]
-        users = [(k, i) for k, i in enumerate(ins) if any(re.search(r"\b%s\b" % r, i.ops) for r in regs)]
-        loads = [k for k, i in users if i.mnem == "global_load_dword"]
-        reads = [k for k, i in users if i.mnem == "v_accvgpr_read_b32"]
-        assert loads == [k0, k0 + 1, k0 + 2], (sn, [i.text for _, i in users])
-        assert len(reads) == 3 and reads == list(range(reads[0], reads[0] + 3)), (sn, [i.text for _, i in users])
-        assert len(users) == 6, (sn, [i.text for _, i in users])            # no copy, no spill, no other use
-        assert [ins[k].ops.split(", ")[1] for k in reads] == regs, sn
-        # the settle: the wait sits immediately in front of the three reads, and the reads come after the loads
-        assert ins[reads[0] - 1].mnem == "s_waitcnt" and "vmcnt(0)" in ins[reads[0] - 1].ops, (sn, ins[reads[0] - 1].text)
-        assert reads[0] > k0 + 2, sn
+        pat = re.compile(r"\b(%s)\b" % "|".join(regs))
+        # the settle: s_waitcnt vmcnt(0) immediately followed by the three v_accvgpr_read of exactly these registers
+        settles = [k for k in range(1, len(ins) - 2)
+                   if all(ins[k + j].mnem == "v_accvgpr_read_b32" and ins[k + j].ops.split(", ")[1] == regs[j] for j in range(3))
+                   and ins[k - 1].mnem == "s_waitcnt" and "vmcnt(0)" in ins[k - 1].ops]
+        assert len(settles) == 1, (sn, settles)
+        k1 = settles[0]
+        # everything that can run between the issue and the wait -- the whole IK, its cold blocks included -- leaves the three
+        # registers alone: no copy (v_accvgpr_mov / read), no spill into them, no reuse
+        window = _reachable_before(ins, k0 + 3, k1 - 1)
+        assert len(window) > 500, (sn, len(window))                     # the IK really lies in between
+        touched = [ins[k].text for k in sorted(window) if pat.search(ins[k].ops)]
+        assert not touched, (sn, touched)
+        # and the loads themselves are not re-issued inside the window (one prefetch in flight)
+        assert not any(k0 <= k < k0 + 3 for k in window), sn
 
 
 def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
