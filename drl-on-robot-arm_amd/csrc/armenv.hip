@@ -148,6 +148,9 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->pick_gripper_length = 0.257;   // rl_pick_env.py:79
   c->pick_trigger_dis = 0.006;      // rl_pick_env.py:412
   c->pick_jaw_half = 0.02;
+  // measured at 32 768 envs, 100-step launches: pick 27.6 -> 23.3 us per step at 62; push and reach are
+  // faster in lockstep (their per-wave maxima are close to their means, and every transition round costs a tail block)
+  c->rollout_ready_lanes = task == ARMENV_TASK_PICK ? 62 : 0;
   return armenv_builtin_chain(ARMENV_ROBOT_KUKA, &c->chain);
 }
 

@@ -108,6 +108,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   double *summary_rows = nullptr;
   static constexpr int block = 256;   // four waves: one per SIMD of a CU; the f16x3 actor phase is a 4-wave workgroup
   int cus = 256;
+  int ready_lanes = 0;   // > 0: rollouts run lane-asynchronously (env_rollout_async_kernel)
   // Workgroup size of the env kernels that have no workgroup phase (step, rollout without a fused actor): the IK keeps
   // one wave per SIMD, so a batch that does not fill the chip is launched as smaller workgroups -- the dispatcher then
   // spreads its waves over all CUs (1 or 2 per CU) instead of packing four onto a quarter or half of them, and a wave
@@ -201,6 +202,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     P.ik.exit_mode = cfg.ik_exit_mode;
     P.ik.angle_f32 = cfg.ik_angle_f32;
     P.ik.clamp_limits = cfg.clamp_joint_limits;
+    ready_lanes = cfg.rollout_ready_lanes < 0 ? 0 : (cfg.rollout_ready_lanes > 64 ? 64 : cfg.rollout_ready_lanes);
     P.ik.fence = cfg.fence_counters;
     P.fence_z = (T)cfg.fence_z;
     for (int j = 0; j < NJ; ++j) {
@@ -241,7 +243,20 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, pol, steps,
                        actions, io0, actions_out);
   }
+  template <int POLICY>
+  void launch_rollout_async(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
+    const int b = lane_block();
+    hipLaunchKernelGGL((env_rollout_async_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, pol, steps,
+                       actions, io0, actions_out, (int32_t)ready_lanes);
+  }
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
+    // lane-asynchronous form (ArmEnvConfig.rollout_ready_lanes > 0): external actions or the in-kernel random policy
+    const bool fused_actor = !actions && (pol.kind == ARMENV_POLICY_ACTOR || pol.kind == ARMENV_POLICY_ACTOR_F16X3);
+    if (ready_lanes > 0 && steps > 1 && !fused_actor) {
+      if (actions) launch_rollout_async<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
+      else launch_rollout_async<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
+      return;
+    }
     if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR_F16X3) launch_rollout<ARMENV_POLICY_ACTOR_F16X3>(steps, actions, io0, actions_out, s);

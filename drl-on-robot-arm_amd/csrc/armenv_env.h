@@ -262,9 +262,10 @@ AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint3
 }
 
 // Per-lane state of one reach env and the body of one env step.  The single-step kernel and the T-step rollout
-// kernel both run this code: a one-step rollout is bit-identical to a step launch (see `trig` below for longer ones).
+// kernel both run this code: a rollout of any length is bit-identical to the same steps as separate launches (see `cq` below).
 template <class C, typename T> struct ReachLane {
   using M = Mth<T>;
+  using Chain = C;
   static constexpr int kTask = ARMENV_TASK_REACH;
   static constexpr int kObs = 6;
   static constexpr int kAuxRows = 0, kAuxDim = 0;
@@ -312,7 +313,7 @@ template <class C, typename T> struct ReachLane {
   // to ~1e-7 rad and, rarely, into a flipped IK update count.  The pair is re-derived from q whenever the env's own step
   // counter reaches a multiple of 512 (never inside the reference's 501-step episodes), which bounds the accumulated
   // rounding of the incremental rotations (~1e-16 each) for callers that run unbounded episodes.
-  T trig[2 * NJ];
+  T cq[NJ], sq[NJ];
   // The link frames of the current pose.  A step's IK leaves FK(q) of the pose it ends with (the frame _reward reads);
   // that is also the frame the NEXT step starts from, so inside a rollout launch it is carried over instead of being
   // recomputed from the same (cos q, sin q): 120 of a step's ~3 300 instructions, the same bits.  Invalid after load and
@@ -331,39 +332,36 @@ template <class C, typename T> struct ReachLane {
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; g[k] = P.goal[(int64_t)k * n + i]; });
     step = P.step[i];
     ep_ret = P.ep_return[i];
-    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig[(int64_t)j * n + i]; });
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = P.trig[(int64_t)j * n + i]; sq[j] = P.trig[(int64_t)(NJ + j) * n + i]; });
   }
-  AE_DEV void derive_trig() {
-    T c_[NJ], s_[NJ];
-    sincos_all<T>(q, c_, s_);
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; trig[j] = c_[j]; trig[NJ + j] = s_[j]; });
-  }
+  AE_DEV void derive_trig() { sincos_all<T>(q, cq, sq); }
 
   AE_DEV void store(const EnvParams<T> &P, int64_t i) {
     const int64_t n = P.n;
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
-    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = trig[j]; });
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = cq[j]; P.trig[(int64_t)(NJ + j) * n + i] = sq[j]; });
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
     flush_counts(P, i, n_done, n_succ, n_bad, n_upd, n_lim, n_low);
   }
 
-  // RLReachEnv.step + _reward (rl_reach_env.py:219-319) with action a; writes row i of the caller's buffers.
-  // Returns the number of IK updates.
-  // `prefetched` (nullable): registers a caller is loading during this step (the rollout's next action).  They are
-  // consumed here, right after the IK and BEFORE this step's stores are issued: the s_waitcnt the consumption needs
-  // then covers only that old load; placed at the next step's top it would also wait for this step's stores
-  // (vmcnt is in-order) -- measured 15 % of the wave's cycles.
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
-                    float (*next_action)[3] = nullptr) {
-    const int64_t n = P.n;
-    T tgt[3];
+  // RLReachEnv.step + _reward (rl_reach_env.py:219-319) in three pieces -- step_begin, the IK trips (ik_trip), step_tail --
+  // so that the lockstep kernels (env_step below: all lanes of a wave walk through a step together) and the
+  // lane-asynchronous rollout kernel (env_rollout_async_kernel: every lane at its own step and trip) run the same code.
+  //
+  // step_begin: everything ahead of the IK trips -- the frame of the start pose (carried over or recomputed) and the
+  // clipped Cartesian target (:237-242).
+  AE_DEV void step_begin(const EnvParams<T> &P, const T (&a)[3], T (&tgt)[3]) {
     if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) { derive_trig(); have_S = false; } }
-    bool lim_hit = false;
-    const int updates = ik_move<C, T, true>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, nullptr, &trig, &lim_hit, have_S);  // :237-257
+    if (!have_S) fk<C, T>(P.chain, cq, sq, S);
+    ik_target<T, false>(S, a, P.dv, P.box_lo, P.box_hi, tgt);
+  }
+  // step_tail: everything after the IK (q, cq / sq and S = FK(q) hold its result; `updates` trips applied an update; lim_hit:
+  // ik_limits): step counter, distance, reward / done / success (:264-309), observation (:319), episode accounting,
+  // in-place reset.  Writes row i of the caller's buffers.
+  AE_DEV void step_tail(const EnvParams<T> &P, int64_t i, const StepIO &io, int updates, bool lim_hit) {
+    const int64_t n = P.n;
     have_S = true;
-    if (prefetched) prefetch_settle(*prefetched, *next_action);
-
     n_upd += (uint32_t)updates;
     if (P.ik.fence) { n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; }
     step += 1;                                                                    // :264
@@ -403,7 +401,7 @@ template <class C, typename T> struct ReachLane {
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
       const EnvCold<T> &K = *P.cold;
       static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
-      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = K.trig_init[j]; });
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = K.trig_init[j]; sq[j] = K.trig_init[NJ + j]; });
       have_S = false;
       step = 0;
       ep_ret = T(0);
@@ -413,17 +411,33 @@ template <class C, typename T> struct ReachLane {
       store_obs6<T>(io.obs, i, S.p, g);                                           // :319
       cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
     }
+  }
+  // The lockstep step.  Returns the number of IK updates.
+  // `prefetched` (nullable): registers a caller is loading during this step (the rollout's next action).  They are
+  // consumed here, right after the IK and BEFORE this step's stores are issued: the s_waitcnt the consumption needs
+  // then covers only that old load; placed at the next step's top it would also wait for this step's stores
+  // (vmcnt is in-order) -- measured 15 % of the wave's cycles.
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
+                    float (*next_action)[3] = nullptr) {
+    T tgt[3];
+    step_begin(P, a, tgt);
+    const T res2 = P.ik.residual * P.ik.residual;
+    const bool small_steps = P.ik.max_dtheta <= T(0.7854);
+    T diff2_prev = T(1e60);
+    int updates = 0;
+    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps)) {}    // :244-257
+    const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, q, S, cq, sq);
+    if (prefetched) prefetch_settle(*prefetched, *next_action);
+    step_tail(P, i, io, updates, lim_hit);
     return updates;
   }
 
   float cur_obs[3];   // eef part of the observation the policy sees next (goal part is g)
   // eef of the current state, for the first policy call of a launch (later ones reuse the step's exit FK)
   AE_DEV void refresh_obs(const EnvParams<T> &P) {
-    FKState<T> S;
-    T cq[NJ], sq[NJ];
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = trig[j]; sq[j] = trig[NJ + j]; });
-    fk<C, T>(P.chain, cq, sq, S);
-    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    FKState<T> F;
+    fk<C, T>(P.chain, cq, sq, F);
+    cur_obs[0] = (float)F.p[0]; cur_obs[1] = (float)F.p[1]; cur_obs[2] = (float)F.p[2];
   }
   AE_DEV void policy_obs(float (&s)[6]) const {
     s[0] = cur_obs[0]; s[1] = cur_obs[1]; s[2] = cur_obs[2]; s[3] = g[0]; s[4] = g[1]; s[5] = g[2];
@@ -474,12 +488,13 @@ AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&
 //     model, see grip().
 template <class C, typename T, bool PICK> struct CubeLane {
   using M = Mth<T>;
+  using Chain = C;
   static constexpr int kTask = PICK ? ARMENV_TASK_PICK : ARMENV_TASK_PUSH;
   static constexpr int kObs = 9;
   static constexpr int kAuxRows = PICK ? 11 : 7, kAuxDim = PICK ? 12 : 8;
   static constexpr const char *kName = PICK ? "pick" : "push";
   T q[NJ];
-  T trig[2 * NJ];           // (cos q, sin q), carried with q in the env's state: see ReachLane
+  T cq[NJ], sq[NJ];         // (cos q, sin q), carried with q in the env's state: see ReachLane::cq
   T cube[3], target[3], d_last;
   FKState<T> S;             // link frames of the current pose, carried from step to step (push only): see ReachLane::S
   bool have_S = false;
@@ -490,11 +505,9 @@ template <class C, typename T, bool PICK> struct CubeLane {
   uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0, n_lim = 0, n_low = 0;
   float cur_obs[3];
   AE_DEV void refresh_obs(const EnvParams<T> &P) {
-    FKState<T> S;
-    T cq[NJ], sq[NJ];
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = trig[j]; sq[j] = trig[NJ + j]; });
-    fk<C, T>(P.chain, cq, sq, S);
-    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    FKState<T> F;
+    fk<C, T>(P.chain, cq, sq, F);
+    cur_obs[0] = (float)F.p[0]; cur_obs[1] = (float)F.p[1]; cur_obs[2] = (float)F.p[2];
   }
   AE_DEV void policy_obs(float (&s)[9]) const {
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; s[k] = cur_obs[k]; s[3 + k] = (float)cube[k]; s[6 + k] = (float)target[k]; });
@@ -545,18 +558,14 @@ template <class C, typename T, bool PICK> struct CubeLane {
     }
     step = P.step[i];
     ep_ret = P.ep_return[i];
-    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = P.trig[(int64_t)j * n + i]; });
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = P.trig[(int64_t)j * n + i]; sq[j] = P.trig[(int64_t)(NJ + j) * n + i]; });
   }
-  AE_DEV void derive_trig() {
-    T c_[NJ], s_[NJ];
-    sincos_all<T>(q, c_, s_);
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; trig[j] = c_[j]; trig[NJ + j] = s_[j]; });
-  }
+  AE_DEV void derive_trig() { sincos_all<T>(q, cq, sq); }
 
   AE_DEV void store(const EnvParams<T> &P, int64_t i) {
     const int64_t n = P.n;
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.q[(int64_t)j * n + i] = q[j]; });
-    static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = trig[j]; });
+    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = cq[j]; P.trig[(int64_t)(NJ + j) * n + i] = sq[j]; });
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = cube[k]; P.aux[(int64_t)(3 + k) * n + i] = target[k]; });
     P.aux[(int64_t)6 * n + i] = d_last;
     if constexpr (PICK) {
@@ -641,22 +650,25 @@ template <class C, typename T, bool PICK> struct CubeLane {
     contact(P, tip0, tip);
   }
 
-  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
-                    float (*next_action)[3] = nullptr) {
-    T tgt[3];
-    T p0[3];
+  // The step in three pieces (see ReachLane): step_begin (frame of the start pose, clipped target :322-338; pick: the
+  // float32-rounded start position :328), the IK trips, step_tail.
+  T p0[3];                  // eef position at the start of the running step (the contact model's sweep origin)
+  T q7s, c7s, s7s;          // pick: joint 7 and its (cos, sin) before the IK (rl_pick_env.py:343 applies joints 0..5 only)
+  AE_DEV void step_begin(const EnvParams<T> &P, const T (&a)[3], T (&tgt)[3]) {
     if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) { derive_trig(); have_S = false; } }
-    const T q7 = q[NJ - 1], c7 = trig[NJ - 1], s7 = trig[2 * NJ - 1];
-    bool lim_hit = false;
-    const int updates = ik_move<C, T, true, PICK>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S, &p0, &trig, &lim_hit, have_S);  // :322-347
+    if constexpr (PICK) { q7s = q[NJ - 1]; c7s = cq[NJ - 1]; s7s = sq[NJ - 1]; }
+    if (!have_S) fk<C, T>(P.chain, cq, sq, S);
+    p0[0] = S.p[0]; p0[1] = S.p[1]; p0[2] = S.p[2];
+    ik_target<T, PICK>(S, a, P.dv, P.box_lo, P.box_hi, tgt);
+  }
+  AE_DEV void step_tail(const EnvParams<T> &P, int64_t i, const StepIO &io, int updates, bool lim_hit) {
     // pick restores joint 7 below, so the exit frame's orientation is not the next step's: only push carries the frame over
     have_S = !PICK;
-    if (prefetched) prefetch_settle(*prefetched, *next_action);
     n_upd += (uint32_t)updates;
     if (P.ik.fence) { n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; }
     if constexpr (PICK) {
-      q[NJ - 1] = q7;               // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
-      trig[NJ - 1] = c7; trig[2 * NJ - 1] = s7;
+      q[NJ - 1] = q7s;              // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
+      cq[NJ - 1] = c7s; sq[NJ - 1] = s7s;
       grip_step(P, p0, S);          // :349, :412-417
     } else {
       contact(P, p0, S.p);          // :349
@@ -704,7 +716,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
       if constexpr (PICK) { grip = T(0); off[0] = off[1] = off[2] = T(0); }
       const EnvCold<T> &K = *P.cold;
       static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
-      static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[j] = K.trig_init[j]; });
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = K.trig_init[j]; sq[j] = K.trig_init[NJ + j]; });
       have_S = false;
       step = 0;
       ep_ret = T(0);
@@ -714,6 +726,19 @@ template <class C, typename T, bool PICK> struct CubeLane {
       store_obs9<T>(io.obs, i, S.p, cube, target);                               // :308
       cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
     }
+  }
+  AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
+                    float (*next_action)[3] = nullptr) {
+    T tgt[3];
+    step_begin(P, a, tgt);
+    const T res2 = P.ik.residual * P.ik.residual;
+    const bool small_steps = P.ik.max_dtheta <= T(0.7854);
+    T diff2_prev = T(1e60);
+    int updates = 0;
+    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps)) {}    // :339-347
+    const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, q, S, cq, sq);
+    if (prefetched) prefetch_settle(*prefetched, *next_action);
+    step_tail(P, i, io, updates, lim_hit);
     return updates;
   }
 };
@@ -866,6 +891,100 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   }
   L.store(P, i);
   if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) actor_ring_drain();
+  flush_env_steps(P.counters, i, (unsigned long long)n * (unsigned long long)steps);
+}
+
+// Lane-asynchronous rollout: the same `steps` env steps per env as env_rollout_kernel, but the lanes of a wave do not walk
+// through a step together.  The wave's loop body is ONE IK TRIP; every lane carries its own step index t and trip state.
+// A lane whose IK has stopped waits (masked off) until `ready_lanes` lanes of the wave are in that state or nobody is
+// iterating any more; then all waiting lanes run their step's tail (contact / gripper, reward, stores to row t, in-place
+// reset), take the next action and start the next step's trips, while the laggards carry on with theirs.
+// Why: a lockstep wave pays sum_t max_lane trips(lane, t).  Where a few lanes need many more trips than the rest -- pick
+// under random exploration: 0.85 % of the env-steps run Bullet's loop to its 20-iteration cap, so nearly every wave-step
+// contains one (12.2 trips per wave-step for 4.45 per env-step, tests/tools/trip_stats.py); push: a 5th trip in one lane
+// of most waves (5.5 for 4.1) -- the wave is held to its slowest lane at EVERY step.  Here a slow lane only delays itself:
+// the wave pays ~max_lane sum_t trips (pick 6.5, push 4.4) plus one tail block per transition round.  ready_lanes trades
+// the two: 64 is lockstep (one tail per step), 1 runs a tail block on nearly every trip.
+// Per-lane arithmetic, its order and every store are those of env_step: trajectories are bit-identical to the lockstep
+// kernels and to armenv_step launches (tested).  Not used with the fused actors (their MFMA phases are wave-synchronous).
+template <class Lane, typename T, int POLICY>
+__global__ __launch_bounds__(256) void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
+                                                                const float *actions, StepIO io0, float *actions_out,
+                                                                int32_t ready_lanes) {
+  static_assert(POLICY == ARMENV_POLICY_EXTERNAL || POLICY == ARMENV_POLICY_RANDOM, "no wave-synchronous policy phases here");
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const int64_t n = P.n;
+  constexpr int kObs = Lane::kObs;
+  using C = typename Lane::Chain;
+  Lane L;
+  L.load(P, i);
+  uint32_t episode = (POLICY != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
+  const T res2 = P.ik.residual * P.ik.residual;
+  const bool small_steps = P.ik.max_dtheta <= T(0.7854);
+  int32_t t = 0;            // this lane's step inside the launch
+  bool ready = false;       // the step's IK has stopped; the lane waits for a transition round
+  T tgt[3], diff2_prev = T(1e60);
+  int updates = 0;
+  float af[3] = {0.f, 0.f, 0.f};     // the action of step t (external policy: loaded by load_action ahead of its use)
+  auto load_action = [&](int32_t tt) {
+    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+      const float *ap = actions + ((int64_t)tt * n + i) * 3;
+      af[0] = ap[0]; af[1] = ap[1]; af[2] = ap[2];
+    }
+  };
+  auto begin_step = [&]() {
+    T a[3];
+    if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
+      float nz[3];
+      policy_noise(P.seed, P.env_id0 + (uint64_t)i, episode - 1u, (uint32_t)L.step, nz);
+      static_for<0, 3>([&](auto KI) {
+        constexpr int k = KI;
+        float v = nz[k] * pol.sigma;                                     // zero actor + N(0, sigma), main.py:116
+        af[k] = fminf(fmaxf(v, -pol.clip), pol.clip);                     // .clip(-bound, bound), main.py:117
+      });
+    }
+    a[0] = (T)af[0]; a[1] = (T)af[1]; a[2] = (T)af[2];
+    if (actions_out) {
+      float *ao = actions_out + ((int64_t)t * n + i) * 3;
+      ao[0] = af[0]; ao[1] = af[1]; ao[2] = af[2];
+    }
+    L.step_begin(P, a, tgt);
+    diff2_prev = T(1e60);
+    updates = 0;
+    ready = false;
+  };
+  load_action(0);
+  begin_step();
+  for (;;) {
+    if (!ready && t < steps) ready = ik_trip<C, T>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps);
+    const unsigned long long rb = __ballot(ready), ib = __ballot(!ready && t < steps);
+    if (__popcll(rb) >= ready_lanes || ib == 0ull) {       // wave-uniform: a transition round
+      if (ready) {
+        // the next step's action is requested first: the step's tail (a few hundred instructions) covers most of the
+        // load's latency before begin_step consumes it
+        if (t + 1 < steps) load_action(t + 1);
+        const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, L.q, L.S, L.cq, L.sq);
+        StepIO io;
+        io.action = nullptr;
+        io.obs = io0.obs + (int64_t)t * n * kObs;
+        io.reward = io0.reward + (int64_t)t * n;
+        io.done = io0.done + (int64_t)t * n;
+        io.success = io0.success + (int64_t)t * n;
+        io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
+        const uint32_t before = L.n_done;
+        L.step_tail(P, i, io, updates, lim_hit);
+        if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
+          if (L.n_done != before && P.auto_reset) episode += 1u;
+        }
+        ready = false;
+        ++t;
+        if (t < steps) begin_step();
+      }
+    }
+    if (__ballot(t < steps) == 0ull) break;
+  }
+  L.store(P, i);
   flush_env_steps(P.counters, i, (unsigned long long)n * (unsigned long long)steps);
 }
 

@@ -572,66 +572,63 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
 // which is the post-step FK of _reward() (:271).  Returns the number of updates applied.
 // START_F32: the start position is rounded through float before the action is added (rl_pick_env.py:328 casts
 // getLinkState's tuple to np.float32; reach / push keep the f64 tuple).
-template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
-AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
-                   const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr,
-                   T (*trig)[2 * NJ] = nullptr, bool *limit_hit = nullptr, bool frame_valid = false) {
+// The three pieces of the arm move, shared by the lockstep loop of ik_move() below and by the lane-asynchronous rollout
+// kernel (armenv_env.h env_rollout_async_kernel), where every lane walks through its own (step, trip) sequence.
+//
+// ik_target: tgt = clip(p(q) + dv * a, box) from the frame S of the start pose (rl_reach_env.py:231-242).
+template <typename T, bool START_F32>
+AE_DEV void ik_target(const FKState<T> &S, const T (&a)[3], T dv, const T (&box_lo)[3], const T (&box_hi)[3], T (&tgt)[3]) {
   using M = Mth<T>;
-  // the residual test |p - tgt| > residual is evaluated on squares (no sqrt on the loop-carried critical path)
-  const T res2 = P.residual * P.residual;
-  T diff2_prev = T(1e60);
-  int it = 0;
-  T cq[NJ], sq[NJ];
-  if (trig) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = (*trig)[j]; sq[j] = (*trig)[NJ + j]; }); }
-  else sincos_all<T>(q, cq, sq);
-  // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced
-  // incrementally, otherwise cos/sin are recomputed from q
-  const bool small_steps = P.max_dtheta <= T(0.7854);
-  // The loop is written rotated -- FK of the start pose and the target ahead of it, the FK of each updated pose at its
-  // bottom -- so that the target's inputs (action, dv, the workspace box: 14 scalar registers) are dead across the trips.
-  // frame_valid: S already is FK of (cq, sq) -- the exit FK of the caller's previous step (the same inputs give the same bits).
-  if (!frame_valid) fk<C, T>(ch, cq, sq, S);
-  if constexpr (FROM_ACTION) {
-    if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
-    static_for<0, 3>([&](auto KI) {
-      constexpr int k = KI;
-      T v = M::fma(a[k], dv, START_F32 ? (T)(float)S.p[k] : S.p[k]);
-      v = v < box_lo[k] ? box_lo[k] : v;   // clip_val, rl_reach_env.py:225-230
-      v = v > box_hi[k] ? box_hi[k] : v;
-      tgt[k] = v;
-    });
+  static_for<0, 3>([&](auto KI) {
+    constexpr int k = KI;
+    T v = M::fma(a[k], dv, START_F32 ? (T)(float)S.p[k] : S.p[k]);
+    v = v < box_lo[k] ? box_lo[k] : v;   // clip_val, rl_reach_env.py:225-230
+    v = v > box_hi[k] ? box_hi[k] : v;
+    tgt[k] = v;
+  });
+}
+// ik_trip: one trip of Bullet's loop on the pose whose frame is S.  Returns true when the loop stops (nothing changes);
+// otherwise applies one DLS update to q and (cq, sq), leaves S = FK(q) of the updated pose and counts the update in `it`.
+template <class C, typename T>
+AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
+                    T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps) {
+  using M = Mth<T>;
+  T e[6];
+  e[0] = tgt[0] - S.p[0];
+  e[1] = tgt[1] - S.p[1];
+  e[2] = tgt[2] - S.p[2];
+  const T diff2 = M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2]));
+  const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff2_prev > res2) : !(diff2 > res2));
+  if (stop) return true;
+  T qc[4], eo[3], dth[NJ];
+  quat_from_frame<T>(S.W, qc);
+  orientation_error<T>(P.tq, qc, P.angle_f32, eo);
+  e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
+  dls_update<C, T>(S, e, P, dth);
+  static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
+  if (small_steps) {
+    static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
+  } else {
+    sincos_all<T>(q, cq, sq);
   }
-  for (;; ++it) {
-    T e[6];
-    e[0] = tgt[0] - S.p[0];
-    e[1] = tgt[1] - S.p[1];
-    e[2] = tgt[2] - S.p[2];
-    const T diff2 = M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2]));
-    const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff2_prev > res2) : !(diff2 > res2));
-    if (stop) break;
-    T qc[4], eo[3], dth[NJ];
-    quat_from_frame<T>(S.W, qc);
-    orientation_error<T>(P.tq, qc, P.angle_f32, eo);
-    e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
-    dls_update<C, T>(S, e, P, dth);
-    static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
-    if (small_steps) {
-      static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
-    } else {
-      sincos_all<T>(q, cq, sq);
-    }
-    diff2_prev = diff2;
-    fk<C, T>(ch, cq, sq, S);
-  }
-  // URDF joint limits (/root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7, fields 8-9).  The reference never passes
-  // them to the IK (rl_reach_env.py:103-107 are dead data, :244-250), so q may leave them; Bullet then pushes the joint
-  // back inside stepSimulation (:258) through a limit constraint this build does not model.  `hit` fences those steps
-  // (counted by the caller); with clamp_limits the result is projected onto the limits -- the hard-limit idealisation
-  // of that constraint -- and the frame recomputed, for the lanes that left them only (the others keep their bits).
+  diff2_prev = diff2;
+  ++it;
+  fk<C, T>(ch, cq, sq, S);
+  return false;
+}
+// ik_limits: URDF joint limits (/root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7, fields 8-9).  The reference never
+// passes them to the IK (rl_reach_env.py:103-107 are dead data, :244-250), so q may leave them; Bullet then pushes the joint
+// back inside stepSimulation (:258) through a limit constraint this build does not model.  Returns whether the IK result
+// lies outside the limits (the parity fence, counted by the caller); with clamp_limits the result is projected onto them
+// -- the hard-limit idealisation of that constraint -- and the frame recomputed, for the lanes that left them only (the
+// others keep their bits).
+template <class C, typename T>
+AE_DEV bool ik_limits(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], FKState<T> &S, T (&cq)[NJ], T (&sq)[NJ]) {
+  using M = Mth<T>;
+  bool hit = false;
   if (P.clamp_limits || P.fence) {
     T m = M::fabs(q[0]);
     static_for<1, NJ>([&](auto II) { constexpr int i = II; m = M::fmax(m, M::fabs(q[i])); });
-    bool hit = false;
     if (__builtin_expect(m > P.lim_min, 0)) {
       T lo[NJ], hi[NJ];
       static_for<0, NJ>([&](auto II) { constexpr int i = II; lo[i] = P.lim[i]; hi[i] = P.lim[NJ + i]; });
@@ -642,9 +639,36 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
         fk<C, T>(ch, cq, sq, S);
       }
     }
-    if (limit_hit) *limit_hit = hit;
   }
-  if (trig) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; (*trig)[j] = cq[j]; (*trig)[NJ + j] = sq[j]; }); }
+  return hit;
+}
+
+template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
+AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
+                   const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr,
+                   T (*cq_io)[NJ] = nullptr, T (*sq_io)[NJ] = nullptr, bool *limit_hit = nullptr, bool frame_valid = false) {
+  // the residual test |p - tgt| > residual is evaluated on squares (no sqrt on the loop-carried critical path)
+  const T res2 = P.residual * P.residual;
+  T diff2_prev = T(1e60);
+  int it = 0;
+  T cq[NJ], sq[NJ];
+  if (cq_io) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = (*cq_io)[j]; sq[j] = (*sq_io)[j]; }); }
+  else sincos_all<T>(q, cq, sq);
+  // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced
+  // incrementally, otherwise cos/sin are recomputed from q
+  const bool small_steps = P.max_dtheta <= T(0.7854);
+  // The loop is written rotated -- FK of the start pose and the target ahead of it, the FK of each updated pose at its
+  // bottom -- so that the target's inputs (action, dv, the workspace box: 14 scalar registers) are dead across the trips.
+  // frame_valid: S already is FK of (cq, sq) -- the exit FK of the caller's previous step (the same inputs give the same bits).
+  if (!frame_valid) fk<C, T>(ch, cq, sq, S);
+  if constexpr (FROM_ACTION) {
+    if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
+    ik_target<T, START_F32>(S, a, dv, box_lo, box_hi, tgt);
+  }
+  while (!ik_trip<C, T>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps)) {}
+  const bool hit = ik_limits<C, T>(ch, P, q, S, cq, sq);
+  if (limit_hit) *limit_hit = hit;
+  if (cq_io) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; (*cq_io)[j] = cq[j]; (*sq_io)[j] = sq[j]; }); }
   return it;
 }
 

@@ -124,6 +124,16 @@ typedef struct ArmEnvConfig {
                                  distance of the tool axis (default: push_cube_half) */
   double fence_z;             /* 0.05 */
 
+  /* armenv_rollout scheduling.  0: lockstep -- the lanes of a wavefront walk through every step together (a step costs the
+   * wave its slowest lane's IK trips).  k in 1..64: lane-asynchronous -- a lane whose IK has stopped waits until k lanes of
+   * its wave are waiting (or nobody iterates), then they finish their step and start the next one while the others carry on;
+   * same trajectories bit for bit.  Defaults: reach and push 0 (their lanes mostly agree: 4.00 / 5.5 trips per wave-step for
+   * 3.92 / 4.1 per env-step, and every transition round of the asynchronous form costs a tail block), pick 62 (0.85 % of its
+   * env-steps run Bullet's loop to the 20-iteration cap: 12.2 trips per wave-step for 4.45 per env-step in lockstep;
+   * DESIGN.md section 4).  Ignored with a fused actor. */
+  int32_t rollout_ready_lanes;
+  int32_t reserved1;
+
   ArmEnvChain chain;
 } ArmEnvConfig;
 

@@ -714,6 +714,41 @@ def test_benchmarked_launch_shape_free_running_vs_oracle_f32(envs, O, kuka):
     assert cnt["nonfinite"] == 0
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("task", ["reach", "push", "pick"])
+def test_lane_asynchronous_rollout_equals_lockstep(envs, task, precision):
+    """armenv_rollout's two schedules (ArmEnvConfig.rollout_ready_lanes): lockstep (0) and lane-asynchronous with several
+    waiting thresholds -- 1 (a tail block on nearly every trip), 7, 33, 64 (every lane waits for the whole wave) -- give the
+    SAME bits: every per-step output, the final state, the counters.  Ragged batch (not a multiple of 64), 20-step episodes
+    (in-place resets while other lanes of the wave are mid-IK), external actions and the in-kernel random policy."""
+    n, T = 2048 + 64 + 5, 45
+    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv, pick=envs.BatchedPickEnv)[task]
+    rng = np.random.default_rng(77)
+    sig = 0.686 if task == "reach" else 0.392
+    acts = torch.from_numpy((rng.standard_normal((T, n, 3)) * sig).clip(-0.7, 0.7).astype(np.float32)).to(DEV)
+    for policy in ("external", "random"):
+        ref = None
+        for k in (0, 1, 7, 33, 64):
+            e = Env(n, device=DEV, seed=13, precision=precision, max_steps=20, rollout_ready_lanes=k, fence_counters=1)
+            if policy == "random":
+                e.set_policy("random", noise_sigma=sig, noise_clip=0.7)
+            e.reset()
+            out = e.rollout(T, acts if policy == "external" else None, want_actions=True, want_terminal_obs=True)
+            out2 = e.rollout(7, acts[:7].contiguous() if policy == "external" else None)       # a second launch continues the same envs
+            got = {kk: out[kk].clone() for kk in ("obs", "reward", "done", "success", "actions", "terminal_obs")}
+            got.update({"obs2": out2["obs"].clone(), "done2": out2["done"].clone()})
+            got.update({"st_" + kk: v.clone() for kk, v in e.get_state().items()})
+            cnt = e.counters()
+            e.close()
+            if ref is None:
+                ref, ref_cnt = got, cnt
+                assert cnt["episodes"] >= 2 * n and cnt["env_steps"] == n * (T + 7)
+            else:
+                for kk in ref:
+                    assert torch.equal(ref[kk], got[kk]), (task, precision, policy, k, kk)
+                assert cnt == ref_cnt, (task, precision, policy, k)
+
+
 def test_rollout_random_policy_matches_oracle(envs, O, kuka):
     """Fused random policy (zero actor + clipped Gaussian noise, main.py:116-117) inside the rollout kernel."""
     n, T = 512, 60
