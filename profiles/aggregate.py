@@ -27,6 +27,8 @@ ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def short(name):
+    if "env_rollout_async_kernel" in name:      # lane-asynchronous schedule (pick's default): POLICY 0 external, 1 in-kernel
+        return "rollout_philox" if ", 1>(" in name else "rollout"
     if "env_rollout_kernel" in name:
         # template argument POLICY: 0 external actions (the headline), 1 in-kernel Philox policy (the bench line's
         # "in_kernel_policy" leg), 2 / 3 fused actors
