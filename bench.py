@@ -314,7 +314,9 @@ def main():
                 if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
                     ops.append(do_gather); gathers += 1
         if world > 1 and gathers == 0:
-            ops.append(do_gather); gathers = 1
+            # a region shorter than --gather-every (the driver's 20 steps) still carries one all-gather; it goes FIRST, so that
+            # the collective (side stream) runs under the launches instead of after them
+            ops.insert(0, do_gather); gathers = 1
         launches = sum(1 for o in ops if o is not do_gather)
         return ops, launches, gathers
 
@@ -347,10 +349,10 @@ def main():
         ev1.synchronize()            # spin on the event: the stream's work is done when it returns
         td = p()
         if world > 1:
-            gather.result()
-            torch.cuda.synchronize(dev)
-            dist.barrier()
+            gather.result()          # the logging collective belongs to the K steps
         torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()           # the contract's closing bracket: synchronize + barrier on both sides of the K steps
         wall = p() - t0
         host_us.update(event0_record=(ta - t0) * 1e6, enqueue=(tb - ta) * 1e6, event1_record=(tc - tb) * 1e6,
                        wait_for_gpu=(td - tc) * 1e6, closing_syncs=(t0 + wall - td) * 1e6)

@@ -6,7 +6,7 @@ A step of env e costs trips(e, t) = updates + 1 FKs.  For a wave of 64 envs over
   lockstep   sum_t max_lane trips      every step ends with the wave's slowest lane (what env_rollout_kernel does)
   async      max_lane sum_t trips      lanes never wait for each other inside the launch (critical path of the slowest env)
   mean       mean_lane sum_t trips     perfect load balance
-and the LAUNCH ends with its slowest wave.  Usage: trip_stats.py [task] [envs] [T] [pre_steps]"""
+and the LAUNCH ends with its slowest wave.  Usage: trip_stats.py [task] [envs] [T] [pre_steps] [envs per wave]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,7 @@ task = sys.argv[1] if len(sys.argv) > 1 else "reach"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 pre = int(sys.argv[4]) if len(sys.argv) > 4 else 600
+LW = int(sys.argv[5]) if len(sys.argv) > 5 else 64        # envs per wave (64 = full wavefronts)
 ch, cfg = O.make_chain("kuka"), O.default_config(task)
 State, reset, stepf = dict(reach=(O.ReachState, O.reach_reset, O.reach_step_autoreset), push=(O.PushState, O.push_reset, O.push_step_autoreset),
                            pick=(O.PickState, O.pick_reset, O.pick_step_autoreset))[task]
@@ -32,9 +33,9 @@ for t in range(pre + T):
         stepf(ch, cfg, st, a, seed=0, iters=it)
     if t >= pre:
         trips[t - pre] = it + 1
-W = trips.reshape(T, n // 64, 64)
+W = trips.reshape(T, n // LW, LW)
 lock = W.max(2).sum(0) / T; asyn = W.sum(0).max(1) / T; mean = W.mean()
-print(f"{task} {n} envs, {T}-step launch after {pre} steps: updates per env-step {trips.mean() - 1:.3f}; trips (FKs) per step:")
+print(f"{task} {n} envs, {LW} per wave, {T}-step launch after {pre} steps: updates per env-step {trips.mean() - 1:.3f}; trips (FKs) per step:")
 print(f"  mean over envs            {mean:.3f}")
 print(f"  lockstep wave  (sum_t max_lane): mean over waves {lock.mean():.3f}  slowest wave {lock.max():.3f}")
 print(f"  async wave     (max_lane sum_t): mean over waves {asyn.mean():.3f}  slowest wave {asyn.max():.3f}")
