@@ -110,8 +110,9 @@ static __global__ __launch_bounds__(256) void counters_sum_kernel(const unsigned
 // them before prefetch_settle it would copy stale data.  To give it no reason to, the three AGPRs are used by nothing
 // else and prefetch_settle itself moves them into VGPRs AFTER its wait, inside the same asm block: what is carried round
 // the loop is those VGPRs (a first version carried the AGPRs and hipcc renamed them with v_accvgpr_mov in FRONT of the
-// wait -- harmless only because the load had been in flight for a whole IK).  The one-step-rollout == step (bit for bit) and rollout == step (1e-6) tests
-// (reach / push / pick, f64 / f32) are the guard.
+// wait -- harmless only because the load had been in flight for a whole IK).  Guards: tests/test_isa_guard.py walks the
+// built code object from the issue to the settle and fails if anything reachable in between touches the three AGPRs (CPU,
+// every build); the rollout == step-launches bitwise tests (reach / push / pick, f64 / f32) catch a wrong value on the GPU.
 struct ActionPrefetch { float x, y, z; };
 AE_DEV void prefetch_issue(const float *src, ActionPrefetch &d) {
   asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:8"

@@ -175,15 +175,16 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
 
 /* Replaces the rollout inner loop of /root/reference/main.py:108-128 (take_action -> noise -> step -> store) for
  * `steps` consecutive env steps of all N envs in ONE kernel launch; the env state stays in registers between steps.
- *   actions_dev  f32 [steps][N][3]: external policy -- the trajectory of `steps` armenv_step calls (bit-identical for
- *                steps == 1; for longer launches to the IK's ~1e-7 rad noise floor: (cos q, sin q) are re-derived from q at
- *                the start of every launch and carried between the steps of one).
+ *   actions_dev  f32 [steps][N][3]: external policy -- exactly the trajectory of `steps` armenv_step calls, bit for bit, for
+ *                any `steps` and any split of the same steps into several launches ((cos q, sin q) of the joints travel
+ *                with q in the handle's state).
  *                NULL: the fused policy installed with armenv_set_policy produces the actions in-kernel.
  *   obs_dev f32 [steps][N][obs_dim], reward_dev f32 [steps][N], done_dev / success_dev u8 [steps][N]: row t holds
  *   what armenv_step would have returned at step t.  actions_out_dev (nullable, f32 [steps][N][3]) receives the
  *   actions taken; terminal_obs_dev (nullable) as in armenv_step, per step.
- * Lanes never synchronise inside the launch, so an env that needs extra IK iterations in one step does not stall
- * the others: throughput follows the mean IK cost per step, not the per-launch maximum. */
+ * Waves never synchronise inside the launch, so an env that needs extra IK iterations in one step stalls only its own
+ * wavefront for that step (lockstep schedule) or only itself (lane-asynchronous schedule, ArmEnvConfig.rollout_ready_lanes):
+ * throughput follows the mean IK cost per step, not the per-launch maximum. */
 int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,
                    uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev, void *stream);
 
