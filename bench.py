@@ -314,10 +314,13 @@ def main():
                 if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
                     ops.append(do_gather); gathers += 1
         if world > 1 and gathers == 0:
-            # a region shorter than --gather-every (the driver's 20 steps) still carries one all-gather; it goes FIRST, so that
-            # the collective (side stream) runs under the launches instead of after them
-            ops.insert(0, do_gather); gathers = 1
-        launches = sum(1 for o in ops if o is not do_gather)
+            # a region shorter than --gather-every (the driver's 20 steps) still carries one all-gather: of the returns as they
+            # stand when the region starts (snapshot taken here, outside the clock), enqueued right after the launches so that
+            # neither its host calls nor the collective itself (side stream, not waiting for the launches) delay the K steps
+            snap = env.episode_stats()[0]
+            torch.cuda.synchronize(dev)
+            ops.append(lambda: gather.launch(snap, ready=True)); gathers = 1
+        launches = len(ops) - gathers
         return ops, launches, gathers
 
     def run(k):

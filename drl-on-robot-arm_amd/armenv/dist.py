@@ -67,16 +67,16 @@ class ReturnGatherer:
     def _host_backend(self):
         return self.side is not None and self.world > 1 and dist.get_backend() != "nccl"
 
-    def launch(self, local_returns):
-        """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs."""
+    def launch(self, local_returns, ready=False):
+        """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs.
+        ready=True: the tensor is already complete (its producer was synchronised earlier), so the side stream does not wait
+        for the work currently queued on the producer stream -- the collective then runs UNDER that work instead of behind it."""
         if tuple(local_returns.shape) != (self.n_local,):
             raise ValueError(f"local_returns must have shape ({self.n_local},)")
         slot = self.slots[self.launches & 1]
         self.launches += 1
         self._last = slot
-        if slot["work"] is not None:          # the collective that used this slot two launches ago
-            slot["work"].wait()
-            slot["work"] = None
+        prev, slot["work"] = slot["work"], None      # the collective that used this slot two launches ago
         if self._host_backend():
             # debugging path (several ranks sharing one GPU cannot use RCCL): stage through the host with gloo
             host = local_returns.detach().to("cpu", torch.float32)
@@ -86,8 +86,11 @@ class ReturnGatherer:
             return
         if self.side is not None:
             cur = torch.cuda.current_stream(self.device)
-            self.side.wait_stream(cur)
+            if not ready:
+                self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
+                if prev is not None:
+                    prev.wait()               # orders the SIDE stream (where the slot is refilled) behind that collective
                 slot["stage"].copy_(local_returns)
                 # the producer's tensor is read on the side stream: keep the caching allocator from recycling it early
                 local_returns.record_stream(self.side)
