@@ -34,7 +34,12 @@ while time.time() - t0 < 0.2:
     w.rollout(100, None, out=b); torch.cuda.synchronize()
 w.close(); del b
 e = Env(n, device=dev, seed=0, precision=a.precision, **kw)
-if a.policy != "external":
+if a.policy.startswith("actor"):      # the golden TD3 actor (tests/golden/td3_actor_seed0.npz), exploration noise of run()
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "td3_actor_seed0.npz"))
+    sd = {k: torch.from_numpy(g[k.replace(".", "_")]) for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+    e.set_policy(a.policy, action_bound=0.7, noise_sigma=0.686, noise_clip=0.7, actor_state_dict=sd)
+elif a.policy != "external":
     e.set_policy(a.policy)
 e.reset()
 cur = [0]
