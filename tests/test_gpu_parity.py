@@ -624,14 +624,20 @@ def test_rollout_external_actions_equals_step_calls(envs, precision):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("task", ["reach", "push", "pick"])
 @pytest.mark.parametrize("precision", [64, 32])
-def test_rollout_500_equals_500_step_launches_bitwise(envs, precision):
+def test_rollout_500_equals_500_step_launches_bitwise(envs, precision, task):
     """The benchmarked launch shape against the gym-style path over a whole reference episode and the reset after it
-    (501 steps, rl_reach_env.py:299): 6 x rollout(100) == one rollout(600) == 600 armenv_step launches, bit for bit."""
-    n, T = 2048, 600
+    (501 steps, rl_reach_env.py:299): 6 x rollout(100) == one rollout(600) == 600 armenv_step launches, bit for bit --
+    outputs, final state, counters -- for the three tasks (pick through its lane-asynchronous default schedule)."""
+    n, T = (2048, 600) if task == "reach" else (1024, 600)
+    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv, pick=envs.BatchedPickEnv)[task]
     gen = torch.Generator(device=DEV); gen.manual_seed(77)
-    acts = (torch.randn((T, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous()
-    a, b, c = (_mk(envs, n, seed=31, precision=precision) for _ in range(3))
+    if task == "reach":
+        acts = (torch.randn((T, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous()
+    else:
+        acts = (torch.randn((T, n, 3), device=DEV, generator=gen) * 0.392).contiguous()       # main.py:484: unclipped
+    a, b, c = (Env(n, device=DEV, seed=31, precision=precision) for _ in range(3))
     for e in (a, b, c):
         e.reset()
     whole = {k: v.clone() for k, v in a.rollout(T, acts).items()}
