@@ -408,6 +408,42 @@ def test_clamp_applies_to_rollouts_and_ik_entry(envs, O, kuka):
     a.close(); b.close()
 
 
+def test_asymmetric_joint_limits_and_other_chain(envs, O, kuka):
+    """The limit handling away from its fast path: a chain whose limits do NOT straddle zero for one joint (the max |q|
+    pre-test is then always true: ArmEnv's lim_min = -1) and a tight asymmetric elbow range, on the generic-FK path; the
+    projection and the fence counters follow the oracle configured with the same limits."""
+    import copy
+    from armenv.urdf import builtin_chain
+    n = 2048
+    rng = np.random.default_rng(9)
+    ch = copy.deepcopy(builtin_chain("kuka"))
+    ch.limit_lo = list(ch.limit_lo); ch.limit_hi = list(ch.limit_hi)
+    ch.limit_lo[3], ch.limit_hi[3] = -1.9, -0.4          # elbow: a range that does not contain 0
+    ch.limit_lo[5], ch.limit_hi[5] = 0.2, 1.6            # wrist: asymmetric, positive only
+    cfg1 = O.default_config(); cfg1.clamp_joint_limits = 1
+    cfg1.lim_lo[:] = ch.limit_lo; cfg1.lim_hi[:] = ch.limit_hi
+    cfg0 = O.default_config(); cfg0.lim_lo[:] = ch.limit_lo; cfg0.lim_hi[:] = ch.limit_hi
+    lo, hi = np.array(ch.limit_lo), np.array(ch.limit_hi)
+    q = np.tile(np.array(O.INIT_Q), (n, 1)) + rng.uniform(-0.25, 0.25, (n, 7))
+    a = _actions(rng, n)
+    for fk_path in (0, 1):
+        e = _mk(envs, n, auto_reset=False, chain=ch, fk_path=fk_path, clamp_joint_limits=1, fence_counters=1)
+        e.reset(); e.set_state(q=q)
+        c0 = e.counters()
+        e.step(torch.from_numpy(a).to(DEV))
+        st = O.ReachState(n); st.q[:] = q; st.goal[:] = _np(e.get_state()["goal"])
+        p0, _ = O.fk(kuka, q)
+        tgt = np.clip(p0 + 0.02 * a.astype(np.float64), [0.2, -0.3, 0.0], [0.7, 0.3, 0.55])
+        flags = O.fence_flags(kuka, cfg0, q, tgt)
+        O.reach_step(kuka, cfg1, st, a)
+        qg = _np(e.get_state()["q"])
+        ok = np.abs(qg - st.q).max(1) < 1e-6
+        assert ok.mean() > 0.999 and (qg >= lo - 1e-12).all() and (qg <= hi + 1e-12).all()
+        hits = int(((flags & 1) != 0).sum())
+        assert hits > 50 and abs((e.counters()["limit_steps"] - c0["limit_steps"]) - hits) <= 2
+        e.close()
+
+
 def test_reward_done_success_thresholds(envs, O, kuka):
     """Drive the branch of rl_reach_env.py:299-309 through the kernel: goals placed just inside / outside
     reach_dis of where the arm ends up, and step counters around max_steps (strict > and <)."""
@@ -1569,6 +1605,37 @@ def test_step_is_capturable_in_a_hip_graph(envs):
         assert torch.equal(o, ref[t][0]) and torch.equal(r, ref[t][1]) and torch.equal(d, ref[t][2]), t
     assert graphed.counters()["env_steps"] == 6 * n
     eager.close(); graphed.close()
+
+
+def test_rollout_is_capturable_in_a_hip_graph(envs):
+    """armenv_rollout (both schedules) inside a HIP graph: a captured 16-step launch over static action / output buffers,
+    replayed four times with fresh actions copied into the static buffer, equals the same 64 steps run eagerly."""
+    n, T = 2048, 16
+    for Env, kw in ((envs.BatchedReachEnv, {}), (envs.BatchedPickEnv, {})):          # lockstep, lane-asynchronous (pick default)
+        gen = torch.Generator(device=DEV); gen.manual_seed(5)
+        acts = (torch.randn((4, T, n, 3), device=DEV, generator=gen) * 0.4).contiguous()
+        eager = Env(n, device=DEV, seed=12, max_steps=30, **kw); graphed = Env(n, device=DEV, seed=12, max_steps=30, **kw)
+        eager.reset(); graphed.reset()
+        ref = [{k: v.clone() for k, v in eager.rollout(T, acts[j]).items()} for j in range(4)]
+        static = acts[0].clone()
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        bufs = {}
+        with torch.cuda.stream(side):
+            launch, out = graphed.bind_rollout(T, static, out=bufs)          # buffers allocated outside the capture
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            graphed.rollout(T, static, out=bufs)
+        for j in range(4):
+            static.copy_(acts[j])
+            g.replay()
+            torch.cuda.synchronize()
+            for k in ("obs", "reward", "done", "success"):
+                assert torch.equal(out[k], ref[j][k]), (Env.__name__, j, k)
+        assert graphed.counters() == eager.counters()
+        eager.close(); graphed.close()
 
 
 def test_two_handles_on_two_streams_are_independent(envs):
