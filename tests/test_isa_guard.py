@@ -29,6 +29,8 @@ import isa  # noqa: E402
 def kernels():
     if not os.path.exists(isa.LIB):
         pytest.skip("libarmenv.so is not built")
+    if not os.path.exists(os.path.join(isa.LLVM, "llvm-objdump")):
+        pytest.skip("the ROCm LLVM tools (llvm-objdump, llvm-readelf) are not installed")
     rows = isa.all_kernels()
     assert len(rows) > 100
     return rows
