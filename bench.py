@@ -367,10 +367,14 @@ def main():
     wall, gpu_ms, launches, gathers, dc = timed(args.steps)
     host_us_main = dict(host_us)
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    t = torch.tensor([wall, gpu_ms * 1e-3], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    per_rank = None
+    if world > 1:       # every rank's wall clock and kernel time of the region (stragglers show here); value uses the MAX wall
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = {"wall_ms": [float(x[0]) * 1e3 for x in allt], "kernel_ms": [float(x[1]) * 1e3 for x in allt]}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    wall_max = float(t[0].item())
     counters = env.counters()
     digests = None
     if args.state_digest:
@@ -461,7 +465,7 @@ def main():
             "config": {"workload": workload,
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
-                       "gathers_in_timed_region": gathers, "state_digest": digests,
+                       "gathers_in_timed_region": gathers, "state_digest": digests, "per_rank": per_rank,
                        # where the wall clock of the timed region went on the host (us): recording the two HIP events,
                        # enqueueing the launches, waiting for the GPU, the closing synchronisations
                        "host_us": host_us_main,
