@@ -151,6 +151,40 @@ def step_api_graph(env, pool, next_actions, n, k2, dev):
     return {"value": n * k3 / w3, "unit": "env-steps/s", "steps": k3, "steps_per_graph": G,
             "avg_launch_us": e0.elapsed_time(e1) * 1e3 / k3}
 
+def large_batch(Env, dev, args):
+    """One GPU holds far more than 65 536 envs (288 GB of HBM; this state is 209 B per env): the same 100-step rollout at
+    --large-batch envs.  With more waves than SIMDs the engine launches env_rollout_kernel<..., WAVES = 2> (<= 256 registers
+    per lane, two waves per SIMD: the second wave issues into the first one's dependent-f64 waits), same bits."""
+    n, T = int(args.large_batch), 100
+    gen = torch.Generator(device=dev); gen.manual_seed(4242)
+    fresh = lambda: (torch.randn((T, n, 3), device=dev, generator=gen) * 0.686).clamp_(-0.7, 0.7)   # i.i.d. rows, never replayed
+    e = Env(n, device=dev, seed=0, precision=args.precision)
+    e.reset()
+    out = {}
+    acts = fresh()
+    for _ in range(7):                 # past the first time-limit resets: the steady state of the workload
+        e.rollout(T, acts, out=out)
+        acts = fresh()
+    k = 3
+    timed_acts = [acts] + [fresh() for _ in range(k - 1)]
+    torch.cuda.synchronize(dev)
+    c0 = e.counters()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for a in timed_acts:
+        e.rollout(T, a, out=out)
+    ev1.record(); torch.cuda.synchronize(dev)
+    c1 = e.counters()
+    e.close()
+    us = ev0.elapsed_time(ev1) * 1e3 / (k * T)
+    upd = (c1["ik_updates"] - c0["ik_updates"]) / (c1["env_steps"] - c0["env_steps"])
+    tf = (upd * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n / (us * 1e-6) / 1e12
+    peak = F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3
+    return {"envs": n, "value": n / (us * 1e-6), "unit": "env-steps/s", "us_per_step": us, "steps": k * T,
+            "kernel": "reach_rollout<f%d,kuka> built for two waves per SIMD" % args.precision,
+            "valu": {"achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "ik_updates_per_env_step": upd}}
+
+
 def parity_fence(Env, n, dev, args, pool):
     """The same workload on a second handle with the fence counters on (ArmEnvConfig.fence_counters): the share of env
     steps whose IK result lies outside the URDF joint limits (Bullet's limit constraint would push back inside
@@ -219,6 +253,9 @@ def main():
     ap.add_argument("--state-digest", action="store_true",
                     help="add config.state_digest: per rank, the sha256 of the joint angles of its envs right after the timed "
                          "region (tests: rank shards reproduce the single-handle trajectory)")
+    ap.add_argument("--large-batch", type=int, default=1048576,
+                    help="extra leg (reach, external actions, one GPU): the same rollout at this many envs on ONE GPU -- more "
+                         "waves than SIMDs, so the engine runs the two-waves-per-SIMD form of the kernel (0 = skip)")
     ap.add_argument("--fence-steps", type=int, default=1200,
                     help="length of the extra parity-fence leg (second handle, fence_counters=1; 0 = skip): how often this "
                          "workload leaves the URDF joint limits / drives the flange below z = 0.05")
@@ -498,6 +535,10 @@ def main():
             line["in_kernel_policy"] = in_kernel
         if world == 1 and args.fence_steps > 0:
             line["parity_fence"] = parity_fence(Env, n, dev, args, pool)
+        if world == 1 and args.large_batch > n and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
+            del pool, bufs
+            torch.cuda.empty_cache()
+            line["large_batch"] = large_batch(Env, dev, args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.precision)
         print(json.dumps(line), flush=True)

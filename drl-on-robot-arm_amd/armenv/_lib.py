@@ -40,7 +40,7 @@ class ArmEnvConfig(C.Structure):
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
-        ("fence_z", C.c_double), ("rollout_ready_lanes", C.c_int32), ("reserved1", C.c_int32),
+        ("fence_z", C.c_double), ("rollout_ready_lanes", C.c_int32), ("rollout_waves_per_simd", C.c_int32),
         ("chain", ArmEnvChain),
     ]
 

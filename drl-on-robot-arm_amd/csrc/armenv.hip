@@ -163,6 +163,7 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   if (cfg->precision != 64 && cfg->precision != 32) return fail(ARMENV_EINVAL, "armenv_create: precision must be 32 or 64");
   if (cfg->task < ARMENV_TASK_REACH || cfg->task > ARMENV_TASK_PICK) return fail(ARMENV_EINVAL, "armenv_create: unknown task %d", cfg->task);
   if (cfg->ik_max_iters < 0 || cfg->ik_max_iters > 1000) return fail(ARMENV_EINVAL, "armenv_create: ik_max_iters out of range");
+  if (cfg->rollout_waves_per_simd < 0 || cfg->rollout_waves_per_simd > 2) return fail(ARMENV_EINVAL, "armenv_create: rollout_waves_per_simd must be 0, 1 or 2");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(ARMENV_ENODEV, "armenv_create: no HIP device is visible (this library has no CPU fallback)");

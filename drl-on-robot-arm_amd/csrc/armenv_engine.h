@@ -109,6 +109,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   static constexpr int block = 256;   // four waves: one per SIMD of a CU; the f16x3 actor phase is a 4-wave workgroup
   int cus = 256;
   int ready_lanes = 0;   // > 0: rollouts run lane-asynchronously (env_rollout_async_kernel)
+  int waves_cfg = 0;     // ArmEnvConfig.rollout_waves_per_simd: 0 auto, 1, 2
   // Workgroup size of the env kernels that have no workgroup phase (step, rollout without a fused actor): the IK keeps
   // one wave per SIMD, so a batch that does not fill the chip is launched as smaller workgroups -- the dispatcher then
   // spreads its waves over all CUs (1 or 2 per CU) instead of packing four onto a quarter or half of them, and a wave
@@ -202,6 +203,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     P.ik.exit_mode = cfg.ik_exit_mode;
     P.ik.angle_f32 = cfg.ik_angle_f32;
     P.ik.clamp_limits = cfg.clamp_joint_limits;
+    waves_cfg = cfg.rollout_waves_per_simd;
     ready_lanes = cfg.rollout_ready_lanes < 0 ? 0 : (cfg.rollout_ready_lanes > 64 ? 64 : cfg.rollout_ready_lanes);
     P.ik.fence = cfg.fence_counters;
     P.fence_z = (T)cfg.fence_z;
@@ -236,9 +238,23 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
+  // Two waves per SIMD (env_rollout_kernel<..., 2>) when the batch has more waves than the chip has SIMDs, or when the
+  // caller asks for it (ArmEnvConfig.rollout_waves_per_simd); never with a fused actor.
+  bool two_waves() const {
+    if (waves_cfg == 1) return false;
+    if (waves_cfg == 2) return true;
+    return (P.n + 63) / 64 > (int64_t)4 * cus;
+  }
   template <int POLICY>
   void launch_rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
+    if constexpr (!kActor) {
+      if (two_waves()) {
+        hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
+                           steps, actions, io0, actions_out);
+        return;
+      }
+    }
     const int b = kActor ? block : lane_block();
     hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, pol, steps,
                        actions, io0, actions_out);

@@ -805,10 +805,22 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io
 // update count instead of the per-launch MAX.
 // POLICY is a compile-time copy of pol.kind: the external-action variant carries no actor / noise code, which keeps it
 // free of the register spills the fused-actor variant's 128 MFMA accumulators would otherwise force on it.
-template <class Lane, typename T, int POLICY>
-__global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
-                                                          const float *actions, StepIO io0, float *actions_out) {
+// WAVES: waves per SIMD the kernel is built for.
+//   1  the whole 512-register file for one wave (f64: 256 VGPRs + AGPRs as spill space, no scratch).  A batch of up to
+//      64 x #SIMDs envs (65 536 on MI355X: BASELINE configs 2 and 5) is exactly one wave per SIMD, so nothing else could
+//      run beside it anyway; the next action is prefetched through AGPRs (prefetch_issue / prefetch_settle).
+//   2  at most 256 registers per lane, so that TWO waves share a SIMD: a larger batch no longer runs as consecutive rounds
+//      of single waves -- the second wave issues into the 22 % of the first one's cycles that are dependent-f64 waits and
+//      scalar instructions (measured: 1 048 576 envs 102 -> 87 us per step, 10.3 -> 12.0e9 env-steps/s; at one wave per
+//      SIMD the same code is no slower).  The compiler spills ~60 dwords per lane to scratch to get there, which the other
+//      wave's issue slots cover; the action is an ordinary load at the top of the step (the other wave covers that too).
+//      Same arithmetic, same bits.  The engine picks it when the batch has more waves than SIMDs and no fused actor.
+template <class Lane, typename T, int POLICY, int WAVES = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const float *actions, StepIO io0, float *actions_out) {
   constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
+  static_assert(WAVES == 1 || (WAVES == 2 && !kActor), "the fused actors need the whole register file");
+  constexpr bool kPrefetch = POLICY == ARMENV_POLICY_EXTERNAL && WAVES == 1;
   __shared__ float4 w1_lds[kActor ? ACTOR_W1_LDS_FLOATS / 4 : 1];
   __shared__ uint4 w2_ring[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_RING_UINT4 : 1];
   int nw = 4;   // live waves of this workgroup (the last one may be ragged; num_envs is a multiple of 64)
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   uint32_t episode = (POLICY != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
   if constexpr (POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3) L.refresh_obs(P);
   float an[3] = {0.f, 0.f, 0.f};
-  if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+  if constexpr (kPrefetch) {
     an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2];
     // settle this load before the loop: otherwise the loop header inherits a pending load on these registers from the
     // entry edge and hipcc puts an in-order vmcnt wait at the top of EVERY step, which also waits for the previous
@@ -840,10 +852,13 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
   ActionPrefetch an_next{0.f, 0.f, 0.f};
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
-    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+    if constexpr (kPrefetch) {
       a[0] = (T)an[0]; a[1] = (T)an[1]; a[2] = (T)an[2];
       // prefetch the next step's action (the last step re-reads its own); settled inside env_step, after the IK
       prefetch_issue(actions + ((int64_t)(t + 1 < steps ? t + 1 : t) * n + i) * 3, an_next);
+    } else if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+      const float *ap = actions + ((int64_t)t * n + i) * 3;
+      a[0] = (T)ap[0]; a[1] = (T)ap[1]; a[2] = (T)ap[2];
     } else {
       float mu[3] = {0.f, 0.f, 0.f};
       if constexpr (POLICY == ARMENV_POLICY_ACTOR) {
@@ -881,7 +896,7 @@ __global__ __launch_bounds__(256) void env_rollout_kernel(EnvParams<T> P, Policy
     const uint32_t before = L.n_done;
     // the fused actor needs the whole register file between two env steps: the link frames are not carried across it
     if constexpr (kActor) L.have_S = false;
-    if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) {
+    if constexpr (kPrefetch) {
       L.env_step(P, i, a, io, &an_next, &an);
     } else {
       L.env_step(P, i, a, io);

@@ -791,6 +791,41 @@ def test_lane_asynchronous_rollout_equals_lockstep(envs, task, precision):
                 assert cnt == ref_cnt, (task, precision, policy, k)
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("task", ["reach", "push"])
+def test_two_waves_per_simd_rollout_equals_one(envs, task, precision):
+    """ArmEnvConfig.rollout_waves_per_simd: the rollout kernel built for two waves per SIMD (<= 256 registers per lane,
+    ordinary action loads, the overflow in scratch) against the one-wave form (whole register file, AGPR action prefetch):
+    the same bits for outputs, state and counters, with external actions and the in-kernel random policy; 0 picks by batch
+    size (one wave per SIMD up to 64 x #SIMDs envs)."""
+    n, T = 4096 + 64 + 3, 50
+    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv)[task]
+    rng = np.random.default_rng(3)
+    sig = 0.686 if task == "reach" else 0.392
+    acts = torch.from_numpy((rng.standard_normal((T, n, 3)) * sig).clip(-0.7, 0.7).astype(np.float32)).to(DEV)
+    for policy in ("external", "random"):
+        ref = None
+        for w in (1, 2, 0):
+            e = Env(n, device=DEV, seed=21, precision=precision, max_steps=20, rollout_waves_per_simd=w)
+            if policy == "random":
+                e.set_policy("random", noise_sigma=sig, noise_clip=0.7)
+            e.reset()
+            out = e.rollout(T, acts if policy == "external" else None, want_actions=True, want_terminal_obs=True)
+            got = {kk: out[kk].clone() for kk in ("obs", "reward", "done", "success", "actions", "terminal_obs")}
+            got.update({"st_" + kk: v.clone() for kk, v in e.get_state().items()})
+            cnt = e.counters()
+            e.close()
+            if ref is None:
+                ref, ref_cnt = got, cnt
+            else:
+                for kk in ref:
+                    assert torch.equal(ref[kk], got[kk]), (task, precision, policy, w, kk)
+                assert cnt == ref_cnt
+    from armenv import ArmEnvError
+    with pytest.raises(ArmEnvError):
+        Env(64, device=DEV, rollout_waves_per_simd=3)
+
+
 def test_rollout_random_policy_matches_oracle(envs, O, kuka):
     """Fused random policy (zero actor + clipped Gaussian noise, main.py:116-117) inside the rollout kernel."""
     n, T = 512, 60
@@ -1907,6 +1942,8 @@ def test_bench_line_contract():
     assert 0.0 < pf["limit_step_rate"] < 0.5 and 0.0 <= pf["low_flange_step_rate"] < 0.1 and pf["env_steps_counted"] >= 65536 * 500
     assert d["value"] > 1e9 and d["nonfinite_states"] == 0
     assert d["step_api"]["value"] > 5e8
+    lb = d["large_batch"]             # 1 048 576 envs on the one GPU: the two-waves-per-SIMD form of the rollout kernel
+    assert lb["envs"] == 1048576 and lb["value"] > 1.05e10 and lb["valu"]["frac"] > 0.55
 
 
 def test_bench_two_ranks_on_one_gpu_shard_the_trajectory(envs):

@@ -48,11 +48,14 @@ def test_every_kernel_variant_is_present(kernels):
                 assert f"{task}_step_{prec}_{chain}" in names
                 for p in range(4):
                     assert f"{task}_rollout_{prec}_{chain}_p{p}" in names
+                for p in range(2):                                   # two-waves-per-SIMD and lane-asynchronous variants
+                    assert f"{task}_rollout_{prec}_{chain}_p{p}_w2" in names
+                    assert f"{task}_rollout_async_{prec}_{chain}_p{p}" in names
 
 
 def test_no_scratch_in_step_and_unfused_rollout_kernels(kernels):
-    sel = _env_kernels(kernels, lambda sn: re.search(r"_(step|reset)_f(64|32)_", sn) or re.search(r"_rollout_f(64|32)_\w+_p[01]$", sn)
-                       or sn.startswith(("fk_", "ik_")))
+    sel = _env_kernels(kernels, lambda sn: re.search(r"_(step|reset)_f(64|32)_", sn) or re.search(r"_rollout_f(64|32)_[a-z]+_p[01]$", sn)
+                       or re.search(r"_rollout_async_f(64|32)_[a-z]+_p[01]$", sn) or sn.startswith(("fk_", "ik_")))
     assert len(sel) >= 3 * 2 * 3 * 3
     for sn, md, ins in sel:
         assert md["scratch"] == 0, (sn, md)            # (vgpr_spill_count may be > 0: spills into AGPRs, not memory)
@@ -93,7 +96,7 @@ def _reachable_before(ins, start, stop):
 
 
 def test_action_prefetch_agprs_are_untouched_between_issue_and_settle(kernels):
-    sel = _env_kernels(kernels, lambda sn: re.search(r"_rollout_f(64|32)_\w+_p0$", sn))
+    sel = _env_kernels(kernels, lambda sn: re.search(r"_rollout_f(64|32)_[a-z]+_p0$", sn))
     assert len(sel) == 18
     for sn, md, ins in sel:
         triples = _prefetch_triples(ins)
@@ -133,8 +136,13 @@ def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
 
 def test_register_budget_of_the_headline_kernels(kernels):
     """One wave per SIMD by design (512 registers per lane): the f64 step / external-rollout kernels use the whole VGPR file
-    and park the overflow in AGPRs, never in scratch; the f32 engine's step kernel fits two waves per SIMD."""
+    and park the overflow in AGPRs, never in scratch; the f32 engine's step kernel fits two waves per SIMD; the _w2 variants of
+    the rollout kernel fit two waves per SIMD in every precision (at most 256 registers, the overflow in scratch)."""
     by = {sn: md for sn, _, md, _ in kernels}
+    w2 = [(sn, md) for sn, _, md, _ in kernels if sn.endswith("_w2")]
+    assert len(w2) == 3 * 2 * 3 * 2
+    for sn, md in w2:
+        assert md["vgpr"] <= 256 and md["agpr"] == 0 and md["lds"] == 0, (sn, md)
     assert by["reach_rollout_f64_kuka_p0"]["vgpr"] <= 512 and by["reach_rollout_f64_kuka_p0"]["scratch"] == 0
     assert by["reach_step_f32_kuka"]["vgpr"] <= 256
     assert by["reach_rollout_f64_kuka_p0"]["lds"] == 0 and by["reach_step_f64_kuka"]["lds"] == 0

@@ -78,7 +78,7 @@ def demangle(names):
 
 
 def short_name(demangled):
-    """env_rollout_kernel<ReachLane<armenv::KukaChain, double>, double, 0>(...) -> reach_rollout_f64_kuka_p0"""
+    """env_rollout_kernel<ReachLane<armenv::KukaChain, double>, double, 0, 2>(...) -> reach_rollout_f64_kuka_p0_w2"""
     m = re.match(r"(?:void )?(\w+)<(.*)>\(", demangled)
     if not m:
         return demangled.split("(")[0]
@@ -87,11 +87,18 @@ def short_name(demangled):
                                                  ("push" if "CubeLane" in targs else ""))
     chain = "kuka" if "KukaChain" in targs else ("diana" if "DianaChain" in targs else ("generic" if "GenericChain" in targs else ""))
     prec = "f64" if "double" in targs else ("f32" if "float" in targs else "")
-    tail = re.search(r", (\d+)>?$", targs)
     k = kern.replace("env_", "").replace("_kernel", "")
     parts = [p for p in (lane, k, prec, chain) if p]
-    if kern == "env_rollout_kernel" and tail:
-        parts.append("p" + tail.group(1))
+    if kern == "env_rollout_kernel":                       # <Lane, T, POLICY, WAVES>
+        m2 = re.search(r", (\d+), (\d+)$", targs)
+        if m2:
+            parts.append("p" + m2.group(1))
+            if m2.group(2) != "1":
+                parts.append("w" + m2.group(2))
+    elif kern == "env_rollout_async_kernel":               # <Lane, T, POLICY>
+        m2 = re.search(r", (\d+)$", targs)
+        if m2:
+            parts.append("p" + m2.group(1))
     if kern == "actor_kernel":
         parts.append(targs.replace(", ", "_"))
     return "_".join(parts)
