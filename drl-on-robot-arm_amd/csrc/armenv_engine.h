@@ -261,6 +261,11 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   }
   template <int POLICY>
   void launch_rollout_async(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
+    if (two_waves()) {
+      hipLaunchKernelGGL((env_rollout_async_kernel<Lane, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
+                         steps, actions, io0, actions_out, (int32_t)ready_lanes);
+      return;
+    }
     const int b = lane_block();
     hipLaunchKernelGGL((env_rollout_async_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, pol, steps,
                        actions, io0, actions_out, (int32_t)ready_lanes);

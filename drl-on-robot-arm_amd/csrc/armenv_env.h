@@ -923,10 +923,11 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
 // the two: 64 is lockstep (one tail per step), 1 runs a tail block on nearly every trip.
 // Per-lane arithmetic, its order and every store are those of env_step: trajectories are bit-identical to the lockstep
 // kernels and to armenv_step launches (tested).  Not used with the fused actors (their MFMA phases are wave-synchronous).
-template <class Lane, typename T, int POLICY>
-__global__ __launch_bounds__(256) void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps,
-                                                                const float *actions, StepIO io0, float *actions_out,
-                                                                int32_t ready_lanes) {
+// WAVES: register budget as for env_rollout_kernel (2: <= 256 registers per lane, for batches with more waves than SIMDs).
+template <class Lane, typename T, int POLICY, int WAVES = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const float *actions, StepIO io0,
+                              float *actions_out, int32_t ready_lanes) {
   static_assert(POLICY == ARMENV_POLICY_EXTERNAL || POLICY == ARMENV_POLICY_RANDOM, "no wave-synchronous policy phases here");
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;

@@ -792,14 +792,14 @@ def test_lane_asynchronous_rollout_equals_lockstep(envs, task, precision):
 
 
 @pytest.mark.parametrize("precision", [64, 32])
-@pytest.mark.parametrize("task", ["reach", "push"])
+@pytest.mark.parametrize("task", ["reach", "push", "pick"])
 def test_two_waves_per_simd_rollout_equals_one(envs, task, precision):
     """ArmEnvConfig.rollout_waves_per_simd: the rollout kernel built for two waves per SIMD (<= 256 registers per lane,
     ordinary action loads, the overflow in scratch) against the one-wave form (whole register file, AGPR action prefetch):
     the same bits for outputs, state and counters, with external actions and the in-kernel random policy; 0 picks by batch
     size (one wave per SIMD up to 64 x #SIMDs envs)."""
     n, T = 4096 + 64 + 3, 50
-    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv)[task]
+    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv, pick=envs.BatchedPickEnv)[task]   # pick: lane-asynchronous
     rng = np.random.default_rng(3)
     sig = 0.686 if task == "reach" else 0.392
     acts = torch.from_numpy((rng.standard_normal((T, n, 3)) * sig).clip(-0.7, 0.7).astype(np.float32)).to(DEV)

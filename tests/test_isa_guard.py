@@ -140,7 +140,7 @@ def test_register_budget_of_the_headline_kernels(kernels):
     the rollout kernel fit two waves per SIMD in every precision (at most 256 registers, the overflow in scratch)."""
     by = {sn: md for sn, _, md, _ in kernels}
     w2 = [(sn, md) for sn, _, md, _ in kernels if sn.endswith("_w2")]
-    assert len(w2) == 3 * 2 * 3 * 2
+    assert len(w2) == 3 * 2 * 3 * 2 * 2              # lockstep and lane-asynchronous
     for sn, md in w2:
         assert md["vgpr"] <= 256 and md["agpr"] == 0 and md["lds"] == 0, (sn, md)
     assert by["reach_rollout_f64_kuka_p0"]["vgpr"] <= 512 and by["reach_rollout_f64_kuka_p0"]["scratch"] == 0

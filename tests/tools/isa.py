@@ -95,10 +95,12 @@ def short_name(demangled):
             parts.append("p" + m2.group(1))
             if m2.group(2) != "1":
                 parts.append("w" + m2.group(2))
-    elif kern == "env_rollout_async_kernel":               # <Lane, T, POLICY>
-        m2 = re.search(r", (\d+)$", targs)
+    elif kern == "env_rollout_async_kernel":               # <Lane, T, POLICY, WAVES>
+        m2 = re.search(r", (\d+), (\d+)$", targs)
         if m2:
             parts.append("p" + m2.group(1))
+            if m2.group(2) != "1":
+                parts.append("w" + m2.group(2))
     if kern == "actor_kernel":
         parts.append(targs.replace(", ", "_"))
     return "_".join(parts)
