@@ -234,7 +234,8 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   }
   int step(const StepIO &io, hipStream_t s) override {
     const int b = lane_block();
-    hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, io);
+    if (two_waves()) hipLaunchKernelGGL((env_step_kernel<Lane, T, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+    else hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, io);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }

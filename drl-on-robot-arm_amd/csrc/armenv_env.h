@@ -758,8 +758,9 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams<T> P, const ui
 // One env step per launch: load state -> FK -> target = clip(p + dv a) -> DLS IK loop -> FK -> (push: contact) ->
 // reward / done -> obs pack -> episode accounting -> optional in-place reset -> store state.
 // Lane = ReachLane (rl_reach_env.py:219-319), PushLane (rl_push_env.py:310-440) or PickLane (rl_pick_env.py:310-440).
-template <class Lane, typename T>
-__global__ __launch_bounds__(256) void env_step_kernel(EnvParams<T> P, StepIO io) {
+// WAVES: register budget as for env_rollout_kernel (2: <= 256 registers per lane, for batches with more waves than SIMDs).
+template <class Lane, typename T, int WAVES = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void env_step_kernel(EnvParams<T> P, StepIO io) {
   TL_STAMP(tl0);
 #ifdef ARMENV_TIMELINE
   const unsigned tl_launch = __hip_atomic_load(&g_tl_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

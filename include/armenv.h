@@ -132,7 +132,7 @@ typedef struct ArmEnvConfig {
    * env-steps run Bullet's loop to the 20-iteration cap: 12.2 trips per wave-step for 4.45 per env-step in lockstep;
    * DESIGN.md section 4).  Ignored with a fused actor. */
   int32_t rollout_ready_lanes;
-  /* Register budget of the lockstep rollout kernel.  1: one wave per SIMD with the whole register file (the shape of a batch
+  /* Register budget of the step and rollout kernels.  1: one wave per SIMD with the whole register file (the shape of a batch
    * of up to 64 x #SIMDs envs: 65 536 on MI355X).  2: at most 256 registers per lane so that two waves share a SIMD -- the
    * right shape for larger batches (+17 % at 1 048 576 envs), same bits.  0 (default): chosen from num_envs and the device's
    * CU count.  Ignored with a fused actor (always 1). */

@@ -812,6 +812,9 @@ def test_two_waves_per_simd_rollout_equals_one(envs, task, precision):
             e.reset()
             out = e.rollout(T, acts if policy == "external" else None, want_actions=True, want_terminal_obs=True)
             got = {kk: out[kk].clone() for kk in ("obs", "reward", "done", "success", "actions", "terminal_obs")}
+            for j in range(4):                                   # the step kernel has the same two budgets
+                o, r, d, s_ = e.step(acts[j] if policy == "external" else None)
+                got.update({f"step{j}_obs": o.clone(), f"step{j}_rew": r.clone(), f"step{j}_done": d.clone()})
             got.update({"st_" + kk: v.clone() for kk, v in e.get_state().items()})
             cnt = e.counters()
             e.close()

@@ -95,6 +95,10 @@ def short_name(demangled):
             parts.append("p" + m2.group(1))
             if m2.group(2) != "1":
                 parts.append("w" + m2.group(2))
+    elif kern == "env_step_kernel":                        # <Lane, T, WAVES>
+        m2 = re.search(r", (\d+)$", targs)
+        if m2 and m2.group(1) != "1":
+            parts.append("w" + m2.group(1))
     elif kern == "env_rollout_async_kernel":               # <Lane, T, POLICY, WAVES>
         m2 = re.search(r", (\d+), (\d+)$", targs)
         if m2:
