@@ -27,14 +27,14 @@ ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def short(name):
-    if "env_rollout_async_kernel" in name:      # lane-asynchronous schedule (pick's default): POLICY 0 external, 1 in-kernel
-        return "rollout_philox" if ", 1>(" in name else "rollout"
-    if "env_rollout_kernel" in name:
-        # template argument POLICY: 0 external actions (the headline), 1 in-kernel Philox policy (the bench line's
-        # "in_kernel_policy" leg), 2 / 3 fused actors
-        if ", 1>(" in name:
-            return "rollout_philox"
-        return "rollout"
+    if "env_rollout_async_kernel" in name or "env_rollout_kernel" in name:
+        # template arguments <Lane, T, POLICY, WAVES>.  POLICY: 0 external actions (the headline), 1 in-kernel Philox policy
+        # (the bench line's "in_kernel_policy" leg and the device pre-warm), 2 / 3 fused actors.  WAVES = 2: the
+        # two-waves-per-SIMD build (bench.py's large_batch leg), kept apart from the headline kernel.
+        import re
+        m = re.search(r", (\d+), (\d+)>\(", name)
+        pol, waves = (m.group(1), m.group(2)) if m else ("0", "1")
+        return ("rollout_philox" if pol == "1" else "rollout") + ("_w2" if waves == "2" else "")
     if "env_step_kernel" in name:
         return "step"
     return None

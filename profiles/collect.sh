@@ -35,8 +35,8 @@ pmc() {   # name, counters..., then -- bench args
   timeout 300 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
   find "$OUT/$name" -name '*counter_collection.csv' -exec cp {} "$OUT/${name}_counters.csv" \;
 }
-B100="--steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0"
-B20="--steps 200 --warmup 20 --rollout-steps 20 --no-cpu-baseline --fence-steps 0"    # the driver's launch shape, ten launches
+B100="--steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0 --large-batch 0"
+B20="--steps 200 --warmup 20 --rollout-steps 20 --no-cpu-baseline --fence-steps 0 --large-batch 0"    # the driver's launch shape, ten launches
 if [ "$MODE" = "all" ]; then
 pmc pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES -- $B100
 pmc pmc2 SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- $B100
