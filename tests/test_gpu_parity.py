@@ -745,13 +745,13 @@ def test_benchmarked_launch_shape_free_running_vs_oracle_f64(envs, O, kuka, n):
 
 def test_benchmarked_launch_shape_free_running_vs_oracle_f32(envs, O, kuka):
     """Same shape, f32 engine against the f64 oracle.  The f32 engine's stated tolerance is per step (1e-4 teacher-forced,
-    test_step_teacher_forced_f32); free-running, an IK update count that flips at the 1e-4 residual gate moves an env by up
-    to that residual, so the bound here is statistical: >= 99 % of the envs within 1e-4 at every step, nobody beyond 2e-3,
-    episode totals within 0.1 %."""
+    test_step_teacher_forced_f32); free-running over 600 steps it measures 6e-6 at worst with identical flags and totals
+    (an IK update count that flips at the 1e-4 residual gate could move an env by up to that residual, hence the margins):
+    >= 99.9 % of the envs within 1e-4 at every step, nobody beyond 5e-4, episode totals within 0.1 %."""
     n = 8192
     worst, within, rworst, tot, dq, cnt = _soak_vs_oracle(envs, O, kuka, n, 32)
-    assert within.min() > 0.99, within.min()
-    assert worst.max() < 2e-3, worst.max()
+    assert within.min() >= 0.999, within.min()
+    assert worst.max() < 5e-4, worst.max()
     assert abs(tot["ep_g"] - tot["ep_o"]) <= 1e-3 * tot["ep_o"] and abs(tot["su_g"] - tot["su_o"]) <= max(3, 0.05 * tot["su_o"]), tot
     assert cnt["nonfinite"] == 0
 
