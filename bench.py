@@ -533,14 +533,20 @@ def main():
             line["step_api"] = step_api
         if in_kernel:
             line["in_kernel_policy"] = in_kernel
+        # the secondary legs never take the headline down with them: a failure is reported in place of the leg
+        def leg(name, fn):
+            try:
+                line[name] = fn()
+            except Exception as e:       # noqa: BLE001
+                line[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and args.fence_steps > 0:
-            line["parity_fence"] = parity_fence(Env, n, dev, args, pool)
+            leg("parity_fence", lambda: parity_fence(Env, n, dev, args, pool))
         if world == 1 and args.large_batch > n and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
             del pool, bufs
             torch.cuda.empty_cache()
-            line["large_batch"] = large_batch(Env, dev, args)
+            leg("large_batch", lambda: large_batch(Env, dev, args))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.precision)
+            leg("cpu_baseline", lambda: cpu_baseline(args.precision))
         print(json.dumps(line), flush=True)
     env.close()
     if world > 1:
