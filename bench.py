@@ -80,6 +80,115 @@ STATE_BYTES = {64: 2 * (56 + 112 + 8) + 12 + 2 * 4, 32: 2 * (28 + 56 + 4) + 12 +
 FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + residual + per-step sincos/reward
 
 
+def algo_bytes_per_launch(task, policy, precision, n, steps_per_launch):
+    """Algorithmic bytes one launch moves: caller I/O per env-step + the state read and written once."""
+    io_b, st_b = IO_BYTES, STATE_BYTES[precision]
+    if policy != "external":
+        io_b -= 12                      # no action read
+    if task != "reach":  # obs 36 B instead of 24; state: cube/target/d_last (7 reals; pick 11) r+w instead of goal
+        io_b += 12
+        st_b += 2 * (7 if task == "push" else 11) * (precision // 8) - 12
+    return (io_b * steps_per_launch + st_b) * n
+
+
+def traffic_lookup(kernel, policy, steps_per_launch, n):
+    """HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md), one entry per launch shape:
+    "<kernel>|policy=<p>|T=<steps per launch>|N=<envs>"; only an exact match is reported."""
+    key = "%s|policy=%s|T=%d|N=%d" % (kernel, policy, int(steps_per_launch), n)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic = None
+    if os.path.exists(tpath) and steps_per_launch == int(steps_per_launch):
+        try:
+            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return traffic, key
+
+
+def rooflines(task, policy, precision, n, steps_per_launch, launch_us, updates, kernel):
+    """(roofline, valu, mfma-or-None) of one launch shape: algorithmic HBM bytes against 8 TB/s (with the PMC traffic of the
+    same shape when profiles/traffic.json has it), algorithmic flops against the vector peak (the bound that binds: 29 flop/B,
+    SURVEY.md section 8d), and the fused actor's dense flops against the MFMA peak."""
+    algo = algo_bytes_per_launch(task, policy, precision, n, steps_per_launch)
+    achieved = algo / (launch_us * 1e-6) / 1e9
+    traffic, key = traffic_lookup(kernel, policy, steps_per_launch, n)
+    flops = (updates * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n * steps_per_launch
+    vpeak = F64_VECTOR_PEAK_TFLOPS if precision == 64 else 157.3
+    tf = flops / (launch_us * 1e-6) / 1e12
+    valu = {"bound": "valu", "achieved": tf, "peak": vpeak, "unit": "TFLOP/s", "frac": tf / vpeak,
+            "ik_updates_per_env_step": updates, "algo_flops_per_launch": flops}
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_key": key, "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
+            "binding_bound": "valu", "valu": valu}
+    mfma = None
+    if policy.startswith("actor"):
+        # 2 * (6*256 + 256*256 + 256*3) flop per env-step (SURVEY.md section 8a row A1); both layers on the MFMA
+        af = 2 * (6 * 256 + 256 * 256 + 256 * 3) * n * steps_per_launch
+        if policy == "actor":
+            peak, dt, mult = 157.3, "f32 (v_mfma_f32_32x32x2_f32)", 1
+        else:   # three f16 MFMA passes per useful multiply-add; priced against the dense f16 MFMA peak
+            peak, dt, mult = 2500.0, "f32 emulated by 3 x f16 (v_mfma_f32_32x32x16_f16, hi/lo split)", 3
+        mfma = {"bound": "mfma", "achieved": mult * af / (launch_us * 1e-6) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": mult * af / (launch_us * 1e-6) / 1e12 / peak, "dtype": dt, "useful_tflops": af / (launch_us * 1e-6) / 1e12}
+    return roof, valu, mfma
+
+
+def golden_actor():
+    """weights of TD3_MLP(6,3,0.7) under torch.manual_seed(0): golden G3 (produced by importing the reference's algo.TD3)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "td3_actor_seed0.npz"))
+    return {k: torch.from_numpy(g[k.replace(".", "_")]) for k in
+            ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+
+
+def secondary_leg(envs, dev, task, n, policy, precision, launches, pre_launches, fence_steps=0):
+    """One more BASELINE config timed by the same command: `launches` x armenv_rollout(100) on a fresh
+    handle after `pre_launches` untimed ones, HIP events on the launch stream, with the same roofline bookkeeping as the
+    headline.  config3 = reach 65 536 + fused TD3 actor (policy actor / actor_f16x3), config4 = push 32 768, external actions."""
+    T = 100
+    Env = {"reach": envs.BatchedReachEnv, "push": envs.BatchedPushEnv, "pick": envs.BatchedPickEnv}[task]
+    e = Env(n, device=dev, seed=0, precision=precision)
+    bound, sig = (0.7, 0.7 * 0.98) if task == "reach" else (0.4, 0.4 * 0.98)
+    pool = None
+    if policy == "external":          # i.i.d. rows, consumed in order (the headline's pool shape)
+        S = T * (launches + pre_launches)
+        gen = torch.Generator(device=dev); gen.manual_seed(2000)
+        pool = torch.randn((S, n, 3), device=dev, generator=gen) * sig
+        if task == "reach":
+            pool.clamp_(-bound, bound)
+    else:
+        e.set_policy(policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if task == "reach" else 1e9,
+                     actor_state_dict=golden_actor() if policy.startswith("actor") else None)
+    e.reset()
+    bufs = {}
+    rows = lambda j: None if pool is None else pool[j * T:(j + 1) * T]
+    for j in range(pre_launches):
+        e.rollout(T, rows(j), out=bufs)
+    torch.cuda.synchronize(dev)
+    c0 = e.counters()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); ev1.record(); torch.cuda.synchronize(dev)      # event creation outside the region
+    t0 = time.perf_counter()
+    ev0.record()
+    for j in range(launches):
+        e.rollout(T, rows(pre_launches + j), out=bufs)
+    ev1.record(); torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    c1 = e.counters()
+    kernel = e.kernel_name.replace("_step", "_rollout")
+    e.close()
+    launch_us = ev0.elapsed_time(ev1) * 1e3 / launches
+    updates = (c1["ik_updates"] - c0["ik_updates"]) / max(1, c1["env_steps"] - c0["env_steps"])
+    roof, valu, mfma = rooflines(task, policy, precision, n, T, launch_us, updates, kernel)
+    out = {"value": n * T * launches / wall, "value_kernel": n * T / (launch_us * 1e-6), "unit": "env-steps/s", "envs": n, "task": task,
+           "policy": policy, "steps": T * launches, "steps_per_launch": T, "untimed_steps_before": T * pre_launches,
+           "us_per_step": launch_us / T, "dtype": "f64" if precision == 64 else "f32", "kernel": kernel, "roofline": roof}
+    if mfma:
+        out["roofline_mfma"] = mfma
+    if fence_steps > 0 and pool is not None:
+        out["parity_fence"] = parity_fence(Env, n, dev, precision, pool, min(fence_steps, pool.shape[0]))
+    return out
+
+
 def cpu_baseline(precision, seconds=8.0):
     """Oracle (C, fp64, gcc -O3 -march=native, OpenMP over envs) on the same workload -- same action distribution, auto-reset --
     timed twice on a bounded sample: ONE thread (8 192 envs) and every core this process may use (65 536 envs;
@@ -185,18 +294,20 @@ def large_batch(Env, dev, args):
             "valu": {"achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "ik_updates_per_env_step": upd}}
 
 
-def parity_fence(Env, n, dev, args, pool):
+def parity_fence(Env, n, dev, precision, pool, fence_steps):
     """The same workload on a second handle with the fence counters on (ArmEnvConfig.fence_counters): the share of env
     steps whose IK result lies outside the URDF joint limits (Bullet's limit constraint would push back inside
-    stepSimulation, /root/reference/envs/rl_reach_env.py:258) or that end with the flange below z = 0.05 (arm-table
-    contact).  On those steps this engine's kinematic stepSimulation is known to differ from Bullet's; counted over the
-    second half of the leg (steady state: past the first time-limit resets), with the cost of the bookkeeping."""
+    stepSimulation, /root/reference/envs/rl_reach_env.py:258), that end with the flange below z = 0.05 (arm-table contact),
+    whose IK call ran to its iteration cap, or whose IK call passed through an ill-conditioned damped system.  On the first
+    two this engine's kinematic stepSimulation is known to differ from Bullet's; on the last two no two implementations of the
+    algorithm agree.  Counted over the second half of the leg (steady state: past the first time-limit
+    resets), with the cost of the bookkeeping."""
     T = 100
-    k = max(2, args.fence_steps // T)
+    k = max(2, fence_steps // T)
     S = pool.shape[0]
     out, res = {}, {}
     for fence in (1, 0):
-        e = Env(n, device=dev, seed=0, precision=args.precision, fence_counters=fence)
+        e = Env(n, device=dev, seed=0, precision=precision, fence_counters=fence)
         e.reset()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for j in range(k):
@@ -210,12 +321,16 @@ def parity_fence(Env, n, dev, args, pool):
         e.close()
     c0, c1, ms_on = res[1]
     steps = c1["env_steps"] - c0["env_steps"]
-    return {"limit_step_rate": (c1["limit_steps"] - c0["limit_steps"]) / steps,
-            "low_flange_step_rate": (c1["low_flange_steps"] - c0["low_flange_steps"]) / steps,
-            "fence_z": 0.05, "env_steps_counted": steps, "steps_before_counting": (k // 2) * T,
+    rate = lambda key: (c1[key] - c0[key]) / steps
+    return {"limit_step_rate": rate("limit_steps"), "low_flange_step_rate": rate("low_flange_steps"),
+            "cap_step_rate": rate("cap_steps"), "illcond_step_rate": rate("illcond_steps"),
+            "fence_z": 0.05, "fence_pivot": 1e-2, "ik_max_iters": 20,
+            "env_steps_counted": steps, "steps_before_counting": (k // 2) * T,
             "bookkeeping_cost_frac": ms_on / res[0][2] - 1.0,
-            "meaning": "share of env steps on which Bullet's stepSimulation (joint-limit constraint / arm-table contact) "
-                       "acts and this kinematic engine's does not; parity claims hold outside them"}
+            "meaning": "share of env steps on which (limit, low_flange) Bullet's stepSimulation acts -- joint-limit constraint / "
+                       "arm-table contact -- and this kinematic engine's does not, and on which (cap, illcond) the IK call did not "
+                       "converge / passed through a near-singular pose, where no two implementations of the algorithm agree; "
+                       "parity claims hold outside them"}
 
 
 def prewarm_device(Env, n, dev, precision, ms):
@@ -259,6 +374,9 @@ def main():
     ap.add_argument("--fence-steps", type=int, default=1200,
                     help="length of the extra parity-fence leg (second handle, fence_counters=1; 0 = skip): how often this "
                          "workload leaves the URDF joint limits / drives the flange below z = 0.05")
+    ap.add_argument("--secondary-legs", type=int, default=1,
+                    help="1: after the headline (reach, external actions) also time BASELINE configs[2] (reach + fused TD3 actor, exact "
+                         "f32 and f16x3) and configs[3] (push, 32 768 envs) with short legs on fresh handles; 0 = skip")
     ap.add_argument("--task", default="reach", choices=["reach", "push", "pick"],
                     help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768); "
                          "pick = the next-row env (SURVEY.md section 8f.4)")
@@ -304,9 +422,7 @@ def main():
         bound, sig = (0.7, 0.7 * 0.98) if args.task == "reach" else (0.4, 0.4 * 0.98)
         sd = None
         if args.policy.startswith("actor"):      # weights of TD3_MLP(6,3,0.7) under torch.manual_seed(0): golden G3
-            g = np.load(os.path.join(ROOT, "tests", "golden", "td3_actor_seed0.npz"))
-            sd = {k: torch.from_numpy(g[k.replace(".", "_")]) for k in
-                  ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+            sd = golden_actor()
             if args.task != "reach":
                 raise SystemExit("--policy actor: the golden actor has 6 inputs (reach)")
         env.set_policy(args.policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if args.task == "reach" else 1e9,
@@ -351,12 +467,9 @@ def main():
                 if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
                     ops.append(do_gather); gathers += 1
         if world > 1 and gathers == 0:
-            # a region shorter than --gather-every (the driver's 20 steps) still carries one all-gather: of the returns as they
-            # stand when the region starts (snapshot taken here, outside the clock), enqueued right after the launches so that
-            # neither its host calls nor the collective itself (side stream, not waiting for the launches) delay the K steps
-            snap = env.episode_stats()[0]
-            torch.cuda.synchronize(dev)
-            ops.append(lambda: gather.launch(snap, ready=True)); gathers = 1
+            # a region shorter than --gather-every (the driver's 20 steps) still carries one all-gather, of the returns as they
+            # stand AFTER its steps: episode_stats is enqueued behind the launches and the collective (side stream) waits for it
+            ops.append(do_gather); gathers = 1
         launches = len(ops) - gathers
         return ops, launches, gathers
 
@@ -378,24 +491,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
         p = time.perf_counter
+        cur = torch.cuda.current_stream(dev)
+        trailing = world > 1 and len(ops) > 1 and ops[-1] is do_gather     # the region's last op is a logging gather
+        step_ops = ops[:-1] if trailing else ops
         t0 = p()
         ev0.record()
         ta = p()
-        for op in ops:
+        for op in step_ops:
             op()
         tb = p()
-        ev1.record()
+        ev1.record()                 # closes the K steps on the launch stream (the trailing logging gather is enqueued behind it)
         tc = p()
-        ev1.synchronize()            # spin on the event: the stream's work is done when it returns
+        if trailing:
+            do_gather()              # host work under the running kernels; its device work is behind ev1 / on the side stream
+        ev1.synchronize()            # spin on the event: the K steps are done when it returns
         td = p()
+        # The contract's closing bracket: device work of the K steps finished on this rank, then the barrier.  The logging
+        # all-gather runs on a side stream and is NOT part of the K steps: it is waited for after the clock stops and its
+        # latency reported separately (`gather_us`); a device-wide synchronize here would put it back on the critical path.
+        cur.synchronize()
+        te = p()
         if world > 1:
-            gather.result()          # the logging collective belongs to the K steps
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()           # the contract's closing bracket: synchronize + barrier on both sides of the K steps
+            dist.barrier()
         wall = p() - t0
+        tg = p()
+        if world > 1:
+            gather.result()
+        torch.cuda.synchronize(dev)
         host_us.update(event0_record=(ta - t0) * 1e6, enqueue=(tb - ta) * 1e6, event1_record=(tc - tb) * 1e6,
-                       wait_for_gpu=(td - tc) * 1e6, closing_syncs=(t0 + wall - td) * 1e6)
+                       wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, barrier=(t0 + wall - te) * 1e6,
+                       gather_wait_after_clock=(p() - tg) * 1e6)
         c1 = env.counters()
         return wall, ev0.elapsed_time(ev1), launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}
 
@@ -459,32 +584,16 @@ def main():
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / wall_max
+        # the same K steps against the slowest rank's KERNEL time (HIP events on its launch stream): what the GPUs did, without
+        # the host-side bracket (event records, enqueue, the barrier's wake-up latency -- fixed costs of the order of one
+        # 20-step launch, see config.host_us); equals the events' figure of the one rank when n_gpus = 1
+        kernel_ms_max = max(per_rank["kernel_ms"]) if per_rank else gpu_ms
+        value_kernel = total_envs * args.steps / (kernel_ms_max * 1e-3)
         launch_us = gpu_ms * 1e3 / launches              # HIP events on the launch stream, per kernel launch
         steps_per_launch = args.steps / launches
         kernel = env.kernel_name if args.mode == "step" else env.kernel_name.replace("_step", "_rollout")
-        io_b, st_b = IO_BYTES, STATE_BYTES[args.precision]
-        if args.policy != "external":
-            io_b -= 12                      # no action read
-        if args.task != "reach":  # obs 36 B instead of 24; state: cube/target/d_last (7 reals; pick 11) r+w instead of goal
-            io_b += 12
-            st_b += 2 * (7 if args.task == "push" else 11) * (args.precision // 8) - 12
-        algo = (io_b * steps_per_launch + st_b) * n   # bytes one launch moves, algorithmically
-        achieved = algo / (launch_us * 1e-6) / 1e9
-        # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md), one entry per launch shape:
-        # "<kernel>|policy=<p>|T=<steps per launch>|N=<envs>"; only an exact match is reported
-        traffic, traffic_key = None, "%s|policy=%s|T=%d|N=%d" % (kernel, args.policy, int(steps_per_launch), n)
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and steps_per_launch == int(steps_per_launch):
-            try:
-                traffic = json.load(open(tpath)).get(traffic_key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         updates = dc["ik_updates"] / max(1, dc["env_steps"])
-        flops = (updates * FLOPS_PER_UPDATE + FLOPS_PER_EXIT_FK) * n * steps_per_launch
-        vpeak = F64_VECTOR_PEAK_TFLOPS if args.precision == 64 else 157.3
-        valu = {"bound": "valu", "achieved": flops / (launch_us * 1e-6) / 1e12, "peak": vpeak, "unit": "TFLOP/s",
-                "frac": flops / (launch_us * 1e-6) / 1e12 / vpeak, "ik_updates_per_env_step": updates,
-                "algo_flops_per_launch": flops}
+        roof, valu, mfma = rooflines(args.task, args.policy, args.precision, n, steps_per_launch, launch_us, updates, kernel)
         pol_txt = {"external": "random policy %s pre-generated in HBM as an i.i.d. [steps, N, 3] pool, step() throughput only",
                    "random": "random policy %s generated in-kernel (Philox)",
                    "actor": "TD3 actor forward (exact f32 MFMA) + exploration noise %s fused into the step kernel",
@@ -496,7 +605,7 @@ def main():
                     }[args.task] % (n, pol_txt[args.policy] % noise)
         line = {
             "metric": "env-steps/sec at N parallel envs (rl_%s_env)" % args.task,
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "value_kernel": value_kernel, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": workload,
@@ -504,31 +613,21 @@ def main():
                        "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
                        "gathers_in_timed_region": gathers, "state_digest": digests, "per_rank": per_rank,
                        # where the wall clock of the timed region went on the host (us): recording the two HIP events,
-                       # enqueueing the launches, waiting for the GPU, the closing synchronisations
+                       # enqueueing the launches, waiting for the GPU, the closing stream synchronisation, the barrier; and,
+                       # outside the clock, the wait for the logging all-gather
                        "host_us": host_us_main,
                        "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps and at least once per "
-                                      "timed region (logging only)"
+                                      "timed region (logging only, side stream, waited for after the clock: host_us.gather_wait_after_clock)"
                                       % (world, "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: debug)", args.gather_every)
                                       if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_key": traffic_key,
-                         "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
-                         # the bound that BINDS: 29 flop/B puts the path right of
-                         # the ridge -- the same launch against the f64 (f32) vector peak
-                         "binding_bound": "valu", "valu": valu},
+            # `roofline.binding_bound` / `roofline.valu`: the bound that BINDS: 29 flop/B
+            # puts the path right of the ridge -- the same launch against the f64 (f32) vector peak
+            "roofline": roof,
             "roofline_valu": valu,
             "episodes_finished": counters["episodes"], "nonfinite_states": counters["nonfinite"],
         }
-        if args.policy.startswith("actor"):
-            # 2 * (6*256 + 256*256 + 256*3) flop per env-step; layer 2 on the f32 MFMA
-            af = 2 * (6 * 256 + 256 * 256 + 256 * 3) * n * steps_per_launch
-            if args.policy == "actor":
-                peak, dt, mult = 157.3, "f32 (v_mfma_f32_32x32x2_f32)", 1
-            else:   # three f16 MFMA passes per useful multiply-add; priced against the dense f16 MFMA peak
-                peak, dt, mult = 2500.0, "f32 emulated by 3 x f16 (v_mfma_f32_32x32x16_f16, hi/lo split)", 3
-            line["roofline_mfma"] = {"bound": "mfma", "achieved": mult * af / (launch_us * 1e-6) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                     "frac": mult * af / (launch_us * 1e-6) / 1e12 / peak, "dtype": dt,
-                                     "useful_tflops": af / (launch_us * 1e-6) / 1e12}
+        if mfma:
+            line["roofline_mfma"] = mfma
         if step_api:
             line["step_api"] = step_api
         if in_kernel:
@@ -540,11 +639,16 @@ def main():
             except Exception as e:       # noqa: BLE001
                 line[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and args.fence_steps > 0:
-            leg("parity_fence", lambda: parity_fence(Env, n, dev, args, pool))
+            leg("parity_fence", lambda: parity_fence(Env, n, dev, args.precision, pool, args.fence_steps))
         if world == 1 and args.large_batch > n and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
             del pool, bufs
             torch.cuda.empty_cache()
             leg("large_batch", lambda: large_batch(Env, dev, args))
+        # the other single-GPU BASELINE configs, timed by the same command (each on a fresh handle, after the headline)
+        if world == 1 and args.secondary_legs and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
+            leg("config3_actor_f32", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor", args.precision, 2, 2))
+            leg("config3_actor_f16x3", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor_f16x3", args.precision, 2, 2))
+            leg("config4_push", lambda: secondary_leg(envs, dev, "push", 32768, "external", args.precision, 5, 6, args.fence_steps))
         if world == 1 and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline(args.precision))
         print(json.dumps(line), flush=True)

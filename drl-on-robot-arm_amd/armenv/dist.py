@@ -67,10 +67,9 @@ class ReturnGatherer:
     def _host_backend(self):
         return self.side is not None and self.world > 1 and dist.get_backend() != "nccl"
 
-    def launch(self, local_returns, ready=False):
-        """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs.
-        ready=True: the tensor is already complete (its producer was synchronised earlier), so the side stream does not wait
-        for the work currently queued on the producer stream -- the collective then runs UNDER that work instead of behind it."""
+    def launch(self, local_returns):
+        """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs: the side stream waits for
+        the work queued on the producer stream so far (the tensor's producer, and every consumer of an earlier result())."""
         if tuple(local_returns.shape) != (self.n_local,):
             raise ValueError(f"local_returns must have shape ({self.n_local},)")
         slot = self.slots[self.launches & 1]
@@ -86,8 +85,9 @@ class ReturnGatherer:
             return
         if self.side is not None:
             cur = torch.cuda.current_stream(self.device)
-            if not ready:
-                self.side.wait_stream(cur)
+            # also orders the refill of this slot's `out` behind consumer kernels that still read the tensor result()
+            # returned two launches ago (they were enqueued on `cur` before this call)
+            self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
                 if prev is not None:
                     prev.wait()               # orders the SIDE stream (where the slot is refilled) behind that collective

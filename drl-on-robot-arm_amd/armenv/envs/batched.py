@@ -62,6 +62,7 @@ class BatchedArmEnv:
         self._done = torch.empty(n, dtype=torch.uint8, device=dev)
         self._success = torch.empty(n, dtype=torch.uint8, device=dev)
         self._terminal = None
+        self._ik_updates = None
         self.action_space = Box(low=[-0.4, -0.4, -0.6], high=[0.4, 0.4, 0.3])       # rl_reach_env.py:87-90
         self.max_steps_one_episode = int(cfg.max_steps)
 
@@ -107,18 +108,26 @@ class BatchedArmEnv:
             L.check(self._lib.armenv_reset_with_goal(self._h, _ptr(m), _ptr(g), _ptr(self._obs), self._stream()))
         return self._obs
 
-    def step(self, action, want_terminal_obs=False):
+    def step(self, action, want_terminal_obs=False, want_ik_updates=False):
         """One env step for all N envs; no host synchronisation.  Returns (obs, reward, done, success)
         -- the same preallocated tensors every call (clone them to keep a history).  With
-        want_terminal_obs the pre-reset observation is available as ``self.terminal_obs``."""
+        want_terminal_obs the pre-reset observation is available as ``self.terminal_obs``; with want_ik_updates the number
+        of DLS updates of every env's IK call as ``self.ik_updates`` (u8; ik_max_iters = the call did not converge)."""
         if action is not None:          # None: the fused policy installed with set_policy() acts
             self._check_action(action)
         if want_terminal_obs and self._terminal is None:
             self._terminal = torch.empty_like(self._obs)
+        if want_ik_updates and self._ik_updates is None:
+            self._ik_updates = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
         term = self._terminal if want_terminal_obs else None
+        upd = self._ik_updates if want_ik_updates else None
         L.check(self._lib.armenv_step(self._h, _ptr(action), _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
-                                      _ptr(self._success), _ptr(term), self._stream()))
+                                      _ptr(self._success), _ptr(term), _ptr(upd), self._stream()))
         return self._obs, self._reward, self._done.view(torch.bool), self._success.view(torch.bool)
+
+    @property
+    def ik_updates(self):
+        return self._ik_updates
 
     @property
     def terminal_obs(self):
@@ -148,15 +157,17 @@ class BatchedArmEnv:
         L.check(self._lib.armenv_actor_forward(self._h, st.shape[0], _ptr(st), _ptr(out), self._stream()))
         return out
 
-    def rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False):
+    def rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, want_ik_updates=False):
         """`steps` env steps of all envs in one kernel launch (the inner loop of main.py:108-128).
         actions: float32 [steps, N, 3] on the device, or None to use the fused policy (set_policy).
-        Returns a dict of [steps, N, ...] tensors: obs, reward, done, success (+ actions, terminal_obs)."""
-        launch, out = self.bind_rollout(steps, actions, out, want_actions, want_terminal_obs, stream=self._stream())
+        Returns a dict of [steps, N, ...] tensors: obs, reward, done, success (+ actions, terminal_obs, ik_updates)."""
+        launch, out = self.bind_rollout(steps, actions, out, want_actions, want_terminal_obs, stream=self._stream(),
+                                        want_ik_updates=want_ik_updates)
         launch()
         return out
 
-    def bind_rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, stream=None):
+    def bind_rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, stream=None,
+                     want_ik_updates=False):
         """Everything `rollout` does except the launch: argument checks, output buffers, pointer and stream resolution.
         Returns (launch, out): `launch()` enqueues the T-step kernel with one ctypes call into armenv_rollout (on the
         stream that was current at bind time, or `stream`), `out` is the dict `rollout` returns.  For callers that issue
@@ -180,12 +191,13 @@ class BatchedArmEnv:
         succ = buf("success_u8", (T, n), torch.uint8)
         acts = buf("actions", (T, n, 3), torch.float32) if want_actions else None
         term = buf("terminal_obs", (T, n, self.obs_dim), torch.float32) if want_terminal_obs else None
+        upd = buf("ik_updates", (T, n), torch.uint8) if want_ik_updates else None
         out["done"] = done.view(torch.bool)
         out["success"] = succ.view(torch.bool)
         fn, h = self._lib.armenv_rollout, self._h
-        args = (h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(succ), _ptr(acts), _ptr(term),
+        args = (h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(succ), _ptr(acts), _ptr(term), _ptr(upd),
                 stream if stream is not None else self._stream())
-        keep = (actions, obs, rew, done, succ, acts, term)     # the closure keeps the tensors alive
+        keep = (actions, obs, rew, done, succ, acts, term, upd)     # the closure keeps the tensors alive
 
         def launch(_fn=fn, _args=args, _check=L.check, _keep=keep):
             rc = _fn(*_args)
@@ -215,23 +227,28 @@ class BatchedArmEnv:
 
     # ------------------------------------------------------------------ state exchange / stats
     def get_state(self):
-        """Reach: q, goal, step, episode, ep_return.  Push: aux [N,8] (cube xyz, target xyz, d_last, 0) replaces goal;
-        pick: aux [N,12] (cube xyz, target xyz, d_last, gripper 0/1/2, hold offset xyz, 0)."""
+        """Reach: q, goal, step, episode, ep_return, trig.  Push: aux [N,8] (cube xyz, target xyz, d_last, 0) replaces goal;
+        pick: aux [N,12] (cube xyz, target xyz, d_last, gripper 0/1/2, hold offset xyz, 0).  trig [N,14] = (cos q, sin q) as
+        the engine carries them: ``set_state(**get_state())`` restores a checkpoint bit for bit."""
         n, dev = self.num_envs, self.device
         push = self.task != L.TASK_REACH
         st = dict(q=torch.empty((n, 7), dtype=torch.float64, device=dev),
                   step=torch.empty(n, dtype=torch.int32, device=dev),
                   episode=torch.empty(n, dtype=torch.int32, device=dev),   # u32 bits
-                  ep_return=torch.empty(n, dtype=torch.float64, device=dev))
+                  ep_return=torch.empty(n, dtype=torch.float64, device=dev),
+                  trig=torch.empty((n, 14), dtype=torch.float64, device=dev))
         if push:
             st["aux"] = torch.empty((n, self.aux_dim), dtype=torch.float64, device=dev)
         else:
             st["goal"] = torch.empty((n, 3), dtype=torch.float32, device=dev)
         L.check(self._lib.armenv_get_state(self._h, _ptr(st["q"]), _ptr(st.get("goal")), _ptr(st["step"]),
-                                           _ptr(st["episode"]), _ptr(st["ep_return"]), _ptr(st.get("aux")), self._stream()))
+                                           _ptr(st["episode"]), _ptr(st["ep_return"]), _ptr(st.get("aux")), _ptr(st["trig"]),
+                                           self._stream()))
         return st
 
-    def set_state(self, q=None, goal=None, step=None, episode=None, ep_return=None, aux=None):
+    def set_state(self, q=None, goal=None, step=None, episode=None, ep_return=None, aux=None, trig=None):
+        """Any subset of the fields of get_state().  q without trig: resetJointState semantics, the carried (cos q, sin q)
+        are re-derived from the new angles."""
         dev = self.device
 
         def prep(x, dt, shape):
@@ -244,7 +261,8 @@ class BatchedArmEnv:
         q_, g_, s_, e_, r_, a_ = (prep(q, torch.float64, (n, 7)), prep(goal, torch.float32, (n, 3)),
                                   prep(step, torch.int32, (n,)), prep(episode, torch.int32, (n,)),
                                   prep(ep_return, torch.float64, (n,)), prep(aux, torch.float64, (n, self.aux_dim)))
-        L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), _ptr(a_),
+        t_ = prep(trig, torch.float64, (n, 14))
+        L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), _ptr(a_), _ptr(t_),
                                            self._stream()))
         torch.cuda.current_stream(dev).synchronize()   # temporaries above must outlive the copy
 
@@ -267,10 +285,10 @@ class BatchedArmEnv:
                     last_success_rate=out[4] / n, raw=out)
 
     def counters(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         L.check(self._lib.armenv_counters(self._h, C.byref(out), self._stream()))
         return dict(episodes=out[0], successes=out[1], env_steps=out[2], nonfinite=out[3], ik_updates=out[4],
-                    limit_steps=out[5], low_flange_steps=out[6])
+                    limit_steps=out[5], low_flange_steps=out[6], cap_steps=out[7], illcond_steps=out[8])
 
 
 class BatchedReachEnv(BatchedArmEnv):

@@ -58,6 +58,7 @@ class RLPickEnv:
 
     def _obs64(self, obs_f32):
         aux = self._eng.get_state()["aux"][0].cpu().numpy()
+        self._aux = aux
         return np.hstack((obs_f32[:3].astype(np.float32), aux[0:3], aux[3:6]))  # :308 (f32 eef, f64 cube, f64 target)
 
     @property
@@ -75,6 +76,7 @@ class RLPickEnv:
         st[0, 0:3], st[0, 3:6] = cube, target
         st[0, 6] = math.sqrt(sum((a - b) ** 2 for a, b in zip(cube, target)))
         self._eng.set_state(aux=st)
+        self._d_last = float(np.linalg.norm(np.asarray(cube) - np.asarray(target)))   # last_object_pos / last_target_pos (:243-245)
         return self._obs64(obs)
 
     def step(self, action):
@@ -86,8 +88,23 @@ class RLPickEnv:
         o = obs[0].cpu().numpy()
         r = float(reward[0].item())
         self.terminated = bool(done[0].item())
-        info = {'is_success': np.float32(bool(success[0].item()))}              # :432-434
-        return self._obs64(o), (100 if r == 100.0 else r), self.terminated, info
+        info = {'is_success': np.float32(bool(success[0].item()))}              # :430-432
+        obs64 = self._obs64(o)
+        # The shaped reward -100 * (d_now - d_last) (:388-397, :427) recomputed in f64 from the env's f64 cube / target state with
+        # the reference's own numpy expressions (armenv_step's reward buffer is f32); the two other branches are exact in f32:
+        # +100 on success (:422-424), and the time-limit reward, which the reference computes from float32 states (:400, :418-420).
+        d_cur = float(np.linalg.norm(obs64[3:6] - obs64[6:9], axis=-1))
+        test = d_cur - self._d_last
+        if abs(test) < 1e-5:
+            test = 0.01
+        self._d_last = d_cur
+        if r == 100.0:
+            reward64 = 100
+        elif self.step_counter > self.max_steps_one_episode:
+            reward64 = r
+        else:
+            reward64 = -test * 100
+        return obs64, reward64, self.terminated, info
 
     def close(self):
         self._eng.close()

@@ -86,17 +86,24 @@ class RLReachEnv:
         return obs[0].cpu().numpy()                                      # np.float32[6]  :217
 
     def step(self, action):
-        """:219-319 -> (np.float32[6], float reward, bool done, bool is_success)"""
+        """:219-319 -> (np.float32[6], float reward, bool done, bool is_success).  The step itself is one armenv_step launch (actions
+        and the reward buffer are f32 at that boundary); the reward returned here is recomputed in f64 from the env's f64 joint
+        state -- armenv_fk, then the expressions of :281-309 in numpy -- because the reference returns a Python float computed in
+        f64: equal to the f64 oracle to ~1e-15, not merely to f32 rounding."""
         self._sync_opt()
         a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 3), dtype=torch.float32).to(self._eng.device)
         obs, reward, done, success = self._eng.step(a)
         self.step_counter += 1
         draw_step_unused()
-        packed = torch.cat([obs[0], reward, done.to(torch.float32), success.to(torch.float32)]).cpu().numpy()
-        self.terminated = bool(packed[7])
-        self.is_success = bool(packed[8])
-        self.distance = float(-packed[6] / 10.0) if not self.is_success else 0.0
-        return packed[:6].copy(), float(packed[6]), self.terminated, self.is_success
+        pos, _ = self._eng.fk(self._eng.get_state()["q"])
+        packed = torch.cat([obs[0].double(), done.double(), success.double(), pos[0]]).cpu().numpy()     # one host sync
+        self.terminated = bool(packed[6])
+        self.is_success = bool(packed[7])
+        self.robot_state = tuple(float(x) for x in packed[8:11])                                 # :271 getLinkState(...)[4]
+        goal = self.object_state.astype(np.float64)                                              # :276-278 float32 cube position
+        self.distance = float(np.sqrt(np.sum((np.asarray(self.robot_state) - goal) ** 2)))       # :281 (f64)
+        reward = 0.0 if self.is_success else -self.distance * 10                                 # :299-309
+        return packed[:6].astype(np.float32), reward, self.terminated, self.is_success
 
     def close(self):
         self._eng.close()

@@ -13,6 +13,26 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class Trajectory:
+    """One episode collected step by step on the host, as the reference's single-env loops do
+    (/root/reference/utils/rl_utils.py:91-105, call sites main.py:109,128): ``Trajectory(init_state)``,
+    ``store_step(action, state, reward, done)``; handed to ``TrajectoryStore.add_trajectory``."""
+
+    def __init__(self, init_state):
+        self.states = [init_state]
+        self.actions = []
+        self.rewards = []
+        self.dones = []
+        self.length = 0
+
+    def store_step(self, action, state, reward, done):
+        self.actions.append(action)
+        self.states.append(state)
+        self.rewards.append(reward)
+        self.dones.append(done)
+        self.length += 1
+
+
 class TrajectoryStore:
     """A time-major ring of the last ``capacity_steps`` env steps of N envs (the reference's deque keeps the last
     `capacity` trajectories, rl_utils.py:109-113).  ``size()`` = number of complete episodes currently in the window;
@@ -65,6 +85,24 @@ class TrajectoryStore:
                     r[k][: Tc - first].copy_(v[first:])
             r["T"] += Tc
         self._index()
+
+    def add_trajectory(self, traj):
+        """``ReplayBuffer_Trajectory_*.add_trajectory`` (rl_utils.py:112-113) for an episode of ONE env collected on the host: the
+        episode becomes a [length, 1, ...] chunk of the device ring (needs ``capacity_steps``).  The episode must end with
+        done = True and start at a reset, as the reference's loops produce them (main.py:108-129)."""
+        import numpy as np
+        if self.capacity is None:
+            raise RuntimeError("TrajectoryStore.add_trajectory: construct the store with capacity_steps")
+        if traj.length < 1 or not traj.dones[-1]:
+            raise ValueError("TrajectoryStore.add_trajectory: a trajectory is one complete episode (last done must be True)")
+        dev = self.device
+        st = torch.as_tensor(np.asarray(traj.states, dtype=np.float32), device=dev)                    # [L + 1, D]
+        out = dict(obs=st[1:, None, :].contiguous(), terminal_obs=st[1:, None, :].contiguous(),
+                   reward=torch.as_tensor(np.asarray(traj.rewards, dtype=np.float32), device=dev)[:, None].contiguous(),
+                   done_u8=torch.as_tensor(np.asarray(traj.dones, dtype=np.uint8), device=dev)[:, None].contiguous())
+        acts = torch.as_tensor(np.asarray(traj.actions, dtype=np.float32), device=dev)[:, None, :].contiguous()
+        first = self._ring is None
+        self.add_rollout(st[0:1].contiguous(), out, actions=acts, starts_at_reset=first)
 
     def _index(self):
         r = self._ring

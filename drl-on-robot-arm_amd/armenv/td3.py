@@ -167,5 +167,13 @@ class TD3:
         g["g"][self.total_it % self.policy_freq == 0].replay()
         return g["loss"]
 
+    def take_action(self, state):
+        """TD3_MLP.take_action (TD3_mlp.py:82-97): one state (sequence of floats) -> np.float32[action_dim], no exploration noise
+        (the caller adds it, main.py:116); one host round trip, like the reference."""
+        import numpy as np
+        with torch.no_grad():
+            s = torch.tensor(np.asarray([state], dtype=np.float32), device=self.device)
+            return self.actor(s).detach().cpu().numpy()[0]
+
     def actor_state_dict(self):
         return {k: v.detach() for k, v in self.actor.state_dict().items()}

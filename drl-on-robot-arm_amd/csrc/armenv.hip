@@ -115,8 +115,10 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->reach_dis = 0.01;
   c->max_steps = 500;
   c->clamp_joint_limits = 0;
+  c->limit_erp = 0.2;      // Bullet's default constraint ERP (btContactSolverInfo::m_erp); read by clamp_joint_limits == 2 only
   c->fence_counters = 0;   // diagnostics off by default (costs ~6 % of a reach step when the limits are crossed as often as under the random policy)
   c->fence_z = 0.05;   // arm-table contact acts when the flange is driven to z <~ 0.05
+  c->fence_pivot = 1e-2;   // conditioning term of the fence: amplification of rounding differences >~ 100
   const double lo[3] = {0.2, -0.3, 0.0}, hi[3] = {0.7, 0.3, 0.55};
   for (int k = 0; k < 3; ++k) { c->box_lo[k] = lo[k]; c->box_hi[k] = hi[k]; c->goal_lo[k] = lo[k]; c->goal_hi[k] = hi[k]; }
   if (task == ARMENV_TASK_PUSH) c->box_hi[2] = 0.1;                 // rl_push_env.py:314
@@ -163,6 +165,8 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   if (cfg->precision != 64 && cfg->precision != 32) return fail(ARMENV_EINVAL, "armenv_create: precision must be 32 or 64");
   if (cfg->task < ARMENV_TASK_REACH || cfg->task > ARMENV_TASK_PICK) return fail(ARMENV_EINVAL, "armenv_create: unknown task %d", cfg->task);
   if (cfg->ik_max_iters < 0 || cfg->ik_max_iters > 1000) return fail(ARMENV_EINVAL, "armenv_create: ik_max_iters out of range");
+  if (cfg->clamp_joint_limits < 0 || cfg->clamp_joint_limits > 2) return fail(ARMENV_EINVAL, "armenv_create: clamp_joint_limits must be 0, 1 or 2");
+  if (cfg->clamp_joint_limits == 2 && !(cfg->limit_erp > 0.0 && cfg->limit_erp <= 1.0)) return fail(ARMENV_EINVAL, "armenv_create: limit_erp must be in (0, 1]");
   if (cfg->rollout_waves_per_simd < 0 || cfg->rollout_waves_per_simd > 2) return fail(ARMENV_EINVAL, "armenv_create: rollout_waves_per_simd must be 0, 1 or 2");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -204,10 +208,10 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
 }
 
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
-                uint8_t *success_dev, float *terminal_obs_dev, void *stream) {
+                uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, void *stream) {
   ENV_ENTER(env);
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_step: NULL output buffer");
-  StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev};
+  StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev};
   if (!action_dev) {   // fused policy: a one-step rollout
     if (env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
       return fail(ARMENV_ESTATE, "armenv_step: action_dev is NULL and no fused policy is installed");
@@ -232,19 +236,20 @@ int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_
 }
 
 int armenv_get_state(ArmEnv *env, double *q_dev, float *goal_dev, int32_t *step_dev, uint32_t *episode_dev,
-                     double *ep_return_dev, double *aux_dev, void *stream) {
+                     double *ep_return_dev, double *aux_dev, double *trig_dev, void *stream) {
   ENV_ENTER(env);
   if (aux_dev && env->cfg.task == ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_get_state: aux is only defined for the push and pick tasks");
   if (goal_dev && env->cfg.task != ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_get_state: push / pick keep cube and target in aux, not goal");
-  return env->eng->get_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, static_cast<hipStream_t>(stream));
+  return env->eng->get_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, trig_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, const int32_t *step_dev,
-                     const uint32_t *episode_dev, const double *ep_return_dev, const double *aux_dev, void *stream) {
+                     const uint32_t *episode_dev, const double *ep_return_dev, const double *aux_dev,
+                     const double *trig_dev, void *stream) {
   ENV_ENTER(env);
   if (aux_dev && env->cfg.task == ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_set_state: aux is only defined for the push and pick tasks");
   if (goal_dev && env->cfg.task != ARMENV_TASK_REACH) return fail(ARMENV_EINVAL, "armenv_set_state: push / pick keep cube and target in aux, not goal");
-  return env->eng->set_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, static_cast<hipStream_t>(stream));
+  return env->eng->set_state(q_dev, goal_dev, step_dev, episode_dev, ep_return_dev, aux_dev, trig_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len_dev, uint8_t *last_success_dev,
@@ -253,7 +258,7 @@ int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len
   return env->eng->episode_stats(last_return_dev, last_len_dev, last_success_dev, static_cast<hipStream_t>(stream));
 }
 
-int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream) {
+int armenv_counters(ArmEnv *env, uint64_t out[16], void *stream) {
   ENV_ENTER(env);
   if (!out) return fail(ARMENV_EINVAL, "armenv_counters: out is NULL");
   return env->eng->counters(out, static_cast<hipStream_t>(stream));
@@ -298,15 +303,15 @@ int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float 
 }
 
 int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,
-                   uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev, void *stream) {
+                   uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev,
+                   uint8_t *ik_updates_dev, void *stream) {
   ENV_ENTER(env);
   if (steps < 0) return fail(ARMENV_EINVAL, "armenv_rollout: steps < 0");
   if (steps == 0) return ARMENV_OK;
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_rollout: NULL output buffer");
   if (!actions_dev && env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
     return fail(ARMENV_ESTATE, "armenv_rollout: actions_dev is NULL and no fused policy is installed");
-  if (steps == 0) return ARMENV_OK;
-  StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev};
+  StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev};
   return env->eng->rollout(steps, actions_dev, io, actions_out_dev, static_cast<hipStream_t>(stream));
 }
 

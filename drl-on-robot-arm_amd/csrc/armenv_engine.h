@@ -5,7 +5,7 @@
 // Data layout in HBM (N envs, T = f64 or f32 by ArmEnvConfig.precision), struct-of-arrays with the env index fastest
 // so that a wave's 64 lanes touch 64 consecutive elements of every array:
 //   q[7][N] T | trig[14][N] T (cos q, sin q) | ep_return[N] T | last_return[N] T | goal[3][N] f32 | step[N] i32 | episode[N] u32 |
-//   last_len[N] i32 | last_success[N] u8 | counters[N/64][8] u64 (one row per wave) | totals[8] u64 | summary rows[N/64][8] f64 | EnvCold | push: aux[7][N] T | pick: aux[11][N] T
+//   last_len[N] i32 | last_success[N] u8 | counters[N/64][16] u64 (one row per wave) | totals[16] u64 | summary rows[N/64][8] f64 | EnvCold | push: aux[7][N] T | pick: aux[11][N] T
 // Caller-facing buffers keep the reference's array-of-struct shapes (action [N][3], obs [N][6|9]); a wave still
 // reads/writes one contiguous span of them.
 #pragma once
@@ -86,11 +86,11 @@ struct EngineBase {
   virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
   virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
   virtual int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
-                        hipStream_t s) = 0;
+                        double *trig, hipStream_t s) = 0;
   virtual int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
-                        const double *ep_return, const double *aux, hipStream_t s) = 0;
+                        const double *ep_return, const double *aux, const double *trig, hipStream_t s) = 0;
   virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
-  virtual int counters(uint64_t out[8], hipStream_t s) = 0;
+  virtual int counters(uint64_t out[16], hipStream_t s) = 0;
   virtual int summary(double *out_dev, hipStream_t s) = 0;
   virtual const char *name() const = 0;
 };
@@ -139,7 +139,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
-    const size_t o_ls = take(n), o_cnt = take(64 * (size_t)((n + 63) / 64)), o_tot = take(64), o_sum = take(64 * (size_t)((n + 63) / 64)), o_cold = take(sizeof(EnvCold<T>));
+    const size_t o_ls = take(n), o_cnt = take(8 * kCounterCols * (size_t)((n + 63) / 64)), o_tot = take(8 * kCounterCols), o_sum = take(64 * (size_t)((n + 63) / 64)), o_cold = take(sizeof(EnvCold<T>));
     const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n), o_trig = take(sizeof(T) * 2 * NJ * n);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
@@ -188,6 +188,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
       K.q_init[j] = (T)cfg.q_init[j];
       K.lim[j] = (T)cfg.chain.limit_lo[j];
       K.lim[NJ + j] = (T)cfg.chain.limit_hi[j];
+      K.lim[2 * NJ] = (T)cfg.limit_erp;
       // no joint can be outside [lower, upper] while max |q| <= min(-lower, upper) (as T: the values the kernel compares with)
       const double a = -(double)K.lim[j], b2 = (double)K.lim[NJ + j];
       lim_min = std::fmin(lim_min, std::fmin(a, b2));
@@ -206,6 +207,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     waves_cfg = cfg.rollout_waves_per_simd;
     ready_lanes = cfg.rollout_ready_lanes < 0 ? 0 : (cfg.rollout_ready_lanes > 64 ? 64 : cfg.rollout_ready_lanes);
     P.ik.fence = cfg.fence_counters;
+    P.ik.fence_pivot = (T)cfg.fence_pivot;
     P.fence_z = (T)cfg.fence_z;
     for (int j = 0; j < NJ; ++j) {
       double R[9];
@@ -220,6 +222,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
       for (int k = 0; k < 3; ++k) P.chain.base_p[k] = (T)cfg.chain.base_xyz[k];
     }
     HIP_TRY(hipMemcpy(cold_dev, &K, sizeof K, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((trig_identity_kernel<T>), dim3(grid_for(n, block)), dim3(block), 0, 0, P);
     hipLaunchKernelGGL((init_consts_kernel<C, T>), dim3(1), dim3(64), 0, 0, P, cold_dev);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -299,17 +302,17 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
-  int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux,
+  int get_state(double *q, float *goal, int32_t *step, uint32_t *episode, double *ep_return, double *aux, double *trig,
                 hipStream_t s) override {
     hipLaunchKernelGGL((get_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
-                       ep_return, aux, (int)Lane::kAuxRows, (int)Lane::kAuxDim);
+                       ep_return, aux, trig, (int)Lane::kAuxRows, (int)Lane::kAuxDim);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
   int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
-                const double *ep_return, const double *aux, hipStream_t s) override {
+                const double *ep_return, const double *aux, const double *trig, hipStream_t s) override {
     hipLaunchKernelGGL((set_state_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, q, goal, step, episode,
-                       ep_return, aux, (int)Lane::kAuxRows, (int)Lane::kAuxDim);
+                       ep_return, aux, trig, (int)Lane::kAuxRows, (int)Lane::kAuxDim);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
@@ -319,10 +322,10 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
-  int counters(uint64_t out[8], hipStream_t s) override {
+  int counters(uint64_t out[16], hipStream_t s) override {
     hipLaunchKernelGGL(counters_sum_kernel, dim3(1), dim3(256), 0, s, P.counters, (P.n + 63) / 64, counter_totals);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, counter_totals, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out, counter_totals, kCounterCols * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return ARMENV_OK;
   }

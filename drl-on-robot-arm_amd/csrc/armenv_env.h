@@ -17,7 +17,7 @@ template <typename T> struct EnvCold {
   T q_init[NJ];
   T p_init[3];          // FK(q_init), computed on the device at create time (init_consts_kernel)
   T trig_init[2 * NJ];  // cos(q_init)[7], sin(q_init)[7] from the device's own sincos_all
-  T lim[2 * NJ];        // URDF joint limits: lower[7], upper[7]
+  T lim[2 * NJ + 1];    // URDF joint limits: lower[7], upper[7]; then limit_erp (ArmEnvConfig.limit_erp, read by clamp mode 2 only)
   double goal_lo[3], goal_hi[3];
   double push_rest_z, push_place_min, push_place_max;
   uint64_t seed, env_id0;
@@ -33,7 +33,7 @@ template <typename T> struct EnvParams {
   uint32_t *episode;
   int32_t *last_len;
   uint8_t *last_success;
-  unsigned long long *counters;   // [ceil(N / 64)][8]: one row per wave, summed by counters_sum_kernel on read
+  unsigned long long *counters;   // [ceil(N / 64)][16]: one row per wave, summed by counters_sum_kernel on read
   T *aux;  // push: [7][N] = cube xyz, target xyz, d_last;  pick: [11][N] = the same + gripper state + hold offset xyz
   T *trig; // [14][N] = cos q[7], sin q[7]: the pair every FK starts from, carried with q (see ReachLane::trig)
   int64_t n;
@@ -58,13 +58,15 @@ template <typename T> struct EnvParams {
 };
 
 // Launch-end flush of a lane's event counts into the handle's counters.  Every wave owns one 64-byte row
-// counters[i >> 6][8] = {episodes, successes, env steps (row 0 only), non-finite, IK updates, joint-limit steps, low-flange steps}; the wave sums its lanes
+// counters[w][16] = {episodes, successes, env steps (row 0 only), non-finite, IK updates, joint-limit steps, low-flange steps,
+// steps whose IK ran to the iteration cap, steps whose IK passed through an ill-conditioned system, 0...}; the wave sums its lanes
 // and ONE lane does a plain read-modify-write of the row -- launches on a stream are serialised, nobody else touches it.
 // Why not atomicAdd on one address: same-address atomics execute one at a time at the memory side of the fabric,
 // 12 ns each from anywhere on the chip (tests/tools/exp/launch_probe.hip: 4096 waves x 1 atomic = 50 us; per-wave rows =
 // nothing), and the kernel cannot complete before they have.  One atomic per wave was 12 us of every 24 us
 // armenv_step launch at 65536 envs.
 // wave_sum: a count v of b significant bits costs b ballots + popcounts on the scalar unit, no cross-lane data moves.
+constexpr int kCounterCols = 16;
 AE_DEV uint32_t wave_sum(uint32_t v) {
   uint32_t s = 0;
   for (int b = 0; b < 32 && __ballot((v >> b) != 0u) != 0ull; ++b) s += (uint32_t)__popcll(__ballot((v >> b) & 1u)) << b;
@@ -72,10 +74,10 @@ AE_DEV uint32_t wave_sum(uint32_t v) {
 }
 template <typename T>
 AE_DEV void flush_counts(const EnvParams<T> &P, int64_t i, uint32_t n_done, uint32_t n_succ, uint32_t n_bad, uint32_t n_upd,
-                         uint32_t n_lim, uint32_t n_low) {
-  unsigned long long *row = P.counters + 8 * (i >> 6);
+                         uint32_t n_lim, uint32_t n_low, uint32_t n_cap, uint32_t n_cond) {
+  unsigned long long *row = P.counters + kCounterCols * (i >> 6);
   const uint32_t d = wave_sum(n_done), s = wave_sum(n_succ), b = wave_sum(n_bad), u = wave_sum(n_upd);
-  const uint32_t l = wave_sum(n_lim), z = wave_sum(n_low);
+  const uint32_t l = wave_sum(n_lim), z = wave_sum(n_low), c = wave_sum(n_cap), k = wave_sum(n_cond);
   if ((threadIdx.x & 63) == 0) {   // lane 0 of a launched wave is always a live env (i < N is a prefix)
     if (d) row[0] += d;
     if (s) row[1] += s;
@@ -83,23 +85,25 @@ AE_DEV void flush_counts(const EnvParams<T> &P, int64_t i, uint32_t n_done, uint
     row[4] += u;
     if (l) row[5] += l;
     if (z) row[6] += z;
+    if (c) row[7] += c;
+    if (k) row[8] += k;
   }
 }
 AE_DEV void flush_env_steps(unsigned long long *counters, int64_t i, unsigned long long env_steps) {
   if (i == 0) counters[2] += env_steps;
 }
 
-// armenv_counters: totals[8] = column sums of the per-wave rows.
+// armenv_counters: totals[16] = column sums of the per-wave rows.
 static __global__ __launch_bounds__(256) void counters_sum_kernel(const unsigned long long *rows, int64_t n_rows,
                                                                    unsigned long long *totals) {
-  __shared__ unsigned long long part[4][8];
-  const int col = threadIdx.x & 7;
+  __shared__ unsigned long long part[4][kCounterCols];
+  const int col = threadIdx.x & (kCounterCols - 1);
   unsigned long long acc = 0;
-  for (int64_t r = threadIdx.x >> 3; r < n_rows; r += 32) acc += rows[8 * r + col];
-  for (int o = 8; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) < 8) part[threadIdx.x >> 6][col] = acc;
+  for (int64_t r = threadIdx.x / kCounterCols; r < n_rows; r += 256 / kCounterCols) acc += rows[kCounterCols * r + col];
+  for (int o = kCounterCols; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) < kCounterCols) part[threadIdx.x >> 6][col] = acc;
   __syncthreads();
-  if (threadIdx.x < 8) totals[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  if (threadIdx.x < kCounterCols) totals[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
 // The rollout's next action, loaded while the current step runs.  The load goes STRAIGHT INTO ACCUMULATION REGISTERS from
@@ -137,6 +141,7 @@ struct StepIO {
   uint8_t *done;
   uint8_t *success;
   float *terminal_obs;
+  uint8_t *updates;   // nullable: DLS updates the step's IK call applied (saturated at 255): the per-step view of counters[4] / [7]
 };
 
 // goal ~ U(box): a + (b - a) * u per axis as random.uniform does (rl_reach_env.py:180-182), then the
@@ -178,6 +183,15 @@ __global__ void init_consts_kernel(EnvParams<T> P, EnvCold<T> *cold) {
   fk<C, T>(P.chain, cq, sq, S);
   cold->p_init[0] = S.p[0]; cold->p_init[1] = S.p[1]; cold->p_init[2] = S.p[2];
   static_for<0, NJ>([&](auto II) { constexpr int i = II; cold->trig_init[i] = cq[i]; cold->trig_init[NJ + i] = sq[i]; });
+}
+
+// A fresh handle's (cos q, sin q) = (1, 0) for q = 0 (the pool is zero-filled): a step issued before the first reset then
+// starts from a valid pose instead of degenerate all-zero rotation frames.
+template <typename T>
+__global__ __launch_bounds__(256) void trig_identity_kernel(EnvParams<T> P) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = T(1); });
 }
 
 // Optional per-wave timeline (make timeline; tests/tools/exp/run_timeline.py): wall-clock stamps at kernel entry, after
@@ -325,7 +339,8 @@ template <class C, typename T> struct ReachLane {
   int32_t step;
   T ep_ret;
   uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0;   // flushed to the handle's counters once per launch
-  uint32_t n_lim = 0, n_low = 0;                           // parity fence: steps the IK left the URDF limits / ended with the flange below fence_z
+  uint32_t n_lim = 0, n_low = 0, n_cap = 0, n_cond = 0;    // parity fence: steps the IK left the URDF limits / ended with the flange below fence_z / ran to the iteration cap / was ill-conditioned
+  T minpiv = T(1e30);                                      // smallest LDL^T pivot of the running step's IK call (fence bookkeeping)
 
   AE_DEV void load(const EnvParams<T> &P, int64_t i) {
     const int64_t n = P.n;
@@ -343,7 +358,7 @@ template <class C, typename T> struct ReachLane {
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * n + i] = cq[j]; P.trig[(int64_t)(NJ + j) * n + i] = sq[j]; });
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
-    flush_counts(P, i, n_done, n_succ, n_bad, n_upd, n_lim, n_low);
+    flush_counts(P, i, n_done, n_succ, n_bad, n_upd, n_lim, n_low, n_cap, n_cond);
   }
 
   // RLReachEnv.step + _reward (rl_reach_env.py:219-319) in three pieces -- step_begin, the IK trips (ik_trip), step_tail --
@@ -356,6 +371,7 @@ template <class C, typename T> struct ReachLane {
     if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) { derive_trig(); have_S = false; } }
     if (!have_S) fk<C, T>(P.chain, cq, sq, S);
     ik_target<T, false>(S, a, P.dv, P.box_lo, P.box_hi, tgt);
+    minpiv = T(1e30);
   }
   // step_tail: everything after the IK (q, cq / sq and S = FK(q) hold its result; `updates` trips applied an update; lim_hit:
   // ik_limits): step counter, distance, reward / done / success (:264-309), observation (:319), episode accounting,
@@ -364,7 +380,11 @@ template <class C, typename T> struct ReachLane {
     const int64_t n = P.n;
     have_S = true;
     n_upd += (uint32_t)updates;
-    if (P.ik.fence) { n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; }
+    if (P.ik.fence) {
+      n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; n_cap += (updates >= P.ik.max_iters) ? 1u : 0u;
+      n_cond += (minpiv < P.ik.fence_pivot) ? 1u : 0u;
+    }
+    if (io.updates) io.updates[i] = (uint8_t)(updates > 255 ? 255 : updates);
     step += 1;                                                                    // :264
     const T dx = S.p[0] - (T)g[0], dy = S.p[1] - (T)g[1], dz = S.p[2] - (T)g[2];
     const T dist = M::sqrt(M::fma(dx, dx, M::fma(dy, dy, dz * dz)));              // :281
@@ -426,7 +446,7 @@ template <class C, typename T> struct ReachLane {
     const bool small_steps = P.ik.max_dtheta <= T(0.7854);
     T diff2_prev = T(1e60);
     int updates = 0;
-    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps)) {}    // :244-257
+    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :244-257
     const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail(P, i, io, updates, lim_hit);
@@ -503,7 +523,8 @@ template <class C, typename T, bool PICK> struct CubeLane {
   T off[3] = {T(0), T(0), T(0)};   // pick: cube - tip while held
   int32_t step;
   T ep_ret;
-  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0, n_lim = 0, n_low = 0;
+  uint32_t n_done = 0, n_succ = 0, n_bad = 0, n_upd = 0, n_lim = 0, n_low = 0, n_cap = 0, n_cond = 0;
+  T minpiv = T(1e30);       // smallest LDL^T pivot of the running step's IK call (fence bookkeeping)
   float cur_obs[3];
   AE_DEV void refresh_obs(const EnvParams<T> &P) {
     FKState<T> F;
@@ -575,7 +596,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
     }
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
-    flush_counts(P, i, n_done, n_succ, n_bad, n_upd, n_lim, n_low);
+    flush_counts(P, i, n_done, n_succ, n_bad, n_upd, n_lim, n_low, n_cap, n_cond);
   }
 
   // stepSimulation (:349), simplified: sphere (tool, radius r, centre p) vs axis-aligned box (cube, half-size h)
@@ -661,12 +682,17 @@ template <class C, typename T, bool PICK> struct CubeLane {
     if (!have_S) fk<C, T>(P.chain, cq, sq, S);
     p0[0] = S.p[0]; p0[1] = S.p[1]; p0[2] = S.p[2];
     ik_target<T, PICK>(S, a, P.dv, P.box_lo, P.box_hi, tgt);
+    minpiv = T(1e30);
   }
   AE_DEV void step_tail(const EnvParams<T> &P, int64_t i, const StepIO &io, int updates, bool lim_hit) {
     // pick restores joint 7 below, so the exit frame's orientation is not the next step's: only push carries the frame over
     have_S = !PICK;
     n_upd += (uint32_t)updates;
-    if (P.ik.fence) { n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; }
+    if (P.ik.fence) {
+      n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; n_cap += (updates >= P.ik.max_iters) ? 1u : 0u;
+      n_cond += (minpiv < P.ik.fence_pivot) ? 1u : 0u;
+    }
+    if (io.updates) io.updates[i] = (uint8_t)(updates > 255 ? 255 : updates);
     if constexpr (PICK) {
       q[NJ - 1] = q7s;              // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
       cq[NJ - 1] = c7s; sq[NJ - 1] = s7s;
@@ -736,7 +762,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
     const bool small_steps = P.ik.max_dtheta <= T(0.7854);
     T diff2_prev = T(1e60);
     int updates = 0;
-    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps)) {}    // :339-347
+    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :339-347
     const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail(P, i, io, updates, lim_hit);
@@ -889,6 +915,7 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     io.done = io0.done + (int64_t)t * n;
     io.success = io0.success + (int64_t)t * n;
     io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
+    io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr;
     if (actions_out) {
       float *ao = actions_out + ((int64_t)t * n + i) * 3;
       if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
@@ -975,7 +1002,7 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
   load_action(0);
   begin_step();
   for (;;) {
-    if (!ready && t < steps) ready = ik_trip<C, T>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps);
+    if (!ready && t < steps) ready = ik_trip<C, T>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps, L.minpiv);
     const unsigned long long rb = __ballot(ready), ib = __ballot(!ready && t < steps);
     if (__popcll(rb) >= ready_lanes || ib == 0ull) {       // wave-uniform: a transition round
       if (ready) {
@@ -990,6 +1017,7 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
         io.done = io0.done + (int64_t)t * n;
         io.success = io0.success + (int64_t)t * n;
         io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
+        io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr;
         const uint32_t before = L.n_done;
         L.step_tail(P, i, io, updates, lim_hit);
         if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
@@ -1082,10 +1110,11 @@ static __global__ __launch_bounds__(256) void summary_reduce_kernel(const double
 
 template <typename T>
 __global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *q, float *goal, int32_t *step,
-                                                        uint32_t *episode, double *ep_return, double *aux, int aux_rows,
-                                                        int aux_dim) {
+                                                        uint32_t *episode, double *ep_return, double *aux, double *trig,
+                                                        int aux_rows, int aux_dim) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
+  if (trig) static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; trig[2 * NJ * i + j] = (double)P.trig[(int64_t)j * P.n + i]; });
   if (aux && P.aux) {
     for (int k = 0; k < aux_rows; ++k) aux[(int64_t)aux_dim * i + k] = (double)P.aux[(int64_t)k * P.n + i];
     for (int k = aux_rows; k < aux_dim; ++k) aux[(int64_t)aux_dim * i + k] = 0.0;
@@ -1100,18 +1129,22 @@ __global__ __launch_bounds__(256) void get_state_kernel(EnvParams<T> P, double *
 template <typename T>
 __global__ __launch_bounds__(256) void set_state_kernel(EnvParams<T> P, const double *q, const float *goal,
                                                         const int32_t *step, const uint32_t *episode,
-                                                        const double *ep_return, const double *aux, int aux_rows,
-                                                        int aux_dim) {
+                                                        const double *ep_return, const double *aux, const double *trig,
+                                                        int aux_rows, int aux_dim) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   if (aux && P.aux)
     for (int k = 0; k < aux_rows; ++k) P.aux[(int64_t)k * P.n + i] = (T)aux[(int64_t)aux_dim * i + k];
-  if (q) {   // resetJointState: the carried (cos q, sin q) restart from the new angles
+  if (q) {   // resetJointState: without `trig` the carried (cos q, sin q) restart from the new angles
     T qq[NJ], c_[NJ], s_[NJ];
     static_for<0, NJ>([&](auto JI) { constexpr int j = JI; qq[j] = (T)q[7 * i + j]; P.q[(int64_t)j * P.n + i] = qq[j]; });
-    sincos_all<T>(qq, c_, s_);
-    static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = c_[j]; P.trig[(int64_t)(NJ + j) * P.n + i] = s_[j]; });
+    if (!trig) {
+      sincos_all<T>(qq, c_, s_);
+      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = c_[j]; P.trig[(int64_t)(NJ + j) * P.n + i] = s_[j]; });
+    }
   }
+  // a checkpoint's own pair (armenv_get_state): the restored env continues the uninterrupted trajectory bit for bit
+  if (trig) static_for<0, 2 * NJ>([&](auto JI) { constexpr int j = JI; P.trig[(int64_t)j * P.n + i] = (T)trig[2 * NJ * i + j]; });
   if (goal) static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * P.n + i] = goal[3 * i + k]; });
   if (step) P.step[i] = step[i];
   if (episode) P.episode[i] = episode[i];

@@ -34,12 +34,14 @@ template <typename T> struct IKParams {
   int32_t exit_mode;
   int32_t angle_f32;
   int32_t clamp_limits;
-  int32_t fence;    // count the steps whose IK result leaves the URDF limits (ArmEnvConfig.fence_counters)
+  int32_t fence;    // parity-fence bookkeeping on (ArmEnvConfig.fence_counters): limit / flange / cap / conditioning counts
+  T fence_pivot;    // an IK call whose damped system J J^T + lambda I had an LDL^T pivot below this is ill-conditioned
   // URDF joint limits: lim[0..6] lower, lim[7..13] upper, in DEVICE MEMORY (EnvCold) -- 28 scalar registers the IK loop
   // needs for its own constants otherwise (measured: +70 instructions per trip from s_mov rematerialisation and
   // v_readlane spills with the limits held as kernel arguments).  lim_min = min over joints of min(-lower, upper) (or -1
   // when a joint's range does not straddle 0): no joint can be outside its limits while max |q_j| <= lim_min, so the
   // per-step test is six v_max and one compare, and the table is read only by waves that hold a lane beyond it.
+  // lim[14] = limit_erp: the share of a violation one step of the push-back model (clamp_limits == 2) removes.
   const T *lim;
   T lim_min;
 };
@@ -440,8 +442,9 @@ AE_DEV T jj_term(T a, T b, T acc) {
   else if constexpr (kb == 3) return acc - a;
   else return Mth<T>::fma(a, b, acc);
 }
+// D_out: the six LDL^T pivots (the caller's conditioning bookkeeping; values the factorisation computes anyway).
 template <class C, typename T>
-AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ]) {
+AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ], T (&D_out)[6]) {
   using M = Mth<T>;
   // fk() defines the end-effector point as the LAST joint's pivot (S.p == S.pj[NJ-1], the same values), so the lever arm of
   // the last joint is x - x = +0 and its linear Jacobian column an exact zero: every term it enters adds +-0.  That column
@@ -506,6 +509,7 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
       L[i][j] = s * invD[j];
     });
   });
+  static_for<0, 6>([&](auto JI) { constexpr int j = JI; D_out[j] = D[j]; });
   // L zf = e ; w = zf / D ; L^T y = w
   T y[6];
   static_for<0, 6>([&](auto II) {
@@ -589,9 +593,12 @@ AE_DEV void ik_target(const FKState<T> &S, const T (&a)[3], T dv, const T (&box_
 }
 // ik_trip: one trip of Bullet's loop on the pose whose frame is S.  Returns true when the loop stops (nothing changes);
 // otherwise applies one DLS update to q and (cq, sq), leaves S = FK(q) of the updated pose and counts the update in `it`.
+// minpiv (fence bookkeeping only): running minimum of the LDL^T pivots of the call's damped systems -- the damped solve
+// amplifies rounding differences by ~1 / pivot, so a call that passes through a near-singular pose (stretched elbow at the
+// edge of the arm's reach, aligned wrist) is where two implementations' trajectories start to part.
 template <class C, typename T>
 AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
-                    T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps) {
+                    T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps, T &minpiv) {
   using M = Mth<T>;
   T e[6];
   e[0] = tgt[0] - S.p[0];
@@ -604,7 +611,12 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
   quat_from_frame<T>(S.W, qc);
   orientation_error<T>(P.tq, qc, P.angle_f32, eo);
   e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
-  dls_update<C, T>(S, e, P, dth);
+  T piv[6];
+  dls_update<C, T>(S, e, P, dth, piv);
+  if (__builtin_expect(P.fence != 0, 0)) {   // bookkeeping build of the loop body: laid out behind the loop
+    const T m = M::fmin(M::fmin(M::fmin(piv[0], piv[1]), M::fmin(piv[2], piv[3])), M::fmin(piv[4], piv[5]));
+    minpiv = M::fmin(minpiv, m);
+  }
   static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
   if (small_steps) {
     static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
@@ -619,9 +631,12 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
 // ik_limits: URDF joint limits (/root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7, fields 8-9).  The reference never
 // passes them to the IK (rl_reach_env.py:103-107 are dead data, :244-250), so q may leave them; Bullet then pushes the joint
 // back inside stepSimulation (:258) through a limit constraint this build does not model.  Returns whether the IK result
-// lies outside the limits (the parity fence, counted by the caller); with clamp_limits the result is projected onto them
-// -- the hard-limit idealisation of that constraint -- and the frame recomputed, for the lanes that left them only (the
-// others keep their bits).
+// lies outside the limits (the parity fence, counted by the caller).  clamp_limits == 1: the result is projected onto them
+// -- the hard-limit idealisation of that constraint; clamp_limits == 2: every joint beyond a limit is moved back by the share
+// limit_erp of its violation -- one velocity-level constraint solve with Baumgarte stabilisation, as Bullet's
+// btMultiBodyJointLimitConstraint does once per stepSimulation (erp 0.2 by default; a named, unpinned model: the first box
+// with pybullet fits one scalar).  Either way the frame is recomputed for the lanes that left the limits only (the others
+// keep their bits).
 template <class C, typename T>
 AE_DEV bool ik_limits(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], FKState<T> &S, T (&cq)[NJ], T (&sq)[NJ]) {
   using M = Mth<T>;
@@ -634,7 +649,15 @@ AE_DEV bool ik_limits(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], F
       static_for<0, NJ>([&](auto II) { constexpr int i = II; lo[i] = P.lim[i]; hi[i] = P.lim[NJ + i]; });
       static_for<0, NJ>([&](auto II) { constexpr int i = II; hit = hit | (q[i] < lo[i]) | (q[i] > hi[i]); });
       if (P.clamp_limits && hit) {
-        static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = q[i] < lo[i] ? lo[i] : (q[i] > hi[i] ? hi[i] : q[i]); });
+        if (P.clamp_limits == 2) {
+          const T erp = P.lim[2 * NJ];
+          static_for<0, NJ>([&](auto II) {
+            constexpr int i = II;
+            q[i] = q[i] < lo[i] ? M::fma(erp, lo[i] - q[i], q[i]) : (q[i] > hi[i] ? M::fma(erp, hi[i] - q[i], q[i]) : q[i]);
+          });
+        } else {
+          static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] = q[i] < lo[i] ? lo[i] : (q[i] > hi[i] ? hi[i] : q[i]); });
+        }
         sincos_all<T>(q, cq, sq);
         fk<C, T>(ch, cq, sq, S);
       }
@@ -665,7 +688,8 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     if (p_start) { (*p_start)[0] = S.p[0]; (*p_start)[1] = S.p[1]; (*p_start)[2] = S.p[2]; }
     ik_target<T, START_F32>(S, a, dv, box_lo, box_hi, tgt);
   }
-  while (!ik_trip<C, T>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps)) {}
+  T minpiv = T(1e30);
+  while (!ik_trip<C, T>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps, minpiv)) {}
   const bool hit = ik_limits<C, T>(ch, P, q, S, cq, sq);
   if (limit_hit) *limit_hit = hit;
   if (cq_io) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; (*cq_io)[j] = cq[j]; (*sq_io)[j] = sq[j]; }); }

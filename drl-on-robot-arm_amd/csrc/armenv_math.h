@@ -32,6 +32,7 @@ template <> struct Mth<double> {
   static AE_DEV double fabs(double x) { return ::fabs(x); }
   static AE_DEV double fma(double a, double b, double c) { return ::fma(a, b, c); }
   static AE_DEV double fmax(double a, double b) { return ::fmax(a, b); }
+  static AE_DEV double fmin(double a, double b) { return ::fmin(a, b); }
   static AE_DEV bool finite(double x) { return ::isfinite(x); }
   static constexpr double eps = 2.220446049250313e-16;
   static constexpr double pi = 3.14159265358979323846;
@@ -44,6 +45,7 @@ template <> struct Mth<float> {
   static AE_DEV float fabs(float x) { return ::fabsf(x); }
   static AE_DEV float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
   static AE_DEV float fmax(float a, float b) { return ::fmaxf(a, b); }
+  static AE_DEV float fmin(float a, float b) { return ::fminf(a, b); }
   static AE_DEV bool finite(float x) { return ::isfinite(x); }
   static constexpr float eps = 1.1920929e-07f;
   static constexpr float pi = 3.14159265358979323846f;

@@ -23,7 +23,7 @@
  *                                                    push / pick: 9 = [eef, cube, target])
  *   reward  f32 [N]         done / success  u8 [N]
  *   state exchange (get/set_state): q f64 [N][7], goal f32 [N][3], step i32 [N],
- *                                   episode u32 [N], ep_return f64 [N]
+ *                                   episode u32 [N], ep_return f64 [N], trig f64 [N][14] = cos q[7], sin q[7]
  */
 #ifndef ARMENV_H
 #define ARMENV_H
@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define ARMENV_NJ 7
-#define ARMENV_ABI_VERSION 2
+#define ARMENV_ABI_VERSION 3
 
 enum {
   ARMENV_OK = 0,
@@ -85,10 +85,14 @@ typedef struct ArmEnvConfig {
   double dv;               /* /root/reference/config.py:41 (reach 0.02); envs/rl_push_env.py:322 (push 0.08) */
   double reach_dis;        /* config.py:42 */
   int32_t max_steps;       /* config.py:51 ; done when step_counter > max_steps (rl_reach_env.py:299) */
-  int32_t clamp_joint_limits; /* 0 = reference behaviour (limits are dead data, rl_reach_env.py:103-107, never passed to the
-                                 IK at :244-250); 1 = project the IK result onto chain.limit_lo/hi (the URDF limits of
-                                 envs/bmirobot_joints_info_pybullet.txt:1-7 fields 8-9) -- the hard-limit idealisation of the
-                                 joint-limit constraint Bullet applies inside stepSimulation (:258) */
+  int32_t clamp_joint_limits; /* what stepSimulation (:258) does to a joint the IK left outside chain.limit_lo/hi (the URDF limits
+                                 of envs/bmirobot_joints_info_pybullet.txt:1-7 fields 8-9; the reference never passes them to
+                                 the IK: rl_reach_env.py:103-107 are dead data, :244-250).
+                                 0 = nothing (this build's kinematic stepSimulation; default);
+                                 1 = project onto the limits -- the hard-limit idealisation of Bullet's joint-limit constraint;
+                                 2 = move the joint back by the share limit_erp of its violation per step -- one Baumgarte-
+                                     stabilised constraint solve per stepSimulation, as btMultiBodyJointLimitConstraint does.
+                                 Modes 1 and 2 are named models, not pinned against PyBullet. */
   double box_lo[3];        /* Cartesian clip, rl_reach_env.py:221-223 */
   double box_hi[3];
   double goal_lo[3];       /* target sampling box, rl_reach_env.py:65-70,180-182 */
@@ -105,9 +109,12 @@ typedef struct ArmEnvConfig {
   int32_t ik_angle_f32;    /* 1: orientation-error angle rounded through f32 as Bullet does */
   int32_t fence_counters;  /* 1: count the env steps on which this build's kinematic stepSimulation is known to differ from
                               Bullet's -- the IK result lies outside the URDF joint limits (Bullet's limit constraint pushes
-                              back), or the step ends with the flange below fence_z (arm-table contact) -- in
-                              armenv_counters out[5] / out[6].  Every parity claim is fenced by these two rates (bench.py
-                              reports them for its workload).  0 (default): no bookkeeping in the step. */
+                              back), or the step ends with the flange below fence_z (arm-table contact) -- and the env steps on
+                              which no two implementations of the reference's algorithm can be expected to agree, Bullet's own
+                              included: the IK call ran to ik_max_iters without converging (the update oscillates), or one of
+                              its damped systems was ill-conditioned (fence_pivot) -- in armenv_counters out[5] / out[6] / out[7] /
+                              out[8].  Every parity claim is fenced by these four rates (bench.py reports them for its
+                              workloads).  0 (default): no bookkeeping in the step. */
 
   /* push task, /root/reference/envs/rl_push_env.py (the pick task, envs/rl_pick_env.py, shares all six) */
   double push_success_dis; /* 0.05  :422 (pick :425) */
@@ -123,6 +130,13 @@ typedef struct ArmEnvConfig {
   double pick_jaw_half;       /* the closing gripper holds the cube when the cube centre is within this horizontal
                                  distance of the tool axis (default: push_cube_half) */
   double fence_z;             /* 0.05 */
+  double fence_pivot;         /* 1e-2: an IK call is counted as ill-conditioned (armenv_counters out[8]) when an LDL^T pivot of
+                                 one of its damped systems J J^T + ik_lambda I fell below this -- the arm passed through a
+                                 near-singular pose (stretched elbow at the edge of its reach, aligned wrist), where the damped
+                                 solve amplifies rounding differences by ~1 / pivot and the trajectories of any two
+                                 implementations start to part */
+  double limit_erp;           /* clamp_joint_limits == 2: share of a joint-limit violation removed per step (Bullet's default
+                                 constraint error-reduction parameter, 0.2) */
 
   /* armenv_rollout scheduling.  0: lockstep -- the lanes of a wavefront walk through every step together (a step costs the
    * wave its slowest lane's IK trips).  k in 1..64: lane-asynchronous -- a lane whose IK has stopped waits until k lanes of
@@ -151,7 +165,7 @@ int armenv_default_config(int32_t task, ArmEnvConfig *cfg);
 int armenv_builtin_chain(int32_t robot, ArmEnvChain *out);
 
 /* Replaces RLReachEnv.__init__ minus its implicit reset (rl_reach_env.py:44-125): allocates the
- * per-env state on `cfg->device`.  State is undefined until the first armenv_reset. */
+ * per-env state on `cfg->device`.  Until the first armenv_reset every env sits at q = 0 with a zero goal. */
 int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out);
 void armenv_destroy(ArmEnv *env);
 
@@ -173,9 +187,11 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
  *   distance/reward/done -> obs.
  * action_dev may be NULL when a fused policy was installed with armenv_set_policy.
  * terminal_obs_dev (nullable, f32 [N][obs_dim]) receives the observation of this step before any
- * auto-reset; with auto_reset the obs of a finished env is its next episode's first observation. */
+ * auto-reset; with auto_reset the obs of a finished env is its next episode's first observation.
+ * ik_updates_dev (nullable, u8 [N]) receives the number of DLS updates the step's calculateInverseKinematics call
+ * (:244-250) applied, saturated at 255: ik_max_iters means the call did not converge (the third parity-fence term). */
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
-                uint8_t *success_dev, float *terminal_obs_dev, void *stream);
+                uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, void *stream);
 
 /* Replaces the rollout inner loop of /root/reference/main.py:108-128 (take_action -> noise -> step -> store) for
  * `steps` consecutive env steps of all N envs in ONE kernel launch; the env state stays in registers between steps.
@@ -185,12 +201,13 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
  *                NULL: the fused policy installed with armenv_set_policy produces the actions in-kernel.
  *   obs_dev f32 [steps][N][obs_dim], reward_dev f32 [steps][N], done_dev / success_dev u8 [steps][N]: row t holds
  *   what armenv_step would have returned at step t.  actions_out_dev (nullable, f32 [steps][N][3]) receives the
- *   actions taken; terminal_obs_dev (nullable) as in armenv_step, per step.
+ *   actions taken; terminal_obs_dev (nullable) and ik_updates_dev (nullable, u8 [steps][N]) as in armenv_step, per step.
  * Waves never synchronise inside the launch, so an env that needs extra IK iterations in one step stalls only its own
  * wavefront for that step (lockstep schedule) or only itself (lane-asynchronous schedule, ArmEnvConfig.rollout_ready_lanes):
  * throughput follows the mean IK cost per step, not the per-launch maximum. */
 int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,
-                   uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev, void *stream);
+                   uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev,
+                   uint8_t *ik_updates_dev, void *stream);
 
 /* Replaces p.getLinkState(body, 6)[4], [5] (call sites rl_reach_env.py:202,237,271): world position
  * f64 [n][3] and orientation quaternion xyzw f64 [n][4] (nullable) of the link-7 frame for joint
@@ -208,23 +225,28 @@ int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_
  * loadURDF :186-189, step_counter :264).  Any pointer may be NULL to skip that field. Push and pick keep their
  * cube state in aux f64 [N][armenv_aux_dim()]: push [N][8] = [cube xyz, target xyz, d_last, pad]; pick [N][12] =
  * [cube xyz, target xyz, d_last, gripper (0 open, 1 closed, 2 closed and holding the cube), cube - tip offset xyz
- * while held, pad]. */
+ * while held, pad].
+ * trig f64 [N][14] = (cos q[7], sin q[7]) is the pair the engine carries with q and advances incrementally (DESIGN.md
+ * section 4): a checkpoint that restores q AND trig continues the uninterrupted trajectory bit for bit; set_state with q
+ * and trig_dev == NULL re-derives the pair from q (resetJointState semantics: equal to ~1e-16, which the IK's 2 acos(w)
+ * orientation error can amplify to ~1e-7 rad over the following steps). */
 int armenv_get_state(ArmEnv *env, double *q_dev, float *goal_dev, int32_t *step_dev, uint32_t *episode_dev,
-                     double *ep_return_dev, double *aux_dev, void *stream);
+                     double *ep_return_dev, double *aux_dev, double *trig_dev, void *stream);
 int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, const int32_t *step_dev,
                      const uint32_t *episode_dev, const double *ep_return_dev, const double *aux_dev,
-                     void *stream);
+                     const double *trig_dev, void *stream);
 
 /* Per-env statistics of the most recently finished episode (what main.py:125-130 accumulates on
  * the host: episode_return, success).  Any pointer may be NULL. */
 int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len_dev, uint8_t *last_success_dev,
                          void *stream);
 
-/* Totals since creation, copied to host (synchronises `stream`): out[0] episodes finished, out[1] successes,
+/* Totals since creation, copied to host (synchronises `stream`), out[16]: out[0] episodes finished, out[1] successes,
  * out[2] env-steps executed, out[3] non-finite joint states seen, out[4] IK (DLS) updates applied, out[5] env steps whose IK
- * result left the URDF joint limits, out[6] env steps that ended with the flange below fence_z (the parity fence, see
- * ArmEnvConfig.fence_counters), out[7] 0. */
-int armenv_counters(ArmEnv *env, uint64_t out[8], void *stream);
+ * result left the URDF joint limits, out[6] env steps that ended with the flange below fence_z, out[7] env steps whose IK
+ * call ran to ik_max_iters, out[8] env steps whose IK call passed through an ill-conditioned system (fence_pivot);
+ * out[5..8]: the parity fence, counted only with ArmEnvConfig.fence_counters; out[9..15] 0 (reserved). */
+int armenv_counters(ArmEnv *env, uint64_t out[16], void *stream);
 
 /* Logging summary computed on the device (no host sync; what main.py:130-160 prints/plots from one env): out_dev f64 [8] =
  * [sum over envs of the current distance to the goal (reach: |FK(q) - goal|, push: |cube - target|), max of it, sum of

@@ -86,15 +86,23 @@ class OrcConfig(C.Structure):
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
         ("clamp_joint_limits", C.c_int32), ("pad0", C.c_int32), ("lim_lo", C.c_double * NJ), ("lim_hi", C.c_double * NJ),
-        ("fence_z", C.c_double),
+        ("fence_z", C.c_double), ("limit_erp", C.c_double), ("fence_pivot", C.c_double),
     ]
 
 
 def build(force=False):
     """Compile the oracle with gcc (no GPU, no reference sources involved)."""
     src = os.path.join(_HERE, "armenv_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, f"TAG={_TAG}"] + (["-B"] if force else []))
+    stale = lambda: not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    if force or stale():
+        # first users race on a fresh box (pytest-xdist workers, torchrun ranks, bench's cpu-leg child beside its parent): one
+        # builds under the lock, the others find the object up to date when they get it; the Makefile renames into place
+        import fcntl
+        os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+        with open(os.path.join(_HERE, "build", ".lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-s", "-C", _HERE, f"TAG={_TAG}"] + (["-B"] if force else []))
     return _SO
 
 
@@ -142,6 +150,8 @@ def default_config(task="reach", robot="kuka"):
     c.lim_lo[:] = [-x for x in ROBOTS[robot]["limit"]]      # bmirobot_joints_info_pybullet.txt:1-7 fields 8-9 (symmetric)
     c.lim_hi[:] = list(ROBOTS[robot]["limit"])
     c.fence_z = 0.05
+    c.limit_erp = 0.2          # Bullet's default constraint ERP; read by clamp_joint_limits == 2 only
+    c.fence_pivot = 1e-2       # conditioning term of the parity fence
     c.task = {"reach": 0, "push": 1, "pick": 2}[task]
     c.dv = 0.02 if task == "reach" else 0.08
     c.reach_dis = 0.01
@@ -220,8 +230,28 @@ def ik(chain, cfg, q, tgt):
     return out, iters
 
 
+def ik_diag(chain, cfg, q, tgt):
+    """Conditioning of IK calls: (diag [n,3] = smallest LDL^T pivot of J J^T + lambda I over the call, largest |dtheta|
+    before the scale-back, final position residual; updates [n])."""
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, NJ)
+    tgt = np.ascontiguousarray(tgt, dtype=np.float64).reshape(-1, 3)
+    n = q.shape[0]
+    diag = np.empty((n, 3)); iters = np.empty(n, dtype=np.int32)
+    lib().orc_ik_diag_batch(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(q), _p(tgt), _p(diag), _p(iters))
+    return diag, iters
+
+
+def pose_min_pivot(chain, cfg, q):
+    """Smallest LDL^T pivot of J J^T + lambda I at the poses q [n,7] (the conditioning term of the parity fence)."""
+    q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, NJ)
+    out = np.empty(q.shape[0])
+    lib().orc_pose_min_pivot_batch(C.byref(chain), C.c_double(cfg.ik_lambda), C.c_int64(q.shape[0]), _p(q), _p(out))
+    return out
+
+
 def fence_flags(chain, cfg, q, tgt):
-    """Per env: bit 0 = the (unclamped) IK result leaves the URDF limits, bit 1 = the flange ends below cfg.fence_z."""
+    """Per env: bit 0 = the (unclamped) IK result leaves the URDF limits, bit 1 = the flange ends below cfg.fence_z,
+    bit 2 = the IK call ran to cfg.ik_max_iters, bit 3 = an LDL^T pivot of one of its damped systems fell below cfg.fence_pivot."""
     q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, NJ)
     tgt = np.ascontiguousarray(tgt, dtype=np.float64).reshape(-1, 3)
     lib().orc_fence_flags.restype = C.c_int
@@ -281,19 +311,20 @@ def reach_reset_with_goal(chain, cfg, st, goal):
     return obs
 
 
-def reach_step(chain, cfg, st, action):
-    """One step, no auto-reset.  Returns obs f32[N,6], reward f64[N], done, success, ik updates."""
+def reach_step(chain, cfg, st, action, minpiv=None):
+    """One step, no auto-reset.  Returns obs f32[N,6], reward f64[N], done, success, ik updates.
+    minpiv (optional f64 [N]): receives the smallest LDL^T pivot of each env's IK call (the fence's conditioning measure)."""
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 6), dtype=np.float32); rew = np.zeros(n)
     done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); iters = np.zeros(n, dtype=np.int32)
     lib().orc_reach_step(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(st.q), _p(st.goal), _p(st.step), _p(a),
-                         _p(obs), _p(rew), _p(done), _p(succ), _p(iters))
+                         _p(obs), _p(rew), _p(done), _p(succ), _p(iters), _p(minpiv))
     st.ep_return += rew
     return obs, rew, done, succ, iters
 
 
-def reach_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, want_terminal=True, iters=None):
+def reach_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, want_terminal=True, iters=None, minpiv=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 6), dtype=np.float32); rew = np.zeros(n)
@@ -302,7 +333,7 @@ def reach_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, want_termina
     lib().orc_reach_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
                                    _p(st.q), _p(st.goal), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a),
                                    _p(obs), _p(rew), _p(done), _p(succ), _p(term),
-                                   _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters))
+                                   _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters), _p(minpiv))
     return obs, rew, done, succ, term
 
 
@@ -367,6 +398,15 @@ def policy_noise(st, seed=0, env_id0=0):
     return nz
 
 
+def policy_noise_ids(seed, env_ids, episode, step):
+    """Exploration noise [n,3] of the envs with global ids `env_ids`, `episode` = resets so far (u32), `step` = step counter."""
+    ids = np.ascontiguousarray(env_ids, dtype=np.int64)
+    ep = np.ascontiguousarray(episode, dtype=np.uint32); sp = np.ascontiguousarray(step, dtype=np.int32)
+    nz = np.zeros((ids.size, 3), dtype=np.float32)
+    lib().orc_policy_noise_ids(C.c_uint64(seed), C.c_int64(ids.size), _p(ids), _p(ep), _p(sp), _p(nz))
+    return nz
+
+
 def reach_rollout(chain, cfg, st, steps, actions=None, seed=0, env_id0=0, sigma=0.7 * 0.98, clip=0.7, actor=None,
                   bound=0.7, obs0=None):
     """`steps` auto-reset steps; actions [steps,N,3], or None for the fused policy: zero actor (random) or, with
@@ -420,25 +460,25 @@ def push_reset_with_goal(chain, cfg, st, goal6):
     return obs
 
 
-def push_step(chain, cfg, st, action):
+def push_step(chain, cfg, st, action, minpiv=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
     done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); iters = np.zeros(n, dtype=np.int32)
     lib().orc_push_step(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(st.q), _p(st.aux), _p(st.step), _p(a), _p(obs),
-                        _p(rew), _p(done), _p(succ), _p(iters))
+                        _p(rew), _p(done), _p(succ), _p(iters), _p(minpiv))
     st.ep_return += rew
     return obs, rew, done, succ, iters
 
 
-def push_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, iters=None):
+def push_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, iters=None, minpiv=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
     done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); term = np.zeros((n, 9), dtype=np.float32)
     lib().orc_push_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
                                   _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a), _p(obs),
-                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters))
+                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters), _p(minpiv))
     return obs, rew, done, succ, term
 
 
@@ -480,23 +520,23 @@ def pick_reset_with_goal(chain, cfg, st, goal6):
     return obs
 
 
-def pick_step(chain, cfg, st, action):
+def pick_step(chain, cfg, st, action, minpiv=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
     done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); iters = np.zeros(n, dtype=np.int32)
     lib().orc_pick_step(C.byref(chain), C.byref(cfg), C.c_int64(n), _p(st.q), _p(st.aux), _p(st.step), _p(a), _p(obs),
-                        _p(rew), _p(done), _p(succ), _p(iters))
+                        _p(rew), _p(done), _p(succ), _p(iters), _p(minpiv))
     st.ep_return += rew
     return obs, rew, done, succ, iters
 
 
-def pick_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, iters=None):
+def pick_step_autoreset(chain, cfg, st, action, seed=0, env_id0=0, iters=None, minpiv=None):
     n = st.n
     a = np.ascontiguousarray(action, dtype=np.float32).reshape(n, 3)
     obs = np.zeros((n, 9), dtype=np.float32); rew = np.zeros(n)
     done = np.zeros(n, dtype=np.uint8); succ = np.zeros(n, dtype=np.uint8); term = np.zeros((n, 9), dtype=np.float32)
     lib().orc_pick_step_autoreset(C.byref(chain), C.byref(cfg), C.c_uint64(seed), C.c_uint64(env_id0), C.c_int64(n),
                                   _p(st.q), _p(st.aux), _p(st.step), _p(st.episode), _p(st.ep_return), _p(a), _p(obs),
-                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters))
+                                  _p(rew), _p(done), _p(succ), _p(term), _p(st.last_return), _p(st.last_len), _p(st.last_success), _p(iters), _p(minpiv))
     return obs, rew, done, succ, term

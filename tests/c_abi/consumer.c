@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
   CHECK_HIP(hipMemcpy(act, h_act, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
 
   CHECK_ENV(armenv_reset(env, NULL, obs, NULL));
-  for (int t = 0; t < steps; ++t) CHECK_ENV(armenv_step(env, act, obs, rew, done, succ, NULL, NULL));
+  for (int t = 0; t < steps; ++t) CHECK_ENV(armenv_step(env, act, obs, rew, done, succ, NULL, NULL, NULL));
   CHECK_HIP(hipDeviceSynchronize());
 
   float h_obs[6];
@@ -46,13 +46,13 @@ int main(int argc, char **argv) {
   CHECK_HIP(hipMemcpy(h_rew, rew, sizeof(float) * n, hipMemcpyDeviceToHost));
   double rsum = 0.0;
   for (long i = 0; i < n; ++i) rsum += h_rew[i];
-  uint64_t c[8];
+  uint64_t c[16];
   CHECK_ENV(armenv_counters(env, c, NULL));
   printf("%.9g %.9g %.9g %.9g %.9g %.9g %.9g %llu %llu %s\n", h_obs[0], h_obs[1], h_obs[2], h_obs[3], h_obs[4], h_obs[5], rsum,
          (unsigned long long)c[2], (unsigned long long)c[3], armenv_kernel_name(env));
 
   /* error path: a NULL output buffer is refused with a message, nothing aborts */
-  if (armenv_step(env, act, NULL, rew, done, succ, NULL, NULL) != ARMENV_EINVAL || armenv_last_error()[0] == '\0') return 5;
+  if (armenv_step(env, act, NULL, rew, done, succ, NULL, NULL, NULL) != ARMENV_EINVAL || armenv_last_error()[0] == '\0') return 5;
   armenv_destroy(env);
   hipFree(obs); hipFree(act); hipFree(rew); hipFree(done); hipFree(succ);
   free(h_act); free(h_rew);

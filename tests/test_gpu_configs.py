@@ -1,0 +1,195 @@
+"""BASELINE.json configs inside the suite, at their own sizes:
+  configs[0]  rl_reach_env.py single env, TD3 from algo/TD3, 1k steps (plumbing)   -> test_config0_*
+  configs[2]  rl_reach_env 65 536 envs + TD3 actor forward fused into the step kernel -> test_config2_*
+(configs[1] and [3] at full size: tests/test_gpu_parity.py::test_benchmarked_launch_shape_free_running_vs_oracle_f64[65536],
+tests/test_gpu_fence.py::test_push_config4_free_running_vs_oracle.)"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_npz
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def envs():
+    from armenv import envs
+    return envs
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_config0_single_env_td3_1000_steps(envs, O, kuka):
+    """BASELINE configs[0]: the loop of /root/reference/main.py:100-138 -- reset, (take_action -> exploration noise -> step ->
+    store_step) until done, add_trajectory, and opt.n_train TD3 updates on HER batches once the store holds
+    opt.minimal_episodes episodes -- for 1 000 steps of the N=1 drop-in ``envs.RLReachEnv`` with the build's TD3 / Trajectory /
+    TrajectoryStore counterparts.  Episodes are 101 steps long here (opt.max_steps_one_episode = 100) so that the training
+    branch runs inside the 1 000 steps.  The N=1 trajectory is checked against the oracle fed the same actions: f32
+    observations to 1e-6, identical done / success, and the reward -- a Python float computed in f64, as the reference returns
+    it (/root/reference/envs/rl_reach_env.py:300-319) -- to 1e-12."""
+    from armenv import opt
+    from armenv.replay import Trajectory, TrajectoryStore
+    from armenv.td3 import TD3
+    saved = opt.max_steps_one_episode
+    opt.max_steps_one_episode = 100
+    try:
+        env = envs.RLReachEnv(is_render=False, is_good_view=False)                   # main.py:83 (the ctor resets once, :125)
+        state_dim, action_dim = env.observation_space.shape[0], env.action_space.shape[0]
+        action_bound = float(env.action_space.high[0]) + 0.3                         # main.py:85-87
+        assert (state_dim, action_dim) == (6, 3) and abs(action_bound - 0.7) < 1e-7
+        random.seed(opt.random_seed); np.random.seed(opt.random_seed); torch.manual_seed(opt.random_seed)   # main.py:89-91
+        store = TrajectoryStore(device=DEV, seed=0, capacity_steps=4096)             # main.py:93
+        agent = TD3(state_dim, action_dim, action_bound, device=DEV)                 # main.py:95
+        cfg = O.default_config(); cfg.max_steps = 100
+        st = O.ReachState(1)
+        steps = episodes = updates = successes = 0
+        worst_obs = worst_rew = 0.0
+        w0 = agent.actor.fc1.weight.detach().clone()
+        while steps < 1000:
+            state = env.reset()                                                      # main.py:108
+            assert state.dtype == np.float32 and state.shape == (6,)
+            obs_r = O.reach_reset_with_goal(kuka, cfg, st, state[3:].reshape(1, 3))
+            assert np.abs(state - obs_r[0]).max() < 1e-6
+            traj = Trajectory(state)                                                 # main.py:109
+            done, ep_ret = False, 0.0
+            while not done:
+                action = agent.take_action(state)                                    # main.py:114
+                action = (action + np.random.normal(0, action_bound * opt.gamma, size=action_dim)).clip(-action_bound, action_bound)
+                state, reward, done, is_success = env.step(action)                   # main.py:124
+                o_r, r_r, d_r, s_r, _ = O.reach_step(kuka, cfg, st, action.astype(np.float32).reshape(1, 3))
+                assert isinstance(reward, float) and isinstance(done, bool) and isinstance(is_success, bool)
+                assert done == bool(d_r[0]) and is_success == bool(s_r[0]), steps
+                worst_obs = max(worst_obs, float(np.abs(state - o_r[0]).max()))
+                worst_rew = max(worst_rew, abs(reward - float(r_r[0])))
+                if is_success:
+                    assert reward == 0 and done                                      # main.py:125 compares reward == 0
+                    successes += 1
+                ep_ret += reward
+                traj.store_step(action, state, reward, done)                         # main.py:128
+                steps += 1
+            store.add_trajectory(traj)                                               # main.py:129
+            episodes += 1
+            assert env.step_counter == traj.length <= 101
+            if store.size() >= opt.minimal_episodes:                                 # main.py:135-138
+                for _ in range(opt.n_train):
+                    batch = store.sample(opt.batch_size, use_her=True, her_ratio=opt.her_ratio)
+                    loss = agent.train(batch)
+                    updates += 1
+                assert bool(torch.isfinite(loss))
+        assert store.size() == episodes >= 9 and updates >= 5 * opt.n_train
+        assert worst_obs < 1e-6, worst_obs
+        assert worst_rew < 1e-12, worst_rew
+        assert not torch.equal(w0, agent.actor.fc1.weight.detach())                  # the delayed actor update ran
+        env.close()
+    finally:
+        opt.max_steps_one_episode = saved
+
+
+@pytest.mark.parametrize("kind", ["push", "pick"])
+def test_n1_cube_envs_return_the_f64_reward(envs, O, kuka, kind):
+    """RLPushEnv / RLPickEnv N=1 drop-ins: the shaped reward -100 * (d_now - d_last) as a Python float in f64
+    (/root/reference/envs/rl_push_env.py:388-397,427), against the f64 oracle fed the same actions."""
+    random.seed(3); np.random.seed(3)
+    Env = envs.RLPushEnv if kind == "push" else envs.RLPickEnv
+    env = Env(is_render=False, is_good_view=False)
+    state = env.reset()
+    cfg = O.default_config(kind)
+    st = (O.PushState if kind == "push" else O.PickState)(1)
+    reset_g, stepf = (O.push_reset_with_goal, O.push_step) if kind == "push" else (O.pick_reset_with_goal, O.pick_step)
+    reset_g(kuka, cfg, st, state[3:9].reshape(1, 6))
+    st.aux[0, :6] = state[3:9]                                   # the f64 placement (reset_with_goal takes f32)
+    st.aux[0, 6] = np.linalg.norm(state[3:6] - state[6:9])
+    worst = 0.0
+    moved = 0
+    d_last = float(np.linalg.norm(state[3:6] - state[6:9]))
+    for t in range(60):
+        # steer the tool through the cube at table height so that the shaped reward is not just the idle -1
+        eef, cube = state[:3].astype(np.float64), state[3:6]
+        tip = eef - np.array([0.0, 0.0, 0.257 if kind == "pick" else 0.0])
+        want = cube + np.array([0.0, 0.0, 0.012]) + 0.05 * np.sign(cube - tip) * np.array([1, 1, 0])
+        action = np.clip((want - tip) / 0.08, -0.5, 0.5)
+        state, reward, done, info = env.step(action)
+        o_r, r_r, d_r, s_r, _ = stepf(kuka, cfg, st, action.astype(np.float32).reshape(1, 3))
+        assert done == bool(d_r[0])
+        worst = max(worst, abs(float(reward) - float(r_r[0])))
+        # the reference computes the reward from the observation it returns (:388-397): the same f64 expression, bit for bit
+        d_cur = float(np.linalg.norm(state[3:6] - state[6:9]))
+        test = d_cur - d_last
+        d_last = d_cur
+        if not done:
+            assert isinstance(reward, float) and reward == -(0.01 if abs(test) < 1e-5 else test) * 100, (t, reward)
+        moved += int(float(reward) != -1.0)
+        if done:
+            break
+    assert worst < 1e-6, worst               # free-running against the oracle for 60 steps (the arm differs by ~1e-10 by then)
+    assert moved >= 3, moved
+    env.close()
+
+
+def _golden_actor_sd():
+    g = golden_npz("td3_actor_seed0.npz")
+    return {k: torch.from_numpy(g[k.replace(".", "_")]) for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+
+
+@pytest.mark.parametrize("kind", ["actor", "actor_f16x3"])
+def test_config2_fused_actor_65536_envs_vs_oracle(envs, O, kuka, kind):
+    """BASELINE configs[2] at its own size: 65 536 reach envs, the reference agent's actor (golden weights produced by importing
+    algo.TD3) folded into the rollout kernel with run()'s exploration noise, 2 x armenv_rollout(100).  Checked on a strided
+    sample of 2 048 envs (global ids 0, 32, 64, ...: the noise and the goals are keyed by global env id, so the oracle
+    reproduces exactly those envs): actions within 2e-5 of oracle actor + noise, observations within 1e-5 while the oracle is
+    teacher-forced with the engine's own actions (so that the MFMA actor's 1e-6 does not compound through the policy
+    loop), identical done / success flags.  Matches /root/reference/algo/TD3/TD3_mlp.py:82-97, main.py:114-117."""
+    n, T, stride = 65536, 100, 32
+    sd = _golden_actor_sd()
+    sd_np = {k: v.numpy() for k, v in sd.items()}
+    e = envs.BatchedReachEnv(n, device=DEV, seed=4)
+    e.set_policy(kind, action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7, actor_state_dict=sd)
+    obs0 = _np(e.reset()).copy()
+    ids = np.arange(0, n, stride)
+    m = ids.size
+    cfg = O.default_config()
+    for gid in ids[:64]:          # goals of the first sampled envs reproduce bit for bit (Philox keyed by global id)
+        s1 = O.ReachState(1)
+        o1 = O.reach_reset(kuka, cfg, s1, seed=4, env_id0=int(gid))
+        assert np.array_equal(o1[0, 3:], obs0[gid, 3:])
+    # batch oracle state for the whole sample, initialised from the engine's own reset (goals verified above)
+    st = O.ReachState(m)
+    st.q[:] = np.array(O.INIT_Q); st.goal[:] = obs0[ids, 3:]; st.episode[:] = 1
+    obs_prev = obs0[ids].copy()
+    worst_a = worst_o = 0.0
+    flags = 0
+    resets = 0
+    for launch in range(2):
+        out = e.rollout(T, None, want_actions=True, want_terminal_obs=True)
+        acts, obs, term, done, succ = (_np(out[k]) for k in ("actions", "obs", "terminal_obs", "done", "success"))
+        for t in range(T):
+            # what the fused policy must have produced from the observation it saw: actor(obs) + sigma * noise, clipped
+            mu = O.actor_forward(sd_np, obs_prev, 0.7)
+            nz = O.policy_noise_ids(4, ids, st.episode, st.step)
+            want = np.clip(mu + np.float32(0.7 * 0.98) * nz, -np.float32(0.7), np.float32(0.7))
+            a = acts[t][ids]
+            worst_a = max(worst_a, float(np.abs(a - want).max()))
+            # teacher-forced on the actions: the oracle env takes the engine's action
+            o_r, r_r, d_r, s_r, iters = O.reach_step(kuka, cfg, st, a)
+            worst_o = max(worst_o, float(np.abs(term[t][ids] - o_r).max()))
+            flags += int((done[t][ids] != d_r.astype(bool)).sum() + (succ[t][ids] != s_r.astype(bool)).sum())
+            # auto-reset on the oracle side for finished envs: next goal from the engine's obs (verified against Philox above)
+            fin = d_r.astype(bool)
+            if fin.any():
+                resets += int(fin.sum())
+                st.q[fin] = np.array(O.INIT_Q); st.step[fin] = 0; st.episode[fin] += 1; st.ep_return[fin] = 0
+                st.goal[fin] = obs[t][ids][fin, 3:]
+            obs_prev = obs[t][ids].copy()            # what the fused policy sees next (a finished env: its new episode's first obs)
+    assert worst_a < 2e-5, worst_a
+    assert worst_o < 1e-5, worst_o
+    assert flags == 0
+    c = e.counters()
+    assert c["env_steps"] == n * 2 * T and c["nonfinite"] == 0
+    e.close()
