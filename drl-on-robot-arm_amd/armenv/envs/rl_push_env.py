@@ -42,7 +42,7 @@ class RLPushEnv:
         self.action_space = Box(low=[-0.4, -0.4, -0.6], high=[0.4, 0.4, 0.3])  # :94-97
         self.observation_space = Box(low=[0.2, -0.3, 0], high=[0.7, 0.3, 0.55])  # :100-103
         self.step_counter = 0
-        self._eng = BatchedPushEnv(1, device=device, auto_reset=False, precision=64,
+        self._eng = BatchedPushEnv(1, device=device, auto_reset=False, precision=64, fk_path=1,
                                    max_steps=int(self.max_steps_one_episode))
         self.seed()
         self.reset()                                                            # :137
@@ -66,7 +66,7 @@ class RLPushEnv:
         st[0, 0:3], st[0, 3:6] = cube, target
         st[0, 6] = math.sqrt(sum((a - b) ** 2 for a, b in zip(cube, target)))
         self._eng.set_state(aux=st)
-        self._d_last = float(np.linalg.norm(np.asarray(cube) - np.asarray(target)))   # last_object_pos / last_target_pos (:243-245)
+        self._d_last = float(np.linalg.norm(np.asarray(cube) - np.asarray(target), axis=-1))   # last_object_pos / last_target_pos (:243-245)
         return self._obs64(obs)
 
     def step(self, action):

@@ -59,7 +59,7 @@ class RLReachEnv:
 
     def _make_engine(self):
         self._dv, self._dis = float(opt.reach_ctr), float(opt.reach_dis)
-        self._eng = BatchedReachEnv(1, device=self._device, auto_reset=False, precision=64,
+        self._eng = BatchedReachEnv(1, device=self._device, auto_reset=False, precision=64, fk_path=1,
                                     dv=self._dv, reach_dis=self._dis, max_steps=int(self.max_steps_one_episode))
 
     def _sync_opt(self):
@@ -89,7 +89,7 @@ class RLReachEnv:
         """:219-319 -> (np.float32[6], float reward, bool done, bool is_success).  The step itself is one armenv_step launch (actions
         and the reward buffer are f32 at that boundary); the reward returned here is recomputed in f64 from the env's f64 joint
         state -- armenv_fk, then the expressions of :281-309 in numpy -- because the reference returns a Python float computed in
-        f64: equal to the f64 oracle to ~1e-15, not merely to f32 rounding."""
+        f64: it carries all its digits, not an f32 rounding of them."""
         self._sync_opt()
         a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 3), dtype=torch.float32).to(self._eng.device)
         obs, reward, done, success = self._eng.step(a)

@@ -167,6 +167,8 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   if (cfg->ik_max_iters < 0 || cfg->ik_max_iters > 1000) return fail(ARMENV_EINVAL, "armenv_create: ik_max_iters out of range");
   if (cfg->clamp_joint_limits < 0 || cfg->clamp_joint_limits > 2) return fail(ARMENV_EINVAL, "armenv_create: clamp_joint_limits must be 0, 1 or 2");
   if (cfg->clamp_joint_limits == 2 && !(cfg->limit_erp > 0.0 && cfg->limit_erp <= 1.0)) return fail(ARMENV_EINVAL, "armenv_create: limit_erp must be in (0, 1]");
+  if (cfg->rollout_lanes_per_wave != 0 && cfg->rollout_lanes_per_wave != 32 && cfg->rollout_lanes_per_wave != 64)
+    return fail(ARMENV_EINVAL, "armenv_create: rollout_lanes_per_wave must be 0, 32 or 64");
   if (cfg->rollout_waves_per_simd < 0 || cfg->rollout_waves_per_simd > 2) return fail(ARMENV_EINVAL, "armenv_create: rollout_waves_per_simd must be 0, 1 or 2");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -284,6 +286,9 @@ int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const fl
       return fail(ARMENV_EINVAL, "armenv_set_policy: hidden_dim %d; the fused actor is built for %d (config.py:56)", hidden_dim, ACTOR_HID);
     if (env->cfg.num_envs % 64 != 0)
       return fail(ARMENV_EINVAL, "armenv_set_policy: the fused actor needs num_envs to be a multiple of 64 (full wavefronts)");
+    if (env->cfg.fence_counters)
+      return fail(ARMENV_ESTATE, "armenv_set_policy: the parity-fence bookkeeping (fence_counters) is built for external actions and the "
+                                 "in-kernel random policy, not for the fused actors");
     const int rc = env->eng->set_actor(W1_dev, b1_dev, W2_dev, b2_dev, W3_dev, b3_dev, armenv_obs_dim(env), action_bound,
                                        static_cast<hipStream_t>(stream));
     if (rc != ARMENV_OK) return rc;

@@ -69,6 +69,42 @@ AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, in
   }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Layer 3 (3 x 256, /root/reference/algo/TD3/net_mlp.py:35,40) on the matrix pipe.  After layer 2 a lane holds, for ITS env column,
+// the 16 neurons {32 nt + 8 (r / 4) + 4 half + (r % 4)} of tile nt in its accumulator registers -- exactly the B operand of
+// v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4x1 outer products: lane l supplies B[block l / 4][column l % 4] and
+// A[block l / 4][row l % 4]; result register i of lane l = sum over the chained instructions of A[block][row i] * B[block][column l % 4];
+// tests/tools/exp/mfma4x4_probe.hip).  With A[row i] = W3[i][neuron] (row 3 unused) every lane ends with the three output sums
+// of its own env over the 128 neurons it holds; lane ^ 32 has the other 128.  Per neuron: one 4-byte LDS read (the A value: the
+// four lanes of a block are in the same wave half, so they want the same neuron), one integer max (relu) and one 8-cycle MFMA
+// issue, instead of a 16-byte LDS read, the relu and three dependent f32 FMAs: the epilogues of the two passes were 3.3 us of
+// the f16x3 actor's 32 us per fused env step (ablation).
+// w3p: the lane's base into the (b2, W3[0], W3[1], W3[2]) table = table + 16 half + 1 + (lane & 3) floats; row 3 of the A
+// operand reads the next neuron's b2 -- finite, and result register 3 is never looked at.
+// Two independent accumulator chains per call (a 4x4x1 result is ready two passes after issue): d0 / d1 are the two halves of
+// one env column's registers (f16x3 actor), or the two env columns of the exact-f32 actor's accumulator pair.
+template <int NT_BASE, class Relu>
+AE_DEV void layer3_tile(const float *w3p, const f32x16 &acc, f32x4 &d0, f32x4 &d1, Relu relu) {
+  float a[16];
+  static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[r] = w3p[4 * (32 * NT_BASE + (r & 3) + 8 * (r >> 2))]; });
+  static_for<0, 8>([&](auto RI) {
+    constexpr int r = RI;
+    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], relu(acc[r]), d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r + 8], relu(acc[r + 8]), d1, 0, 0, 0);
+  });
+}
+template <int NT_BASE, class Relu>
+AE_DEV void layer3_tile_pair(const float *w3p, const f32x16 &accA, const f32x16 &accB, f32x4 &dA, f32x4 &dB, Relu relu) {
+  float a[16];
+  static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[r] = w3p[4 * (32 * NT_BASE + (r & 3) + 8 * (r >> 2))]; });
+  static_for<0, 16>([&](auto RI) {
+    constexpr int r = RI;
+    dA = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], relu(accA[r]), dA, 0, 0, 0);
+    dB = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], relu(accB[r]), dB, 0, 0, 0);
+  });
+}
+
 // Exact-f32 actor for the 64 envs of one wave.  s: this lane's env observation (IN floats); all 64 lanes must be active;
 // w1_lds: the tables of actor_stage_w1.
 //   Layer 1 runs on the f32 MFMA as W1aug . [obs, 1] per 32-neuron row tile and env column tile.  In the accumulator
@@ -127,16 +163,23 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
   // accumulator depended on what the scheduler happened to put in between (wrong actions in the 9-input push rollout
   // after an unrelated change elsewhere in the kernel).
   auto relu = [](float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); };
-  float p[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   const float4 *w2 = A.W2P + l32;
   const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;     // staged beside the layer-1 table
+  const float4 *b2tab = b2w3 + ACTOR_HID;                 // b2 alone, four consecutive neurons per float4
+  const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);   // layer3_tile
+  f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};   // layer-3 sums of the env in tile 0 / tile 1
   constexpr int AD = 4;
 #pragma unroll 1
   for (int part = 0; part < 2; ++part) {
-    f32x16 acc[4][2];
+    f32x16 acc[4][2];   // start from the layer-2 bias: register r <-> neuron 32 (4 part + nt) + 8 (r / 4) + 4 half + (r % 4)
     static_for<0, 4>([&](auto NI) {
       constexpr int nt = NI;
-      static_for<0, 16>([&](auto RI) { constexpr int r = RI; acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f; });
+      static_for<0, 4>([&](auto QI) {
+        constexpr int q = QI;
+        const float4 b = b2tab[8 * (4 * part + nt) + 2 * q + half];
+        acc[nt][0][4 * q] = b.x; acc[nt][0][4 * q + 1] = b.y; acc[nt][0][4 * q + 2] = b.z; acc[nt][0][4 * q + 3] = b.w;
+        acc[nt][1][4 * q] = b.x; acc[nt][1][4 * q + 1] = b.y; acc[nt][1][4 * q + 2] = b.z; acc[nt][1][4 * q + 3] = b.w;
+      });
     });
     float4 aring[AD];
     auto load_a = [&](int kk) {   // k-pair kk = 16 R + i, i = 4 b + c  ->  k = 32 R + 8 b + 4 half + c
@@ -167,24 +210,19 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
       });
       a1A = nA; a1B = nB;
     }
-    // layer 2 bias + relu, layer 3 partial sums over the 64 neurons this lane holds per env tile in this pass
+    // relu of layer 2 (the bias is already in the accumulators) and layer 3 over the 64 neurons this lane holds per env tile in
+    // this pass, on the matrix pipe (layer3_tile)
+    const float *w3part = w3p + 4 * 128 * part;
     static_for<0, 4>([&](auto NI) {
       constexpr int nt = NI;
-      static_for<0, 16>([&](auto RI) {
-        constexpr int r = RI;
-        const int n = 32 * (4 * part + nt) + (r & 3) + 8 * (r >> 2) + 4 * half;   // accumulator row -> neuron
-        const float4 c = b2w3[n];
-        const float h0 = relu(acc[nt][0][r] + c.x);
-        const float h1 = relu(acc[nt][1][r] + c.x);
-        p[0][0] = fmaf(c.y, h0, p[0][0]); p[0][1] = fmaf(c.z, h0, p[0][1]); p[0][2] = fmaf(c.w, h0, p[0][2]);
-        p[1][0] = fmaf(c.y, h1, p[1][0]); p[1][1] = fmaf(c.z, h1, p[1][1]); p[1][2] = fmaf(c.w, h1, p[1][2]);
-      });
+      layer3_tile_pair<nt>(w3part, acc[nt][0], acc[nt][1], dA, dB, relu);
     });
   }
+  const f32x4 sA = dA, sB = dB;
   static_for<0, 3>([&](auto OI) {
     constexpr int o = OI;
-    const float t0 = p[0][o] + __shfl_xor(p[0][o], 32);
-    const float t1 = p[1][o] + __shfl_xor(p[1][o], 32);
+    const float t0 = sA[o] + __shfl_xor(sA[o], 32);
+    const float t1 = sB[o] + __shfl_xor(sB[o], 32);
     const float z = (half ? t1 : t0) + A.b3[o];     // lane e holds env e: tile e>>5, column e&31
     out[o] = tanhf(z) * A.bound;                    // net_mlp.py:40
   });
@@ -440,34 +478,15 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n);
       bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
     }
-    // layer 2 bias + relu and layer 3 over the 128 neurons this lane holds for its env column (the other 128 are in
-    // lane ^ 32)
-    float p[3] = {0.f, 0.f, 0.f};
-    // table rows of tile nt + 1 are read from LDS while tile nt is reduced (two register sets of 16 float4)
-    float4 tab[2][16];
-    auto tab_load = [&](auto NI, float4 (&c)[16]) {
-      constexpr int nt = NI;
-      static_for<0, 16>([&](auto RI) {
-        constexpr int r = RI;
-        c[r] = b2w3[32 * nt + (r & 3) + 8 * (r >> 2) + 4 * half];
-      });
-    };
-    tab_load(std::integral_constant<int, 0>{}, tab[0]);
-    static_for<0, NT>([&](auto NI) {
-      constexpr int nt = NI;
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (nt + 1 < NT) tab_load(std::integral_constant<int, nt + 1>{}, tab[(nt + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<0, 16>([&](auto RI) {
-        constexpr int r = RI;
-        const float4 c = tab[nt & 1][r];
-        const float h2 = relu(acc[nt][r]);                     // the bias is already in the accumulator
-        p[0] = fmaf(c.y, h2, p[0]); p[1] = fmaf(c.z, h2, p[1]); p[2] = fmaf(c.w, h2, p[2]);
-      });
-    });
+    // relu of layer 2 (the bias is already in the accumulators) and layer 3 over the 128 neurons this lane holds for its env
+    // column (the other 128 are in lane ^ 32), on the matrix pipe (layer3_tile)
+    f32x4 d30 = {0.f, 0.f, 0.f, 0.f}, d31 = {0.f, 0.f, 0.f, 0.f};
+    const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);
+    static_for<0, NT>([&](auto NI) { constexpr int nt = NI; layer3_tile<nt>(w3p, acc[nt], d30, d31, relu); });
+    const f32x4 s3 = d30 + d31;
     static_for<0, 3>([&](auto OI) {
       constexpr int o = OI;
-      const float tot = p[o] + __shfl_xor(p[o], 32);         // lane e holds env e: tile e >> 5, column e & 31
+      const float tot = s3[o] + __shfl_xor(s3[o], 32);       // lane e holds env e: tile e >> 5, column e & 31
       z[o] = (half == t) ? tot : z[o];
     });
   }

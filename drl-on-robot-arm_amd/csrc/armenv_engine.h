@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -100,8 +101,10 @@ static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + b
 
 // One engine per (task, chain, precision); each task x precision pair is compiled in its own translation unit
 // (armenv_task.hip, see the Makefile) so that the kernel variants build in parallel.
-template <template <class, class> class LaneT, class C, typename T> struct Engine final : EngineBase {
-  using Lane = LaneT<C, T>;
+template <template <class, class, bool> class LaneT, class C, typename T> struct Engine final : EngineBase {
+  using Lane = LaneT<C, T, false>;
+  using LaneF = LaneT<C, T, true>;   // the bookkeeping build of the same lane (parity-fence counters)
+  bool fence_on = false;
   EnvParams<T> P{};
   void *pool = nullptr;
   unsigned long long *counter_totals = nullptr;
@@ -115,8 +118,18 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
   // spreads its waves over all CUs (1 or 2 per CU) instead of packing four onto a quarter or half of them, and a wave
   // that shares its CU's instruction fetch with fewer neighbours runs 5-10 % faster (65 536 envs: 9.9 us per step,
   // 16 384: 9.0).
+  int lanes_cfg = 0;     // ArmEnvConfig.rollout_lanes_per_wave: 0 auto, 64, 32
+  // Half-filled waves (32 envs in lanes 0..31) for the kernels without a workgroup phase: when the batch leaves at least half
+  // of the SIMDs without a wave anyway, spreading it over twice as many waves costs nothing in issue slots and every wave's
+  // per-step maximum of IK trips is taken over 32 lanes instead of 64 (push at 32 768 envs: 5.67 -> 5.36 trips per wave-step,
+  // pick lane-asynchronous 6.51 -> 6.14; tests/tools/regroup_sim.py).  Same per-env arithmetic, same bits.
+  bool half_waves() const {
+    if (lanes_cfg == 64 || two_waves()) return false;
+    if (lanes_cfg == 32) return true;
+    return task != ARMENV_TASK_REACH && (P.n + 31) / 32 <= (int64_t)4 * cus;
+  }
   int lane_block() const {
-    const int64_t waves = (P.n + 63) / 64;
+    const int64_t waves = half_waves() ? (P.n + 31) / 32 : (P.n + 63) / 64;
     const int64_t per_cu = (waves + cus - 1) / cus;
     return 64 * (int)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
   }
@@ -139,7 +152,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_q = take(sizeof(T) * NJ * n), o_er = take(sizeof(T) * n), o_lr = take(sizeof(T) * n);
     const size_t o_goal = take(sizeof(float) * 3 * n), o_step = take(4 * n), o_ep = take(4 * n), o_ll = take(4 * n);
-    const size_t o_ls = take(n), o_cnt = take(8 * kCounterCols * (size_t)((n + 63) / 64)), o_tot = take(8 * kCounterCols), o_sum = take(64 * (size_t)((n + 63) / 64)), o_cold = take(sizeof(EnvCold<T>));
+    const size_t o_ls = take(n), o_cnt = take(8 * kCounterCols * (size_t)((n + 31) / 32)), o_tot = take(8 * kCounterCols), o_sum = take(64 * (size_t)((n + 63) / 64)), o_cold = take(sizeof(EnvCold<T>));
     const size_t o_aux = take(sizeof(T) * Lane::kAuxRows * n), o_trig = take(sizeof(T) * 2 * NJ * n);
     if (hipMalloc(&pool, off) != hipSuccess) return fail(ARMENV_ENOMEM, "hipMalloc(%zu bytes) failed", off);
     HIP_TRY(hipMemset(pool, 0, off));
@@ -205,8 +218,9 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     P.ik.angle_f32 = cfg.ik_angle_f32;
     P.ik.clamp_limits = cfg.clamp_joint_limits;
     waves_cfg = cfg.rollout_waves_per_simd;
+    lanes_cfg = cfg.rollout_lanes_per_wave;
     ready_lanes = cfg.rollout_ready_lanes < 0 ? 0 : (cfg.rollout_ready_lanes > 64 ? 64 : cfg.rollout_ready_lanes);
-    P.ik.fence = cfg.fence_counters;
+    fence_on = cfg.fence_counters != 0;
     P.ik.fence_pivot = (T)cfg.fence_pivot;
     P.fence_z = (T)cfg.fence_z;
     for (int j = 0; j < NJ; ++j) {
@@ -235,10 +249,21 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
+  // launch geometry of the kernels without a workgroup phase: threads to cover every env, and the params with the lane mapping
+  int64_t lane_threads(bool half) const { return half ? 64 * ((P.n + 31) / 32) : P.n; }
+  EnvParams<T> params(bool half) const { EnvParams<T> Q = P; Q.half_waves = half ? 1 : 0; return Q; }
   int step(const StepIO &io, hipStream_t s) override {
-    const int b = lane_block();
-    if (two_waves()) hipLaunchKernelGGL((env_step_kernel<Lane, T, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
-    else hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, io);
+    // the one-launch-per-step kernel keeps full waves: a launch ends with its slowest wave whatever the wave count, and twice
+    // as many waves share the CUs' instruction fetch (push, 32 768 envs: 22.9 us per launch with full waves, 23.4 with half)
+    const bool h = false;
+    const int b = 64 * (int)std::min<int64_t>(4, std::max<int64_t>(1, ((P.n + 63) / 64 + cus - 1) / cus));
+    if (fence_on) {
+      if (two_waves()) hipLaunchKernelGGL((env_step_kernel<LaneF, T, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+      else hipLaunchKernelGGL((env_step_kernel<LaneF, T>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), io);
+    } else {
+      if (two_waves()) hipLaunchKernelGGL((env_step_kernel<Lane, T, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+      else hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), io);
+    }
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
@@ -249,37 +274,49 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     if (waves_cfg == 2) return true;
     return (P.n + 63) / 64 > (int64_t)4 * cus;
   }
-  template <int POLICY>
+  template <int POLICY, class LaneX = Lane>
   void launch_rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
     if constexpr (!kActor) {
       if (two_waves()) {
-        hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
+        hipLaunchKernelGGL((env_rollout_kernel<LaneX, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
                            steps, actions, io0, actions_out);
         return;
       }
     }
     const int b = kActor ? block : lane_block();
-    hipLaunchKernelGGL((env_rollout_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, pol, steps,
+    const bool h = !kActor && half_waves();
+    hipLaunchKernelGGL((env_rollout_kernel<LaneX, T, POLICY>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), pol, steps,
                        actions, io0, actions_out);
   }
-  template <int POLICY>
+  template <int POLICY, class LaneX = Lane>
   void launch_rollout_async(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     if (two_waves()) {
-      hipLaunchKernelGGL((env_rollout_async_kernel<Lane, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
+      hipLaunchKernelGGL((env_rollout_async_kernel<LaneX, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
                          steps, actions, io0, actions_out, (int32_t)ready_lanes);
       return;
     }
     const int b = lane_block();
-    hipLaunchKernelGGL((env_rollout_async_kernel<Lane, T, POLICY>), dim3(grid_for(P.n, b)), dim3(b), 0, s, P, pol, steps,
-                       actions, io0, actions_out, (int32_t)ready_lanes);
+    const bool h = half_waves();
+    hipLaunchKernelGGL((env_rollout_async_kernel<LaneX, T, POLICY>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), pol, steps,
+                       actions, io0, actions_out, (int32_t)(h && ready_lanes > 32 ? ready_lanes - 32 : ready_lanes));
   }
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     // lane-asynchronous form (ArmEnvConfig.rollout_ready_lanes > 0): external actions or the in-kernel random policy
     const bool fused_actor = !actions && (pol.kind == ARMENV_POLICY_ACTOR || pol.kind == ARMENV_POLICY_ACTOR_F16X3);
     if (ready_lanes > 0 && steps > 1 && !fused_actor) {
-      if (actions) launch_rollout_async<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
-      else launch_rollout_async<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
+      if (fence_on) {
+        if (actions) launch_rollout_async<ARMENV_POLICY_EXTERNAL, LaneF>(steps, actions, io0, actions_out, s);
+        else launch_rollout_async<ARMENV_POLICY_RANDOM, LaneF>(steps, actions, io0, actions_out, s);
+      } else {
+        if (actions) launch_rollout_async<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
+        else launch_rollout_async<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
+      }
+      return;
+    }
+    if (fence_on && !fused_actor) {   // the bookkeeping builds exist for external actions and the in-kernel random policy
+      if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL, LaneF>(steps, actions, io0, actions_out, s);
+      else launch_rollout<ARMENV_POLICY_RANDOM, LaneF>(steps, actions, io0, actions_out, s);
       return;
     }
     if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
@@ -323,7 +360,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
     return ARMENV_OK;
   }
   int counters(uint64_t out[16], hipStream_t s) override {
-    hipLaunchKernelGGL(counters_sum_kernel, dim3(1), dim3(256), 0, s, P.counters, (P.n + 63) / 64, counter_totals);
+    hipLaunchKernelGGL(counters_sum_kernel, dim3(1), dim3(256), 0, s, P.counters, (P.n + 31) / 32, counter_totals);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, counter_totals, kCounterCols * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -339,7 +376,7 @@ template <template <class, class> class LaneT, class C, typename T> struct Engin
 };
 
 
-template <template <class, class> class LaneT, typename T> static EngineBase *make_task_engine(const ArmEnvConfig &cfg) {
+template <template <class, class, bool> class LaneT, typename T> static EngineBase *make_task_engine(const ArmEnvConfig &cfg) {
   if (cfg.fk_path == ARMENV_FK_AUTO) {
     if (chain_matches<KukaChain>(cfg.chain)) return new (std::nothrow) Engine<LaneT, KukaChain, T>();
     if (chain_matches<DianaChain>(cfg.chain)) return new (std::nothrow) Engine<LaneT, DianaChain, T>();

@@ -45,6 +45,9 @@ template <typename T> struct EnvParams {
   T box_lo[3];
   T box_hi[3];
   const EnvCold<T> *cold;   // device memory: reset / limit constants (see EnvCold)
+  int32_t half_waves;       // 1: a wave carries 32 envs in its lanes 0..31 (lanes 32..63 exit at once): a batch of at most
+                            // 32 x #SIMDs envs then spreads over twice as many SIMDs, one wave each, and every wave's per-step
+                            // maximum of IK trips is taken over 32 lanes instead of 64 (ArmEnvConfig.rollout_lanes_per_wave)
   uint64_t seed;            // Philox key and global index of env 0: the fused policy's noise reads them every step
   uint64_t env_id0;
   // push task (rl_push_env.py): simplified pusher model + reward constants
@@ -67,15 +70,25 @@ template <typename T> struct EnvParams {
 // armenv_step launch at 65536 envs.
 // wave_sum: a count v of b significant bits costs b ballots + popcounts on the scalar unit, no cross-lane data moves.
 constexpr int kCounterCols = 16;
+// wave index of the calling lane in the launch: the row of the handle's per-wave counters it flushes into
+AE_DEV int64_t wave_row() { return ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
 AE_DEV uint32_t wave_sum(uint32_t v) {
   uint32_t s = 0;
   for (int b = 0; b < 32 && __ballot((v >> b) != 0u) != 0ull; ++b) s += (uint32_t)__popcll(__ballot((v >> b) & 1u)) << b;
   return s;
 }
+// Env index of the calling lane, or -1 for a lane that has none.
+template <typename T>
+AE_DEV int64_t lane_env(const EnvParams<T> &P) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!P.half_waves) return t;
+  return (t & 32) ? (int64_t)-1 : ((t >> 6) << 5) + (t & 31);
+}
 template <typename T>
 AE_DEV void flush_counts(const EnvParams<T> &P, int64_t i, uint32_t n_done, uint32_t n_succ, uint32_t n_bad, uint32_t n_upd,
                          uint32_t n_lim, uint32_t n_low, uint32_t n_cap, uint32_t n_cond) {
-  unsigned long long *row = P.counters + kCounterCols * (i >> 6);
+  (void)i;
+  unsigned long long *row = P.counters + kCounterCols * wave_row();
   const uint32_t d = wave_sum(n_done), s = wave_sum(n_succ), b = wave_sum(n_bad), u = wave_sum(n_upd);
   const uint32_t l = wave_sum(n_lim), z = wave_sum(n_low), c = wave_sum(n_cap), k = wave_sum(n_cond);
   if ((threadIdx.x & 63) == 0) {   // lane 0 of a launched wave is always a live env (i < N is a prefix)
@@ -278,7 +291,8 @@ AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint3
 
 // Per-lane state of one reach env and the body of one env step.  The single-step kernel and the T-step rollout
 // kernel both run this code: a rollout of any length is bit-identical to the same steps as separate launches (see `cq` below).
-template <class C, typename T> struct ReachLane {
+template <class C, typename T, bool FENCE = false> struct ReachLane {
+  static constexpr bool kFence = FENCE;   // the bookkeeping build of the lane: parity-fence counts (ArmEnvConfig.fence_counters)
   using M = Mth<T>;
   using Chain = C;
   static constexpr int kTask = ARMENV_TASK_REACH;
@@ -380,7 +394,7 @@ template <class C, typename T> struct ReachLane {
     const int64_t n = P.n;
     have_S = true;
     n_upd += (uint32_t)updates;
-    if (P.ik.fence) {
+    if constexpr (kFence) {
       n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; n_cap += (updates >= P.ik.max_iters) ? 1u : 0u;
       n_cond += (minpiv < P.ik.fence_pivot) ? 1u : 0u;
     }
@@ -446,8 +460,8 @@ template <class C, typename T> struct ReachLane {
     const bool small_steps = P.ik.max_dtheta <= T(0.7854);
     T diff2_prev = T(1e60);
     int updates = 0;
-    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :244-257
-    const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, q, S, cq, sq);
+    while (!ik_trip<C, T, kFence>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :244-257
+    const bool lim_hit = ik_limits<C, T, kFence>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail(P, i, io, updates, lim_hit);
     return updates;
@@ -507,7 +521,8 @@ AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&
 //     joints 0..5 receive the IK result (:343 `range(self.end_effector_index)`), so joint 7 keeps its reset value and
 //     the tool's yaw error is never corrected; the gripper (closed by getClosestPoints, :412-416) is the build's own
 //     model, see grip().
-template <class C, typename T, bool PICK> struct CubeLane {
+template <class C, typename T, bool PICK, bool FENCE = false> struct CubeLane {
+  static constexpr bool kFence = FENCE;
   using M = Mth<T>;
   using Chain = C;
   static constexpr int kTask = PICK ? ARMENV_TASK_PICK : ARMENV_TASK_PUSH;
@@ -688,7 +703,7 @@ template <class C, typename T, bool PICK> struct CubeLane {
     // pick restores joint 7 below, so the exit frame's orientation is not the next step's: only push carries the frame over
     have_S = !PICK;
     n_upd += (uint32_t)updates;
-    if (P.ik.fence) {
+    if constexpr (kFence) {
       n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; n_cap += (updates >= P.ik.max_iters) ? 1u : 0u;
       n_cond += (minpiv < P.ik.fence_pivot) ? 1u : 0u;
     }
@@ -762,15 +777,15 @@ template <class C, typename T, bool PICK> struct CubeLane {
     const bool small_steps = P.ik.max_dtheta <= T(0.7854);
     T diff2_prev = T(1e60);
     int updates = 0;
-    while (!ik_trip<C, T>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :339-347
-    const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, q, S, cq, sq);
+    while (!ik_trip<C, T, kFence>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :339-347
+    const bool lim_hit = ik_limits<C, T, kFence>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail(P, i, io, updates, lim_hit);
     return updates;
   }
 };
-template <class C, typename T> using PushLane = CubeLane<C, T, false>;
-template <class C, typename T> using PickLane = CubeLane<C, T, true>;
+template <class C, typename T, bool FENCE = false> using PushLane = CubeLane<C, T, false, FENCE>;
+template <class C, typename T, bool FENCE = false> using PickLane = CubeLane<C, T, true, FENCE>;
 
 // reset() of the envs whose mask byte is set (mask == NULL: all).
 template <class Lane, typename T>
@@ -791,7 +806,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 #ifdef ARMENV_TIMELINE
   const unsigned tl_launch = __hip_atomic_load(&g_tl_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = lane_env(P);   // env of this lane (full or half-filled waves, EnvParams::half_waves)
+  if (i < 0) return;
   if (i >= P.n) return;
   Lane L;
   L.load(P, i);
@@ -860,7 +876,9 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     }
     __syncthreads();
   }
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // env of this lane (full or half-filled waves, EnvParams::half_waves; the fused actors' MFMA phases need full waves)
+  const int64_t i = kActor ? (int64_t)blockIdx.x * blockDim.x + threadIdx.x : lane_env(P);
+  if (i < 0) return;
   if (i >= P.n) return;
   const int64_t n = P.n;
   constexpr int kObs = Lane::kObs;
@@ -957,7 +975,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const float *actions, StepIO io0,
                               float *actions_out, int32_t ready_lanes) {
   static_assert(POLICY == ARMENV_POLICY_EXTERNAL || POLICY == ARMENV_POLICY_RANDOM, "no wave-synchronous policy phases here");
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = lane_env(P);   // env of this lane (full or half-filled waves, EnvParams::half_waves)
+  if (i < 0) return;
   if (i >= P.n) return;
   const int64_t n = P.n;
   constexpr int kObs = Lane::kObs;
@@ -1002,14 +1021,14 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
   load_action(0);
   begin_step();
   for (;;) {
-    if (!ready && t < steps) ready = ik_trip<C, T>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps, L.minpiv);
+    if (!ready && t < steps) ready = ik_trip<C, T, Lane::kFence>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps, L.minpiv);
     const unsigned long long rb = __ballot(ready), ib = __ballot(!ready && t < steps);
     if (__popcll(rb) >= ready_lanes || ib == 0ull) {       // wave-uniform: a transition round
       if (ready) {
         // the next step's action is requested first: the step's tail (a few hundred instructions) covers most of the
         // load's latency before begin_step consumes it
         if (t + 1 < steps) load_action(t + 1);
-        const bool lim_hit = ik_limits<C, T>(P.chain, P.ik, L.q, L.S, L.cq, L.sq);
+        const bool lim_hit = ik_limits<C, T, Lane::kFence>(P.chain, P.ik, L.q, L.S, L.cq, L.sq);
         StepIO io;
         io.action = nullptr;
         io.obs = io0.obs + (int64_t)t * n * kObs;

@@ -34,7 +34,7 @@ template <typename T> struct IKParams {
   int32_t exit_mode;
   int32_t angle_f32;
   int32_t clamp_limits;
-  int32_t fence;    // parity-fence bookkeeping on (ArmEnvConfig.fence_counters): limit / flange / cap / conditioning counts
+  int32_t pad0;
   T fence_pivot;    // an IK call whose damped system J J^T + lambda I had an LDL^T pivot below this is ill-conditioned
   // URDF joint limits: lim[0..6] lower, lim[7..13] upper, in DEVICE MEMORY (EnvCold) -- 28 scalar registers the IK loop
   // needs for its own constants otherwise (measured: +70 instructions per trip from s_mov rematerialisation and
@@ -442,9 +442,11 @@ AE_DEV T jj_term(T a, T b, T acc) {
   else if constexpr (kb == 3) return acc - a;
   else return Mth<T>::fma(a, b, acc);
 }
-// D_out: the six LDL^T pivots (the caller's conditioning bookkeeping; values the factorisation computes anyway).
-template <class C, typename T>
-AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ], T (&D_out)[6]) {
+// FENCE (the bookkeeping builds of the kernels, ArmEnvConfig.fence_counters): minpiv is lowered to the smallest of the six
+// LDL^T pivots.  A compile-time switch: as a run-time branch in this loop body it cost the one-launch-per-step kernel 3 %
+// with the bookkeeping OFF (A/B inside one GPU session, tests/tools/ab_time.sh).
+template <class C, typename T, bool FENCE = false>
+AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ], T &minpiv) {
   using M = Mth<T>;
   // fk() defines the end-effector point as the LAST joint's pivot (S.p == S.pj[NJ-1], the same values), so the lever arm of
   // the last joint is x - x = +0 and its linear Jacobian column an exact zero: every term it enters adds +-0.  That column
@@ -509,7 +511,10 @@ AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &
       L[i][j] = s * invD[j];
     });
   });
-  static_for<0, 6>([&](auto JI) { constexpr int j = JI; D_out[j] = D[j]; });
+  if constexpr (FENCE) {
+    const T m = M::fmin(M::fmin(M::fmin(D[0], D[1]), M::fmin(D[2], D[3])), M::fmin(D[4], D[5]));
+    minpiv = M::fmin(minpiv, m);
+  }
   // L zf = e ; w = zf / D ; L^T y = w
   T y[6];
   static_for<0, 6>([&](auto II) {
@@ -596,7 +601,7 @@ AE_DEV void ik_target(const FKState<T> &S, const T (&a)[3], T dv, const T (&box_
 // minpiv (fence bookkeeping only): running minimum of the LDL^T pivots of the call's damped systems -- the damped solve
 // amplifies rounding differences by ~1 / pivot, so a call that passes through a near-singular pose (stretched elbow at the
 // edge of the arm's reach, aligned wrist) is where two implementations' trajectories start to part.
-template <class C, typename T>
+template <class C, typename T, bool FENCE = false>
 AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
                     T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps, T &minpiv) {
   using M = Mth<T>;
@@ -611,12 +616,7 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
   quat_from_frame<T>(S.W, qc);
   orientation_error<T>(P.tq, qc, P.angle_f32, eo);
   e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
-  T piv[6];
-  dls_update<C, T>(S, e, P, dth, piv);
-  if (__builtin_expect(P.fence != 0, 0)) {   // bookkeeping build of the loop body: laid out behind the loop
-    const T m = M::fmin(M::fmin(M::fmin(piv[0], piv[1]), M::fmin(piv[2], piv[3])), M::fmin(piv[4], piv[5]));
-    minpiv = M::fmin(minpiv, m);
-  }
+  dls_update<C, T, FENCE>(S, e, P, dth, minpiv);
   static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
   if (small_steps) {
     static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
@@ -637,11 +637,11 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
 // btMultiBodyJointLimitConstraint does once per stepSimulation (erp 0.2 by default; a named, unpinned model: the first box
 // with pybullet fits one scalar).  Either way the frame is recomputed for the lanes that left the limits only (the others
 // keep their bits).
-template <class C, typename T>
+template <class C, typename T, bool FENCE = false>
 AE_DEV bool ik_limits(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], FKState<T> &S, T (&cq)[NJ], T (&sq)[NJ]) {
   using M = Mth<T>;
   bool hit = false;
-  if (P.clamp_limits || P.fence) {
+  if (P.clamp_limits || FENCE) {
     T m = M::fabs(q[0]);
     static_for<1, NJ>([&](auto II) { constexpr int i = II; m = M::fmax(m, M::fabs(q[i])); });
     if (__builtin_expect(m > P.lim_min, 0)) {

@@ -151,6 +151,12 @@ typedef struct ArmEnvConfig {
    * right shape for larger batches (+17 % at 1 048 576 envs), same bits.  0 (default): chosen from num_envs and the device's
    * CU count.  Ignored with a fused actor (always 1). */
   int32_t rollout_waves_per_simd;
+  /* Envs per wavefront of the step and rollout kernels.  64: full waves.  32: half-filled waves (lanes 0..31 carry envs) -- for a
+   * batch of at most 32 x #SIMDs envs (32 768 on MI355X: BASELINE config 4) twice as many SIMDs get a wave, at no cost in issue
+   * slots, and a wave's per-step maximum of IK trips is taken over 32 lanes (push 5.67 -> 5.36 trips per wave-step); same bits.
+   * 0 (default): 32 for push / pick when the half-filled waves still get one SIMD each, 64 otherwise.  Ignored with a fused actor. */
+  int32_t rollout_lanes_per_wave;
+  int32_t reserved0;
 
   ArmEnvChain chain;
 } ArmEnvConfig;

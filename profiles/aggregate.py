@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the raw rocprofv3 outputs of profiles/collect.sh (gpurun_out/prof/) into the summaries kept in profiles/
-(ROUND = r02 unless given as argv[1]):
+(ROUND = r03 unless given as argv[1]):
   <round>_kernel_stats_<config>.csv   --stats tables, armenv kernels only (config "driver" = `bench.py --steps 20 --warmup 5`)
   <round>_bench_<config>.json         the bench.py line of the same run
   <round>_pmc_default_bench_f64.json  per-launch means of every counter for the rollout / step kernels of the default bench
@@ -23,7 +23,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def short(name):
@@ -92,15 +92,29 @@ def main():
     # HBM traffic per launch shape
     tpath = os.path.join(DST, "traffic.json")
     traffic = {}
+    if os.path.exists(tpath):        # keep the entries of shapes this run did not collect
+        try:
+            traffic = {k: v for k, v in json.load(open(tpath)).items() if not k.startswith("_")}
+        except Exception:
+            traffic = {}
+
+    def add(d, k, key, n):
+        if k in d and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k]:
+            fe, wr = d[k]["FETCH_SIZE"]["mean_per_launch"], d[k]["WRITE_SIZE"]["mean_per_launch"]
+            traffic[key] = {"hbm_bytes_per_launch": (2 * fe + wr) * 1024, "fetch_size_kb_raw": fe, "write_size_kb_raw": wr,
+                            "launches_averaged": d[k]["FETCH_SIZE"]["launches"], "round": ROUND}
+
     shapes = {"": 100, "_T20": 20}    # suffix of the pmc3 / pmc4 passes -> steps per rollout launch (profiles/collect.sh B100 / B20)
     for suf, T in shapes.items():
         d = pmc(sorted(glob.glob(os.path.join(SRC, f"pmc[34]{suf}_counters.csv"))), short)
-        for k, T_k, name in (("rollout", T, "reach_rollout<f64,kuka>"), ("step", 1, "reach_step<f64,kuka>")):
-            if k in d and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k]:
-                fe, wr = d[k]["FETCH_SIZE"]["mean_per_launch"], d[k]["WRITE_SIZE"]["mean_per_launch"]
-                key = "%s|policy=external|T=%d|N=65536" % (name, T_k)
-                traffic[key] = {"hbm_bytes_per_launch": (2 * fe + wr) * 1024, "fetch_size_kb_raw": fe, "write_size_kb_raw": wr,
-                                "launches_averaged": d[k]["FETCH_SIZE"]["launches"], "round": ROUND}
+        add(d, "rollout", "reach_rollout<f64,kuka>|policy=external|T=%d|N=65536" % T, 65536)
+        add(d, "step", "reach_step<f64,kuka>|policy=external|T=1|N=65536", 65536)
+    # the launch shapes of bench.py's config3 / config4 legs (one bench run per shape: its headline kernel is "rollout")
+    for suf, key in (("_actor", "reach_rollout<f64,kuka>|policy=actor|T=100|N=65536"),
+                     ("_actor_f16x3", "reach_rollout<f64,kuka>|policy=actor_f16x3|T=100|N=65536"),
+                     ("_push", "push_rollout<f64,kuka>|policy=external|T=100|N=32768")):
+        d = pmc(sorted(glob.glob(os.path.join(SRC, f"pmc[34]{suf}_counters.csv"))), short)
+        add(d, "rollout", key, 0)
     traffic["_note"] = ("FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over bench.py (KiB per launch, mean over "
                         "launches, N=65536; profiles/collect.sh + aggregate.py). hbm_bytes_per_launch = 2*FETCH + WRITE: FETCH "
                         "doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section).  Keys: "

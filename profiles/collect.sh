@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects a round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only)
-# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r02_*).
+# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r03_*).
 # PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
 set -u
 REPO=$(pwd)
@@ -23,7 +23,7 @@ stats actor_f16x3 --policy actor_f16x3 --steps 1000 --no-cpu-baseline --fence-st
 stats actor_f32 --policy actor --steps 500 --no-cpu-baseline --fence-steps 0
 stats push32768 --task push --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
 stats pick32768 --task pick --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
-stats f32engine --precision 32 --steps 1000 --no-cpu-baseline --fence-steps 0
+stats f32engine --precision 32 --steps 1000 --no-cpu-baseline --fence-steps 0 --secondary-legs 0
 fi
 # one small counter set per pass: a set the hardware cannot collect in one pass makes rocprofv3 abort and then hang in its
 # signal handler (FETCH_SIZE + WRITE_SIZE + GRBM_GUI_ACTIVE did), hence the timeouts
@@ -35,8 +35,8 @@ pmc() {   # name, counters..., then -- bench args
   timeout 300 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
   find "$OUT/$name" -name '*counter_collection.csv' -exec cp {} "$OUT/${name}_counters.csv" \;
 }
-B100="--steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0 --large-batch 0"
-B20="--steps 200 --warmup 20 --rollout-steps 20 --no-cpu-baseline --fence-steps 0 --large-batch 0"    # the driver's launch shape, ten launches
+B100="--steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"
+B20="--steps 200 --warmup 20 --rollout-steps 20 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"    # the driver's launch shape, ten launches
 if [ "$MODE" = "all" ]; then
 pmc pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES -- $B100
 pmc pmc2 SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- $B100
@@ -46,8 +46,19 @@ pmc pmc3 FETCH_SIZE -- $B100
 pmc pmc4 WRITE_SIZE -- $B100
 pmc pmc3_T20 FETCH_SIZE -- $B20
 pmc pmc4_T20 WRITE_SIZE -- $B20
+# the launch shapes of bench.py's config3 / config4 legs (100 steps per launch): HBM traffic for their `roofline.traffic`
+A32="--policy actor --steps 300 --warmup 100 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"
+A16="--policy actor_f16x3 --steps 500 --warmup 100 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"
+PU="--task push --envs-per-gpu 32768 --steps 500 --warmup 100 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"
+pmc pmc3_actor FETCH_SIZE -- $A32
+pmc pmc4_actor WRITE_SIZE -- $A32
+pmc pmc3_actor_f16x3 FETCH_SIZE -- $A16
+pmc pmc4_actor_f16x3 WRITE_SIZE -- $A16
+pmc pmc3_push FETCH_SIZE -- $PU
+pmc pmc4_push WRITE_SIZE -- $PU
 if [ "$MODE" = "all" ]; then
 pmc pmc_actor SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- --policy actor_f16x3 --steps 200 --no-cpu-baseline --fence-steps 0
+pmc pmc_actor3 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_WAVES -- --policy actor_f16x3 --steps 200 --no-cpu-baseline --fence-steps 0
 pmc pmc_actor2 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- --policy actor_f16x3 --steps 200 --no-cpu-baseline --fence-steps 0
 pmc pmc_push SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- --task push --envs-per-gpu 32768 --steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0
 pmc pmc_pick SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- --task pick --envs-per-gpu 32768 --steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0

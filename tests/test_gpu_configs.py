@@ -32,8 +32,9 @@ def test_config0_single_env_td3_1000_steps(envs, O, kuka):
     opt.minimal_episodes episodes -- for 1 000 steps of the N=1 drop-in ``envs.RLReachEnv`` with the build's TD3 / Trajectory /
     TrajectoryStore counterparts.  Episodes are 101 steps long here (opt.max_steps_one_episode = 100) so that the training
     branch runs inside the 1 000 steps.  The N=1 trajectory is checked against the oracle fed the same actions: f32
-    observations to 1e-6, identical done / success, and the reward -- a Python float computed in f64, as the reference returns
-    it (/root/reference/envs/rl_reach_env.py:300-319) -- to 1e-12."""
+    observations to 1e-6, identical done / success; the reward -- a Python float computed in f64, as the reference returns it
+    (/root/reference/envs/rl_reach_env.py:300-319) -- equals the oracle's reward of the env's own joint state to 1e-12 and the
+    free-running oracle's to 2e-8."""
     from armenv import opt
     from armenv.replay import Trajectory, TrajectoryStore
     from armenv.td3 import TD3
@@ -50,7 +51,7 @@ def test_config0_single_env_td3_1000_steps(envs, O, kuka):
         cfg = O.default_config(); cfg.max_steps = 100
         st = O.ReachState(1)
         steps = episodes = updates = successes = 0
-        worst_obs = worst_rew = 0.0
+        worst_obs = worst_rew = worst_rew_state = 0.0
         w0 = agent.actor.fc1.weight.detach().clone()
         while steps < 1000:
             state = env.reset()                                                      # main.py:108
@@ -68,6 +69,13 @@ def test_config0_single_env_td3_1000_steps(envs, O, kuka):
                 assert done == bool(d_r[0]) and is_success == bool(s_r[0]), steps
                 worst_obs = max(worst_obs, float(np.abs(state - o_r[0]).max()))
                 worst_rew = max(worst_rew, abs(reward - float(r_r[0])))
+                # the reward arithmetic itself (:271-309) on the env's own f64 joint state: the oracle's FK and outcome, 1e-12
+                q_env = _np(env._eng.get_state()["q"])
+                p_or, _ = O.fk(kuka, q_env)
+                d_or = float(np.sqrt(np.sum((p_or[0] - state[3:].astype(np.float64)) ** 2)))
+                r_or, d_flag, s_flag = O.reach_outcome(cfg, d_or, env.step_counter)
+                assert d_flag == done and s_flag == is_success
+                worst_rew_state = max(worst_rew_state, abs(reward - r_or))
                 if is_success:
                     assert reward == 0 and done                                      # main.py:125 compares reward == 0
                     successes += 1
@@ -85,7 +93,9 @@ def test_config0_single_env_td3_1000_steps(envs, O, kuka):
                 assert bool(torch.isfinite(loss))
         assert store.size() == episodes >= 9 and updates >= 5 * opt.n_train
         assert worst_obs < 1e-6, worst_obs
-        assert worst_rew < 1e-12, worst_rew
+        assert worst_rew_state < 1e-12, worst_rew_state      # f64 all the way (an f32 reward buffer would show 1e-7 here); the N=1
+                                                             # classes use the generic FK path: the URDF's own rpy = 1.57079632679
+        assert worst_rew < 2e-8, worst_rew                    # free-running against the oracle's own trajectory (101-step episodes)
         assert not torch.equal(w0, agent.actor.fc1.weight.detach())                  # the delayed actor update ran
         env.close()
     finally:
@@ -108,7 +118,7 @@ def test_n1_cube_envs_return_the_f64_reward(envs, O, kuka, kind):
     st.aux[0, 6] = np.linalg.norm(state[3:6] - state[6:9])
     worst = 0.0
     moved = 0
-    d_last = float(np.linalg.norm(state[3:6] - state[6:9]))
+    d_last = float(np.linalg.norm(state[3:6] - state[6:9], axis=-1))     # np.linalg.norm(..., axis=-1) as the reference calls it (:388)
     for t in range(60):
         # steer the tool through the cube at table height so that the shaped reward is not just the idle -1
         eef, cube = state[:3].astype(np.float64), state[3:6]
@@ -120,7 +130,7 @@ def test_n1_cube_envs_return_the_f64_reward(envs, O, kuka, kind):
         assert done == bool(d_r[0])
         worst = max(worst, abs(float(reward) - float(r_r[0])))
         # the reference computes the reward from the observation it returns (:388-397): the same f64 expression, bit for bit
-        d_cur = float(np.linalg.norm(state[3:6] - state[6:9]))
+        d_cur = float(np.linalg.norm(state[3:6] - state[6:9], axis=-1))
         test = d_cur - d_last
         d_last = d_cur
         if not done:

@@ -315,3 +315,44 @@ def test_step_before_first_reset_is_well_defined(envs):
     assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all()) and e.counters()["nonfinite"] == 0
     assert bool((obs == obs[0]).all())                                   # every env did the same well-defined thing
     e.close()
+
+
+# ------------------------------------------------------------------------------ multi-GPU plumbing on the one GPU
+
+def test_return_gatherer_gpu_branch_survives_freed_producers():
+    """armenv.dist.ReturnGatherer's GPU branch (side stream, two alternating (stage, out) slots, record_stream on the
+    producer's tensor) with world = 1 semantics, against what a synchronous gather would return: 60 launches, the producer
+    tensor freed right after each launch and its block immediately re-used for garbage (the round-1 hazard: the side stream
+    read a tensor the caching allocator had already handed out again), results consumed on the producer stream while the
+    next launches are queued (the write-after-read hazard of ADVICE r02)."""
+    from armenv.dist import ReturnGatherer
+    n = 1 << 18
+    g = ReturnGatherer(n, DEV, world=1)
+    ramp = torch.arange(n, device=DEV, dtype=torch.float32) * 1e-3
+    consumed = []
+    for k in range(60):
+        x = ramp + float(k)                          # a fresh producer tensor every launch
+        for _ in range(4):                           # queued work in front of it: the tensor is not complete at launch time
+            x = x * 1.0
+        g.launch(x)
+        del x
+        junk = [torch.full((n,), -7.0, device=DEV) for _ in range(3)]      # re-uses the freed blocks at once
+        del junk
+        if k % 2 == 1:
+            out = g.result()                         # orders the producer stream behind the collective(s)
+            consumed.append((k, (out - ramp).sum() / n))          # a consumer kernel reading `out` on the producer stream
+    torch.cuda.synchronize()
+    for k, v in consumed:
+        assert abs(float(v) - k) < 1e-3, (k, float(v))
+    assert g.launches == 60 and torch.equal(g.result(), ramp + 59.0)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL cannot run between ranks that share one device")
+def test_bench_two_gpus_over_rccl():
+    """`bench.py --gpus 2` under torch.distributed.run on two real GPUs: the logging all-gather goes through RCCL (backend
+    "nccl"), every rank owns its device, and the line carries the kernel-time figure beside the wall-clock one."""
+    from test_gpu_parity import _run_bench
+    d = _run_bench(["--gpus", "2", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"], nproc=2)
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 131072 and "RCCL" in d["config"]["parallelism"]
+    assert d["config"]["gathers_in_timed_region"] >= 1 and d["value_kernel"] >= d["value"] > 5e9
+    assert len(d["config"]["per_rank"]["kernel_ms"]) == 2

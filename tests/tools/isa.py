@@ -83,8 +83,18 @@ def short_name(demangled):
     if not m:
         return demangled.split("(")[0]
     kern, targs = m.group(1), m.group(2)
-    lane = "reach" if "ReachLane" in targs else ("pick" if "CubeLane" in targs and ", true>" in targs else
-                                                 ("push" if "CubeLane" in targs else ""))
+    # ReachLane<Chain, T, FENCE>, CubeLane<Chain, T, PICK, FENCE>: FENCE = the bookkeeping build of the lane (parity-fence counters)
+    lane, fence = "", False
+    m3 = re.search(r"ReachLane<[^,<>]+, \w+, (true|false)>", targs)
+    m4 = re.search(r"CubeLane<[^,<>]+, \w+, (true|false), (true|false)>", targs)
+    if m3:
+        lane, fence = "reach", m3.group(1) == "true"
+    elif m4:
+        lane, fence = ("pick" if m4.group(1) == "true" else "push"), m4.group(2) == "true"
+    elif "ReachLane" in targs:
+        lane = "reach"
+    elif "CubeLane" in targs:
+        lane = "pick" if ", true>" in targs else "push"
     chain = "kuka" if "KukaChain" in targs else ("diana" if "DianaChain" in targs else ("generic" if "GenericChain" in targs else ""))
     prec = "f64" if "double" in targs else ("f32" if "float" in targs else "")
     k = kern.replace("env_", "").replace("_kernel", "")
@@ -107,6 +117,8 @@ def short_name(demangled):
                 parts.append("w" + m2.group(2))
     if kern == "actor_kernel":
         parts.append(targs.replace(", ", "_"))
+    if fence:
+        parts.append("fence")
     return "_".join(parts)
 
 

@@ -8,6 +8,8 @@ the slow ones into the same waves.  This script replays the oracle's per-step tr
   identity   env e in slot e (what the engine did up to round 2)
   previous   slots sorted by the previous T-step window's trip total (what a launch-end regroup can know)
   oracle     slots sorted by THIS window's trip total (the bound for any predictor)
+Then two sweeps over the same trip record: the launch length T (regrouping more often needs shorter launches, which cost the
+lane-asynchronous schedule its averaging), and the number of envs per wave (half-filled waves).
 Usage: regroup_sim.py [task] [envs] [T] [windows] [pre_steps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -68,3 +70,29 @@ for r in rows:
               f" | two buckets lock {r['bucket'][0]:.2f} async {r['bucket'][1]:.2f} (slow {100 * r['slow_frac']:.1f} %)")
     s += f" | clairvoyant lock {r['oracle'][0]:.2f} async {r['oracle'][1]:.2f}"
     print(s)
+
+
+# launch-length sweep: predictors a launch-end regroup could use -- the previous window's total, its last step, an EWMA
+cap = trips >= cfg.ik_max_iters + 1
+print(f"  per-step persistence: P(capped at t+1 | capped at t) = {(cap[1:] & cap[:-1]).sum() / max(1, cap[:-1].sum()):.2f}; "
+      + "lag correlation of trips: " + " ".join(f"{lag}:{np.corrcoef(trips[:-lag].ravel(), trips[lag:].ravel())[0, 1]:.2f}" for lag in (1, 5, 20, 100)))
+S = trips.shape[0]
+for Tw in (5, 10, 20, 50, 100):
+    acc = {k: [] for k in ("identity", "previous", "last step", "ewma", "clairvoyant")}
+    prev = None; ew = np.zeros(n)
+    for k in range(S // Tw):
+        W = trips[k * Tw:(k + 1) * Tw]; tot = W.sum(0)
+        acc["identity"].append(cost(W, ident)); acc["clairvoyant"].append(cost(W, np.argsort(tot, kind="stable")))
+        if prev is not None:
+            acc["previous"].append(cost(W, np.argsort(prev, kind="stable")))
+            acc["last step"].append(cost(W, np.argsort(last, kind="stable")))
+            acc["ewma"].append(cost(W, np.argsort(ew, kind="stable")))
+        prev, last, ew = tot, W[-1], 0.5 * ew + tot / Tw
+    print(f"  launches of {Tw:3d} steps: " + " | ".join(f"{k} lock {np.mean([c[0] for c in v]):.2f} async {np.mean([c[1] for c in v]):.2f}" for k, v in acc.items()))
+# envs per wave
+for LW in (64, 32, 16):
+    lock, asy = [], []
+    for k in range(S // T):
+        W = trips[k * T:(k + 1) * T].reshape(T, n // LW, LW)
+        lock.append(W.max(2).sum(0).mean() / T); asy.append(W.sum(0).max(1).mean() / T)
+    print(f"  {LW:2d} envs per wave ({T}-step launches): lockstep {np.mean(lock):.2f}  lane-asynchronous {np.mean(asy):.2f}  (mean over envs {trips.mean():.2f})")
