@@ -213,6 +213,8 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
                 uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, void *stream) {
   ENV_ENTER(env);
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_step: NULL output buffer");
+  if (ik_updates_dev && !env->cfg.fence_counters)
+    return fail(ARMENV_ESTATE, "armenv_step: ik_updates_dev needs a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
   StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev};
   if (!action_dev) {   // fused policy: a one-step rollout
     if (env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
@@ -316,6 +318,10 @@ int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_rollout: NULL output buffer");
   if (!actions_dev && env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
     return fail(ARMENV_ESTATE, "armenv_rollout: actions_dev is NULL and no fused policy is installed");
+  if (ik_updates_dev && !env->cfg.fence_counters)
+    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev needs a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
+  if (ik_updates_dev && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
+    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev is not available with a fused actor");
   StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev};
   return env->eng->rollout(steps, actions_dev, io, actions_out_dev, static_cast<hipStream_t>(stream));
 }

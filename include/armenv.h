@@ -195,7 +195,8 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
  * terminal_obs_dev (nullable, f32 [N][obs_dim]) receives the observation of this step before any
  * auto-reset; with auto_reset the obs of a finished env is its next episode's first observation.
  * ik_updates_dev (nullable, u8 [N]) receives the number of DLS updates the step's calculateInverseKinematics call
- * (:244-250) applied, saturated at 255: ik_max_iters means the call did not converge (the third parity-fence term). */
+ * (:244-250) applied, saturated at 255: ik_max_iters means the call did not converge (the cap term of the parity fence).
+ * Diagnostics: only on a handle created with fence_counters = 1 (ARMENV_ESTATE otherwise). */
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                 uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, void *stream);
 

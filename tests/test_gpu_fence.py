@@ -219,9 +219,12 @@ def test_cap_counter_and_update_counts_teacher_forced(envs, O, kuka):
     r.reset()
     r.step(torch.ones((m, 3), device=DEV), want_ik_updates=True)
     assert bool((r.ik_updates == 20).all()) and r.counters()["cap_steps"] == m
-    off = envs.BatchedReachEnv(m, device=DEV, seed=1, auto_reset=False, dv=1.0, box_hi=[2.0, 2.0, 2.0])    # counters off (default)
-    off.reset(); off.step(torch.ones((m, 3), device=DEV), want_ik_updates=True)
-    assert bool((off.ik_updates == 20).all()) and off.counters()["cap_steps"] == 0
+    off = envs.BatchedReachEnv(m, device=DEV, seed=1, auto_reset=False, dv=1.0, box_hi=[2.0, 2.0, 2.0])    # bookkeeping off (default)
+    off.reset(); off.step(torch.ones((m, 3), device=DEV))
+    assert off.counters()["cap_steps"] == 0 and off.counters()["ik_updates"] == 20 * m
+    from armenv import ArmEnvError
+    with pytest.raises(ArmEnvError):               # the per-step view belongs to the bookkeeping build of the kernels
+        off.step(torch.ones((m, 3), device=DEV), want_ik_updates=True)
     r.close(); off.close()
 
 

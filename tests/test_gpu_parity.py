@@ -1132,8 +1132,8 @@ def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka):
     n, T = 256, 80
     rng = np.random.default_rng(91)
     cfg = O.default_config("pick"); cfg.max_steps = 24
-    mk = lambda: envs.BatchedPickEnv(n, device=DEV, seed=12, max_steps=24)
-    e, r_env, e2 = mk(), mk(), mk()
+    mk = lambda **kw: envs.BatchedPickEnv(n, device=DEV, seed=12, max_steps=24, **kw)
+    e, r_env, e2 = mk(fence_counters=1), mk(), mk()      # e: the bookkeeping build (per-step IK update counts out)
     st = O.PickState(n)
     obs_r = O.pick_reset(kuka, cfg, st, seed=12)
     for x in (e, r_env, e2):

@@ -5,6 +5,7 @@
 // hipcc -O3 --offload-arch=gfx950 tests/tools/exp/mfma4x4_probe.hip -o /tmp/mfma4x4 && /tmp/mfma4x4
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ void k(float *out, unsigned long long *cyc) {
   const int l = threadIdx.x;
@@ -37,7 +38,7 @@ int main() {
   for (int l = 0; l < 64; ++l)
     for (int r = 0; r < 4; ++r) {
       const float want = (100.f + (4 * (l / 4) + r)) * (1.f + 0.001f * l);
-      if (h[4 * l + r] != want) { if (bad < 8) printf("lane %d reg %d: got %g want %g\n", l, r, h[4 * l + r], want); ++bad; }
+      if (fabsf(h[4 * l + r] - want) > 1e-4f * want) { if (bad < 8) printf("lane %d reg %d: got %g want %g\n", l, r, h[4 * l + r], want); ++bad; }
     }
   printf("layout %s; 256 v_mfma_f32_4x4x1_16b_f32 on four accumulators: %llu clock64 ticks (%.1f per instruction)\n", bad ? "DIFFERENT" : "as expected", hc, hc / 256.0);
   return bad != 0;
