@@ -646,8 +646,9 @@ def main():
             leg("large_batch", lambda: large_batch(Env, dev, args))
         # the other single-GPU BASELINE configs, timed by the same command (each on a fresh handle, after the headline)
         if world == 1 and args.secondary_legs and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
-            leg("config3_actor_f32", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor", args.precision, 2, 2))
-            leg("config3_actor_f16x3", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor_f16x3", args.precision, 2, 2))
+            # (four timed launches behind three untimed ones: the clocks settle for ~10 ms after the switch to the MFMA-heavy kernel)
+            leg("config3_actor_f32", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor", args.precision, 4, 3))
+            leg("config3_actor_f16x3", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor_f16x3", args.precision, 4, 3))
             leg("config4_push", lambda: secondary_leg(envs, dev, "push", 32768, "external", args.precision, 5, 6, args.fence_steps))
         if world == 1 and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline(args.precision))

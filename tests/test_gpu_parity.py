@@ -1957,13 +1957,15 @@ def test_bench_line_contract():
     for key, pol, peak in (("config3_actor_f32", "actor", 157.3), ("config3_actor_f16x3", "actor_f16x3", 2500.0)):
         c3 = d[key]
         assert "error" not in c3, c3
-        assert c3["envs"] == 65536 and c3["policy"] == pol and c3["steps"] == 200 and c3["value_kernel"] > 5e8
+        assert c3["envs"] == 65536 and c3["policy"] == pol and c3["steps"] == 400 and c3["value_kernel"] > 5e8
+        assert c3["roofline"]["traffic"] is not None and 0.9 < c3["roofline"]["traffic"] / c3["roofline"]["algo_bytes_per_launch"] < 1.2
         assert c3["roofline_mfma"]["peak"] == peak and 0.2 < c3["roofline_mfma"]["frac"] < 1.0
         assert c3["roofline"]["traffic_key"] == "reach_rollout<f64,kuka>|policy=%s|T=100|N=65536" % pol
     c4 = d["config4_push"]
     assert "error" not in c4, c4
     assert c4["envs"] == 32768 and c4["task"] == "push" and c4["value_kernel"] > 2.5e9 and c4["kernel"] == "push_rollout<f64,kuka>"
     assert c4["roofline"]["traffic_key"] == "push_rollout<f64,kuka>|policy=external|T=100|N=32768" and 0.1 < c4["roofline"]["valu"]["frac"] < 1.0
+    assert c4["roofline"]["traffic"] is not None and 0.9 < c4["roofline"]["traffic"] / c4["roofline"]["algo_bytes_per_launch"] < 1.2
     f4 = c4["parity_fence"]
     assert 0.05 < f4["limit_step_rate"] < 0.4 and 0.3 < f4["low_flange_step_rate"] < 0.7 and f4["cap_step_rate"] < 1e-3 and 1e-3 < f4["illcond_step_rate"] < 0.02
     assert d["step_api"]["value"] > 5e8
