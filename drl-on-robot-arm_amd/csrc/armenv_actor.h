@@ -230,64 +230,39 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
 
 // ------------------------------------------------------------------------------------------------------------------
 // The f16x3 actor is a WORKGROUP phase (four waves, 256 envs), same transposed decomposition as above:
-//   - two passes over the NEURON halves (tiles 4 part .. 4 part + 3), each with BOTH env column tiles of the wave: 128
-//     accumulators, and every W2 fragment is used exactly once per call -- W2 streams through LDS once per env step.  (Up to
-//     round 2 the passes were over the env tiles with all eight neuron tiles, and W2 streamed twice: an LDS-DMA piece costs
-//     100-185 cycles of issue inside a phase that also carries LDS reads (MI355X_MICROARCH.md), a wave issued 96 of them per
-//     env step, ~6 us of a 31 us step.)
-//   - layer 1 on the f16 MFMA as well (hi / lo split of W1aug and of [obs, 1], three passes): it is computed once per pass
-//     for both env tiles, i.e. twice per call, and as f32 MFMAs that would be 3.4 us of matrix-pipe time per step; as
-//     3 x v_mfma_f32_32x32x16_f16 per (row tile, env tile) it is 1.3 us.  Its accumulator layout is layer 2's B-operand layout
-//     up to a permutation of k inside each k-step, which the packing of W2H / W2L absorbs: only relu + the hi / lo split is VALU;
-//   - the A operands (W2 hi / lo fragments of one neuron half, 8 KB per k-step) reach the four waves through LDS, filled by
-//     direct-to-LDS loads (global_load_lds_dwordx4: 1 KB per wave instruction, scalar base + M0, no staging registers).
-// A "unit" is (neuron half, k-step): u = 16 part + ks, 32 units per call in program order.  LDS holds units 0..11 permanently
-// (96 KB, filled once per launch) and streams units 12..31 through a ring of four 8 KB slots (slot = (u - 12) mod 4; 20
-// streamed units per call, so the mapping carries over from call to call).  Protocol of unit u (the tail of a call refills
-// for the following one):
-//   head   s_waitcnt vmcnt(0) (own share of the refill issued one unit ago, which is unit u + 1's data)
+//   - one env column tile at a time with all eight neuron tiles (128 accumulators), so that nothing spills inside the
+//     k-loop (scratch traffic there would break the vmcnt accounting of the ring);
+//   - layer 1 on the f32 MFMA (W1aug . [obs, 1]); its accumulator layout is layer 2's B-operand layout up to a
+//     permutation of k inside each k-step, which the packing of W2H / W2L absorbs: only relu + the hi / lo split is VALU;
+//   - the A operands (W2 hi / lo fragments, 16 KB per k-step) reach the four waves through a ring in LDS that the waves
+//     fill cooperatively with direct-to-LDS loads (global_load_lds_dwordx4: 1 KB per wave instruction, scalar base + M0,
+//     no staging registers, no VALU).  Per-wave streaming of the same fragments from L2 left the matrix pipe waiting on
+//     memory: with one wave per SIMD nothing else hides a 1-2 us L2 round trip, and the registers to keep a dozen
+//     k-steps in flight do not exist.
+// Measured (65 536 envs): 37 us standalone, 49 us per fused env step; the MFMAs themselves take 17 us (20.7 ns each, the
+// rate of a constant-operand probe), LDS reads are hidden, fills + barriers cost 6 us, the rest is VALU that cannot
+// overlap the MFMAs of its own wave.
+// LDS holds k-steps 0..3 of W2 permanently (64 KB, filled once per launch) and streams k-steps 4..15 through a ring of
+// four 16 KB slots (slot = k-step mod 4; 12 streamed k-steps per pass, so the mapping carries over from pass to pass
+// and call to call).  Protocol of k-step ks (the tail of a call refills for the following one):
+//   head   s_waitcnt vmcnt(0) (own share of the refill issued one k-step ago, which is k-step ks + 1's data)
 //          -> s_barrier (everyone's share has landed)
-//   body   the 24 MFMAs of unit u (3 passes x 4 neuron tiles x 2 env tiles) from the register set read one unit ago, with
-//          everything else issued in their shadow: slots 1, 3 this wave's two pieces of the refill two stream positions ahead
-//          (unit u + 2's slot was last read during unit u - 3), slots 4..11 the LDS reads of unit u + 1 into the other
-//          register set, slots 8..23 the relu / split of layer 1's next row tile.
+//   body   the 24 MFMAs of k-step ks from the register set read one k-step ago, with everything else issued in their
+//          shadow: slots 1..7 the four quarters of the refill two stream positions ahead (k-step ks + 2's slot was last
+//          read during k-step ks - 3), slots 8..23 the LDS reads of k-step ks + 1 into the other register set and the
+//          relu / split of layer 1.
 // The loads are issued from inline asm so that hipcc's waitcnt insertion does not see them (it would drain the queue
 // with vmcnt(0) before every LDS read that might alias them); the waits above are therefore explicit.
-// Callers: actor_stage_w1h() with the other tables, actor_ring_init() once per kernel after computing `nw` (live waves of this
-// workgroup), actor_ring_drain() before the kernel ends (an LDS DMA must not outlive the workgroup's LDS allocation).  The
-// k-loop must stay free of compiler-generated VMEM (no spills): hipcc's own vmcnt arithmetic does not see the DMA loads.
-constexpr int ACTOR_UNITS = 32;        // (neuron half, k-step) units of W2 per call
-constexpr int ACTOR_URES = 12;         // units 0..11 stay resident in LDS for the whole launch
-constexpr int ACTOR_RING_SLOTS = 4;    // units 12..31 stream through four slots; (UNITS - URES) is a multiple of the slot count
-constexpr int ACTOR_UNIT_UINT4 = 8 * 64;   // 4 neuron tiles x (hi, lo) x 64 lanes x 16 B = 8 KB
-constexpr int ACTOR_RING_UINT4 = (ACTOR_URES + ACTOR_RING_SLOTS) * ACTOR_UNIT_UINT4;   // 128 KB
-// layer 1's f16 operand table, staged behind the f32 tables: [8 row tiles][hi | lo][64 lanes] half8 = 16 KB
-constexpr int ACTOR_W1H_FLOATS = 8 * 2 * 64 * 4;
-constexpr int ACTOR_W1_LDS_FLOATS_H = ACTOR_W1_LDS_FLOATS + ACTOR_W1H_FLOATS;
-// LDS region (in units) that holds unit u
-AE_DEV int actor_region(int u) { return u < ACTOR_URES ? u : ACTOR_URES + ((u - ACTOR_URES) & (ACTOR_RING_SLOTS - 1)); }
-// the streamed unit two stream positions after u (u >= URES): 12 -> 14, ..., 29 -> 31, 30 -> 12, 31 -> 13
-AE_DEV int actor_next2(int u) {
-  const int t = u - ACTOR_URES + 2;
-  return ACTOR_URES + (t >= ACTOR_UNITS - ACTOR_URES ? t - (ACTOR_UNITS - ACTOR_URES) : t);
-}
-// byte offset of unit u's first fragment (neuron tile 4 part, hi or lo) inside W2H / W2L ([16 ks][8 tiles][64 lanes] half8)
-AE_DEV unsigned actor_unit_src(int u) { return (unsigned)(((u & 15) * 8 + 4 * (u >> 4)) * 1024); }
-
-// W1aug = [W1 | b1 | 0...] split hi / lo in the A-operand order of v_mfma_f32_32x32x16_f16: lane l of row tile R holds
-// W1aug[32 R + (l & 31)][8 (l >> 5) + j], j = 0..7.  Every thread of the block calls this once (before the __syncthreads()
-// that follows actor_stage_w1); w1_lds must have ACTOR_W1_LDS_FLOATS_H floats.
-AE_DEV void actor_stage_w1h(const float *W1P, float4 *w1_lds, int in_dim) {
-  _Float16 *t = reinterpret_cast<_Float16 *>(w1_lds + ACTOR_W1_LDS_FLOATS / 4);
-  for (int i = threadIdx.x; i < 8 * 64 * 8; i += blockDim.x) {
-    const int j = i & 7, l = (i >> 3) & 63, R = i >> 9;
-    const int row = 32 * R + (l & 31), k = 8 * (l >> 5) + j;
-    const float x = k < in_dim ? W1P[row * 12 + k] : (k == in_dim ? W1P[row * 12 + 11] : 0.f);
-    const _Float16 hi = (_Float16)x;
-    t[((R * 2 + 0) * 64 + l) * 8 + j] = hi;
-    t[((R * 2 + 1) * 64 + l) * 8 + j] = (_Float16)(x - (float)hi);
-  }
-}
+// Callers: actor_ring_init() once per kernel after computing `nw` (live waves of this workgroup), actor_ring_drain()
+// before the kernel ends (an LDS DMA must not outlive the workgroup's LDS allocation).  The k-loop must stay free of
+// compiler-generated VMEM (no spills): hipcc's own vmcnt arithmetic does not see the DMA loads.
+constexpr int ACTOR_KRES = 4;          // k-steps 0..3 of W2 stay resident in LDS for the whole launch
+constexpr int ACTOR_RING_SLOTS = 4;    // k-steps 4..15 stream through four slots; (16 - KRES) is a multiple of the slot count
+constexpr int ACTOR_RING_UINT4 = (ACTOR_KRES + ACTOR_RING_SLOTS) * 16 * 64;   // 16 KB per k-step: 128 KB
+// LDS region (in k-step units) that holds k-step ks
+AE_DEV int actor_region(int ks) { return ks < ACTOR_KRES ? ks : ACTOR_KRES + (ks & (ACTOR_RING_SLOTS - 1)); }
+// the streamed k-step two stream positions after ks (ks >= KRES): 4 -> 6, ..., 13 -> 15, 14 -> 4, 15 -> 5
+AE_DEV int actor_next2(int ks) { const int t = ks - ACTOR_KRES + 2; return ACTOR_KRES + (t >= 16 - ACTOR_KRES ? t - (16 - ACTOR_KRES) : t); }
 
 // one 1 KB direct-to-LDS copy: lane l moves 16 bytes from src_base + voff (voff = 16 l) to LDS byte lds_dst + 16 l.
 // src_base and lds_dst are wave-uniform (SGPRs): a fill costs scalar adds only, no VALU.
@@ -311,46 +286,53 @@ AE_DEV uint64_t scalar_opaque(uint64_t v) {
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// fragment f = 2 (tile - 4 part) + (0 hi | 1 lo) of unit u -> LDS region of u; w2h / w2l: byte addresses of the packed W2 hi / lo
-AE_DEV void actor_ring_fill_one(uint64_t w2h, uint64_t w2l, uint4 *ring, int u, int f) {
+// fragment f = 2 tile + (0 hi | 1 lo) of k-step ks -> ring slot ks mod R; w2h / w2l: byte addresses of the packed W2 hi / lo
+AE_DEV void actor_ring_fill_one(uint64_t w2h, uint64_t w2l, uint4 *ring, int ks, int f) {
   const unsigned voff = (threadIdx.x & 63u) * 16u;
-  const unsigned base = (unsigned)(uintptr_t)ring + (unsigned)(actor_region(u) * ACTOR_UNIT_UINT4 * 16);
-  const uint64_t a = ((f & 1) ? w2l : w2h) + (uint64_t)(actor_unit_src(u) + (unsigned)((f >> 1) * 1024));
+  const unsigned base = (unsigned)(uintptr_t)ring + (unsigned)(actor_region(ks) * 16 * 64 * 16);
+  const uint64_t a = ((f & 1) ? w2l : w2h) + (uint64_t)(unsigned)((ks * 8 + (f >> 1)) * 64) * sizeof(half8);
   // wave-uniform by construction; readfirstlane tells the compiler so (the asm wants SGPR operands)
   const uint64_t au = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
   glds16(reinterpret_cast<const void *>(au), voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(base + (unsigned)(f * 1024))));
 }
-// the whole unit: wave w takes f = w, w + nw, ... (two each when all four waves of the workgroup are live)
-AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int u, int nw) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  for (int f = wave; f < 8; f += nw) actor_ring_fill_one((uint64_t)(uintptr_t)H.W2H, (uint64_t)(uintptr_t)H.W2L, ring, u, f);
+AE_DEV void actor_ring_fill_one(const ActorParamsH &H, uint4 *ring, int ks, int f) {
+  actor_ring_fill_one((uint64_t)(uintptr_t)H.W2H, (uint64_t)(uintptr_t)H.W2L, ring, ks, f);
 }
-AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // the resident units and the first two streamed
-  for (int u = 0; u < ACTOR_URES + 2; ++u) actor_ring_fill(H, ring, u, nw);
+// the whole k-step: wave w takes f = w, w + nw, ... (four each when all four waves of the workgroup are live)
+AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int ks, int nw) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (nw == 4) {
+    static_for<0, 4>([&](auto FI) { constexpr int fi = FI; actor_ring_fill_one(H, ring, ks, wave + 4 * fi); });
+  } else {
+    for (int f = wave; f < 16; f += nw) actor_ring_fill_one(H, ring, ks, f);
+  }
+}
+AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // the resident k-steps and the first two streamed
+  static_for<0, ACTOR_KRES + 2>([&](auto KI) { constexpr int k = KI; actor_ring_fill(H, ring, k, nw); });
 }
 AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int IN>
 AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, uint4 *ring, int nw,
                                    const float (&s)[IN], float (&out)[3]) {
-  static_assert(IN + 1 <= 16, "augmented input does not fit one f16 MFMA k-step");
+  static_assert(IN + 1 <= 2 * ACTOR_NK, "augmented input does not fit ACTOR_NK k-pairs");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5;
-  constexpr int NT = 4;   // neuron tiles per pass
+  constexpr int NT = 8;
+  const float *w1a = reinterpret_cast<const float *>(w1_lds) + lane;
   const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;
   const float4 *b2tab = b2w3 + ACTOR_HID;                  // b2 alone, four consecutive neurons per float4
-  const half8 *w1h = reinterpret_cast<const half8 *>(w1_lds + ACTOR_W1_LDS_FLOATS / 4) + lane;   // [8 R][hi | lo][64]
-  const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);          // layer3_tile_pair
-  // this wave's two fragments of a fill (f = wave + 4 fi): wave-uniform source bases and LDS destinations, once per call
+  float z[3] = {0.f, 0.f, 0.f};
+  // this wave's four fragments of a fill (f = wave + 4 fi): wave-uniform source bases and LDS destinations, once per call
   const unsigned voff16 = (threadIdx.x & 63u) * 16u;
-  uint64_t fill_src[2];
-  unsigned fill_dst[2];
+  uint64_t fill_src[4];
+  unsigned fill_dst[4];
   // bases for the ragged-workgroup refill inside the k-loop (nw < 4: the last workgroup of a batch that is not a multiple of 256)
   const uint64_t w2h_base = scalar_opaque((uint64_t)(uintptr_t)H.W2H), w2l_base = scalar_opaque((uint64_t)(uintptr_t)H.W2L);
   {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    static_for<0, 2>([&](auto FI) {
+    static_for<0, 4>([&](auto FI) {
       constexpr int fi = FI;
       const int f = wave + 4 * fi;
       const uint64_t a = (uint64_t)(uintptr_t)(((f & 1) ? H.W2L : H.W2H) + (f >> 1) * 64);
@@ -359,160 +341,156 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       fill_dst[fi] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)ring + (unsigned)(f * 1024)));
     });
   }
-  auto relu = [](float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); };   // one v_max_i32, see actor_forward_wave
-  // Layer-1 B operands, once per call: [obs, 1, 0...] of the env in column tile et, hi / lo, k = 8 half + j.
-  half8 oh[2], ol[2];
-  static_for<0, 2>([&](auto EI) {
-    constexpr int et = EI;
-    static_for<0, 8>([&](auto JI) {
-      constexpr int j = JI;
-      float v0 = 0.f, v1 = 0.f;   // k = j (half 0) and k = 8 + j (half 1)
-      if constexpr (j < IN) { const float other = __shfl_xor(s[j], 32); v0 = (half == et) ? s[j] : other; }
-      else if constexpr (j == IN) v0 = 1.f;
-      if constexpr (8 + j < IN) { const float other = __shfl_xor(s[8 + j], 32); v1 = (half == et) ? s[8 + j] : other; }
-      else if constexpr (8 + j == IN) v1 = 1.f;
-      const float v = half ? v1 : v0;
-      const _Float16 h = (_Float16)v;
-      oh[et][j] = h;
-      ol[et][j] = (_Float16)(v - (float)h);
-    });
-  });
-  auto layer1 = [&](int R, auto EI) {   // raw layer-1 sums of row tile R, env tile et: register i <-> neuron 32 R + 8 (i / 4) + 4 half + (i % 4)
-    constexpr int et = EI;
-    const half8 *w = w1h + (R < 8 ? R : 7) * 128;
-    const half8 wh = w[0], wl = w[64];
-    f32x16 a1;
-    static_for<0, 16>([&](auto RI) { constexpr int r = RI; a1[r] = 0.f; });
-    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, oh[et], a1, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ol[et], a1, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, oh[et], a1, 0, 0, 0);
-    return a1;
-  };
-  // relu + f16 hi / lo split of registers 8 u + 2 c, 8 u + 2 c + 1 of a1 -> halfs 2 c, 2 c + 1 of k-step u's B operand.
-  // K order inside a k-step: (half, j) <-> neuron 16 ks + 8 (j / 4) + 4 half + (j % 4); W2H / W2L are packed to match.
-  auto split2 = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2], half8 (&l)[2]) {
-    constexpr int u = UI, c = CI;
-    const float x0 = relu(a1[8 * u + 2 * c]), x1 = relu(a1[8 * u + 2 * c + 1]);
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    h[u][2 * c] = h0; h[u][2 * c + 1] = h1;
-    l[u][2 * c] = (_Float16)(x0 - (float)h0); l[u][2 * c + 1] = (_Float16)(x1 - (float)h1);
-  };
-  // the same in two halves that fit the shadow of one MFMA each: (A) relu + hi, (B) lo
-  float sx0 = 0.f, sx1 = 0.f;
-  auto split2a = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2]) {
-    constexpr int u = UI, c = CI;
-    sx0 = relu(a1[8 * u + 2 * c]); sx1 = relu(a1[8 * u + 2 * c + 1]);
-    h[u][2 * c] = (_Float16)sx0; h[u][2 * c + 1] = (_Float16)sx1;
-  };
-  auto split2b = [&](auto UI, auto CI, const half8 (&h)[2], half8 (&l)[2]) {
-    constexpr int u = UI, c = CI;
-    l[u][2 * c] = (_Float16)(sx0 - (float)h[u][2 * c]); l[u][2 * c + 1] = (_Float16)(sx1 - (float)h[u][2 * c + 1]);
-  };
-  f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};   // layer-3 sums of the env in column tile 0 / 1
   // everything this wave has in flight (ring slots from the previous call's tail or actor_ring_init, and whatever the
   // env step left behind) has landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // The two env column tiles of the wave (envs 0..31 and 32..63) are processed one after the other: 128 accumulator
+  // registers instead of 256 (the full set plus the operands does not fit without spills into the k-loop, and scratch
+  // traffic inside the loop would also break the vmcnt accounting of the ring).  W2 streams through the ring twice.
 #pragma unroll 1
-  for (int part = 0; part < 2; ++part) {
-    f32x16 acc[NT][2];   // start from the layer-2 bias: register r <-> neuron 32 (4 part + nt) + 8 (r / 4) + 4 half + (r % 4)
+  for (int t = 0; t < 2; ++t) {
+    // Layer 1 on the f32 MFMA: H1^T[32 R + row][env] = W1aug[32 R + row][:] . saug[:][env], saug = [obs, 1, 0..].  B operand
+    // of k-pair m: lane l holds saug[2 m + (l >> 5)] of env (l & 31) + 32 t.
+    float bv[ACTOR_NK];
+    {
+      float sv[2 * ACTOR_NK];
+      static_for<0, 2 * ACTOR_NK>([&](auto DI) {
+        constexpr int d = DI;
+        if constexpr (d < IN) {
+          const float other = __shfl_xor(s[d], 32);
+          sv[d] = (half == t) ? s[d] : other;
+        } else {
+          sv[d] = d == IN ? 1.f : 0.f;
+        }
+      });
+      static_for<0, ACTOR_NK>([&](auto MI) { constexpr int m = MI; bv[m] = half ? sv[2 * m + 1] : sv[2 * m]; });
+    }
+    auto layer1 = [&](int R) {   // raw layer-1 sums of row tile R: register i <-> neuron 32 R + 8 (i / 4) + 4 half + (i % 4)
+      f32x16 a1;
+      static_for<0, 16>([&](auto RI) { constexpr int r = RI; a1[r] = 0.f; });
+      const float *w = w1a + (R < 8 ? R : 7) * (ACTOR_NK * 64);
+      static_for<0, ACTOR_NK>([&](auto MI) {
+        constexpr int m = MI;
+        if constexpr (2 * m <= IN) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m * 64], bv[m], a1, 0, 0, 0);
+      });
+      return a1;
+    };
+    // relu + f16 hi / lo split of registers 8 u + 2 c, 8 u + 2 c + 1 of a1 -> halfs 2 c, 2 c + 1 of k-step u's B operand.
+    // K order inside a k-step: (half, j) <-> neuron 16 ks + 8 (j / 4) + 4 half + (j % 4); W2H / W2L are packed to match.
+    auto relu = [](float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); };   // one v_max_i32, see actor_forward_wave
+    auto split2 = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2], half8 (&l)[2]) {
+      constexpr int u = UI, c = CI;
+      const float x0 = relu(a1[8 * u + 2 * c]), x1 = relu(a1[8 * u + 2 * c + 1]);
+      const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+      h[u][2 * c] = h0; h[u][2 * c + 1] = h1;
+      l[u][2 * c] = (_Float16)(x0 - (float)h0); l[u][2 * c + 1] = (_Float16)(x1 - (float)h1);
+    };
+    // the same in two halves that fit the shadow of one MFMA each: (A) relu + hi, (B) lo
+    float sx0 = 0.f, sx1 = 0.f;
+    auto split2a = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2]) {
+      constexpr int u = UI, c = CI;
+      sx0 = relu(a1[8 * u + 2 * c]); sx1 = relu(a1[8 * u + 2 * c + 1]);
+      h[u][2 * c] = (_Float16)sx0; h[u][2 * c + 1] = (_Float16)sx1;
+    };
+    auto split2b = [&](auto UI, auto CI, const half8 (&h)[2], half8 (&l)[2]) {
+      constexpr int u = UI, c = CI;
+      l[u][2 * c] = (_Float16)(sx0 - (float)h[u][2 * c]); l[u][2 * c + 1] = (_Float16)(sx1 - (float)h[u][2 * c + 1]);
+    };
+    f32x16 acc[NT];   // start from the layer-2 bias: register r <-> neuron 32 nt + 8 (r / 4) + 4 half + (r % 4)
     static_for<0, NT>([&](auto NI) {
       constexpr int nt = NI;
       static_for<0, 4>([&](auto QI) {
         constexpr int q = QI;
-        const float4 b = b2tab[8 * (4 * part + nt) + 2 * q + half];
-        acc[nt][0][4 * q] = b.x; acc[nt][0][4 * q + 1] = b.y; acc[nt][0][4 * q + 2] = b.z; acc[nt][0][4 * q + 3] = b.w;
-        acc[nt][1][4 * q] = b.x; acc[nt][1][4 * q + 1] = b.y; acc[nt][1][4 * q + 2] = b.z; acc[nt][1][4 * q + 3] = b.w;
+        const float4 b = b2tab[8 * nt + 2 * q + half];
+        acc[nt][4 * q] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
       });
     });
-    half8 bh[2][2], bl[2][2], bh_n[2][2], bl_n[2][2];   // [env tile][k-step of the row tile]
-    static_for<0, 2>([&](auto EI) {
-      constexpr int et = EI;
-      const f32x16 a1 = layer1(0, EI);
-      static_for<0, 2>([&](auto UI) { static_for<0, 4>([&](auto CI) { split2(a1, UI, CI, bh[et], bl[et]); }); });
-    });
-    f32x16 a1n[2] = {};
-    // One unit.  Head: make unit u + 1 visible (own share landed, then everyone's).  Body: the 24 MFMAs of unit u from
-    // (ch, cl), read one unit ago, each followed by one slice of the other work so that it issues while the matrix pipe is
-    // busy (an MFMA holds the pipe for 8 issue slots and the wave issues in order: work placed behind a block of MFMAs waits
-    // for all of them).
-    auto kstep = [&](auto ODD, int u, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT]) {
-      constexpr int uo = ODD;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of the fill issued one unit ago (unit u + 1)
+    half8 bh[2], bl[2], bh_n[2], bl_n[2];
+    {
+      const f32x16 a1 = layer1(0);
+      static_for<0, 2>([&](auto UI) { static_for<0, 4>([&](auto CI) { split2(a1, UI, CI, bh, bl); }); });
+    }
+    // One k-step.  Head: make k-step ks + 1 visible (own share landed, then everyone's).  Body: the 24 MFMAs of k-step
+    // ks from (ch, cl), read one k-step ago, each followed by one slice of the other work so that it issues while the
+    // matrix pipe is busy (an MFMA holds the pipe for 8 issue slots and the wave issues in order: work placed behind a
+    // block of MFMAs waits for all of them):
+    //   slots 1..7    every other slot one quarter of the ring refill (scalar address arithmetic + one LDS DMA),
+    //   slots 8..23   one LDS read each of k-step ks + 1's fragments into (nh, nl) and, on odd k-steps, half of the
+    //                 relu + hi / lo split of a pair of layer-1 values of the next row tile.
+    auto kstep = [&](auto ODD, int ks, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT],
+                     const f32x16 &a1n) {
+      constexpr int u = ODD;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of the fill issued one k-step ago (k-step ks + 1)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const half8 *slot = reinterpret_cast<const half8 *>(ring) + actor_region((u + 1) & (ACTOR_UNITS - 1)) * ACTOR_UNIT_UINT4 + lane;
-      const bool streamed = u >= ACTOR_URES;            // resident units consume no ring slot: nothing to refill
-      const int kf = actor_next2(streamed ? u : ACTOR_URES);
-      static_for<0, 3 * NT * 2>([&](auto MI) {
+      const half8 *slot = reinterpret_cast<const half8 *>(ring) + actor_region((ks + 1) & 15) * 16 * 64 + lane;
+      const bool streamed = ks >= ACTOR_KRES;            // resident k-steps consume no ring slot: nothing to refill
+      const int kf = actor_next2(streamed ? ks : ACTOR_KRES);
+      static_for<0, 3 * NT>([&](auto MI) {
         constexpr int m = MI;
         // order: pass (hi*hi, hi*lo, lo*hi) outermost, so consecutive MFMAs never share an accumulator
-        constexpr int k3 = m / (2 * NT), nt = (m % (2 * NT)) / 2, et = m % 2;
+        constexpr int k3 = m / NT, nt = m % NT;
         __builtin_amdgcn_sched_barrier(0);
-        acc[nt][et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? cl[nt] : ch[nt], k3 == 1 ? bl[et][uo] : bh[et][uo], acc[nt][et], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? cl[nt] : ch[nt], k3 == 1 ? bl[u] : bh[u], acc[nt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // slots 1, 3: this wave's two pieces of the refill two stream positions ahead (early, so that it has most of a unit
-        // to land before the head of the next one waits for it)
-        if constexpr (m == 1 || m == 3) {
+        // slots 1, 3, 5, 7: one quarter each of the refill two stream positions ahead (early, so that it has most of a
+        // k-step to land before the head of the next one waits for it)
+        if constexpr (m < 8 && m % 2 == 1) {
           constexpr int fi = m / 2;
           if (streamed) {
             if (nw == 4)
-              glds16(reinterpret_cast<const void *>(fill_src[fi] + (uint64_t)actor_unit_src(kf)), voff16,
-                     fill_dst[fi] + (unsigned)actor_region(kf) * (unsigned)(ACTOR_UNIT_UINT4 * 16));
+              glds16(reinterpret_cast<const void *>(fill_src[fi] + (uint64_t)(unsigned)kf * (8u * 64u * 16u)), voff16,
+                     fill_dst[fi] + (unsigned)actor_region(kf) * (16u * 64u * 16u));
             else if (m == 1) {
               const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-              for (int f = wave; f < 8; f += nw) actor_ring_fill_one(w2h_base, w2l_base, ring, kf, f);
+              for (int f = wave; f < 16; f += nw) actor_ring_fill_one(w2h_base, w2l_base, ring, kf, f);
             }
           }
         }
-        // slots 4..11: one LDS read each of unit u + 1's fragments (f = 2 nt + (0 hi | 1 lo))
-        if constexpr (m >= 4 && m < 12) {
-          constexpr int r = m - 4;
+        // slots 8..23: one LDS read each of k-step ks + 1's fragments; odd k-steps: half of the relu / split of a pair
+        if constexpr (m >= 8) {
+          constexpr int r = m - 8;
           if constexpr (r % 2 == 0) nh[r / 2] = slot[r * 64];
           else nl[r / 2] = slot[r * 64];
-        }
-        // slots 8..23: half of the relu / split of one pair of layer-1 values of the next row tile; the 16 pairs (env tile,
-        // k-step, c) take both units of the row tile
-        if constexpr (m >= 8) {
-          constexpr int item = (m - 8) + 16 * uo, pair = item / 2;
-          constexpr int pe = pair / 8, pu = (pair / 4) % 2, pc = pair % 4;
-          if constexpr (item % 2 == 0) split2a(a1n[pe], std::integral_constant<int, pu>{}, std::integral_constant<int, pc>{}, bh_n[pe]);
-          else split2b(std::integral_constant<int, pu>{}, std::integral_constant<int, pc>{}, bh_n[pe], bl_n[pe]);
+          if constexpr (u == 1) {
+            if constexpr (r % 2 == 0) split2a(a1n, std::integral_constant<int, (r / 2) / 4>{}, std::integral_constant<int, (r / 2) % 4>{}, bh_n);
+            else split2b(std::integral_constant<int, (r / 2) / 4>{}, std::integral_constant<int, (r / 2) % 4>{}, bh_n, bl_n);
+          }
         }
       });
       __builtin_amdgcn_sched_barrier(0);
     };
-    half8 ah0[NT], al0[NT], ah1[NT], al1[NT];   // A fragments of even / odd units
-    // Unit 16 part of this pass.  First pass: every wave's share of unit 0 has landed after the vmcnt(0) above and this
-    // barrier; second pass: unit 16 was made visible by the head of unit 15 (its own read there is dropped so that no A
-    // fragments stay live across the pass epilogue).
-    if (part == 0) __builtin_amdgcn_s_barrier();
+    half8 ah0[NT], al0[NT], ah1[NT], al1[NT];   // A fragments of even / odd k-steps
+    // k-step 0 of this pass.  First pass: every wave's share of it has landed after the vmcnt(0) above and this barrier;
+    // second pass: it was made visible by the last k-step of the first pass (its own read there is dropped so that no
+    // A fragments stay live across the pass epilogue).
+    if (t == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
-      const half8 *slot = reinterpret_cast<const half8 *>(ring) + actor_region(16 * part) * ACTOR_UNIT_UINT4 + lane;
+      const half8 *slot = reinterpret_cast<const half8 *>(ring) + lane;        // k-step 0: region 0
       static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah0[nt] = slot[(2 * nt) * 64]; al0[nt] = slot[(2 * nt + 1) * 64]; });
     }
+    f32x16 a1n = {};
 #pragma unroll 1
     for (int R = 0; R < 8; ++R) {
-      // layer 1 of row tile R + 1, both env tiles, goes into the matrix pipe ahead of this row tile's 48 MFMAs; its relu /
-      // split is sliced into their shadows (slots 8..23 of both units)
-      a1n[0] = layer1(R + 1, std::integral_constant<int, 0>{});
-      a1n[1] = layer1(R + 1, std::integral_constant<int, 1>{});
-      kstep(std::integral_constant<int, 0>{}, 16 * part + 2 * R, ah0, al0, ah1, al1);
-      kstep(std::integral_constant<int, 1>{}, 16 * part + 2 * R + 1, ah1, al1, ah0, al0);
-      static_for<0, 2>([&](auto EI) { constexpr int et = EI; bh[et][0] = bh_n[et][0]; bh[et][1] = bh_n[et][1]; bl[et][0] = bl_n[et][0]; bl[et][1] = bl_n[et][1]; });
+      kstep(std::integral_constant<int, 0>{}, 2 * R, ah0, al0, ah1, al1, a1n);
+      a1n = layer1(R + 1);     // layer 1 of row tile R + 1 goes into the matrix pipe behind the 24 MFMAs
+      kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n);
+      bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
     }
-    // relu of layer 2 (the bias is already in the accumulators) and layer 3 over the 64 neurons this lane holds per env tile
-    // in this pass, on the matrix pipe (layer3_tile_pair; the other 64 + 128 are in the other pass and in lane ^ 32)
-    const float *w3part = w3p + 4 * 128 * part;
-    static_for<0, NT>([&](auto NI) { constexpr int nt = NI; layer3_tile_pair<nt>(w3part, acc[nt][0], acc[nt][1], dA, dB, relu); });
+    // relu of layer 2 (the bias is already in the accumulators) and layer 3 over the 128 neurons this lane holds for its env
+    // column (the other 128 are in lane ^ 32), on the matrix pipe (layer3_tile)
+    f32x4 d30 = {0.f, 0.f, 0.f, 0.f}, d31 = {0.f, 0.f, 0.f, 0.f};
+    const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);
+    static_for<0, NT>([&](auto NI) { constexpr int nt = NI; layer3_tile<nt>(w3p, acc[nt], d30, d31, relu); });
+    const f32x4 s3 = d30 + d31;
+    static_for<0, 3>([&](auto OI) {
+      constexpr int o = OI;
+      const float tot = s3[o] + __shfl_xor(s3[o], 32);       // lane e holds env e: tile e >> 5, column e & 31
+      z[o] = (half == t) ? tot : z[o];
+    });
   }
-  static_for<0, 3>([&](auto OI) {
-    constexpr int o = OI;
-    const float t0 = dA[o] + __shfl_xor(dA[o], 32);
-    const float t1 = dB[o] + __shfl_xor(dB[o], 32);
-    const float z = (half ? t1 : t0) + A.b3[o];     // lane e holds env e: tile e >> 5, column e & 31
-    out[o] = tanhf(z) * A.bound;                    // net_mlp.py:40
-  });
+  static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
 }
 
 }  // namespace armenv

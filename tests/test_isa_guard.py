@@ -124,10 +124,7 @@ def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
     assert len(sel) == 18 + 2             # the fused-actor rollout of every (task, precision, chain) + the two standalone actors
     for sn, md, ins in sel:
         m = [k for k, i in enumerate(ins) if i.mnem == "v_mfma_f32_32x32x16_f16"]
-        # layer 1 of the first row tile ahead of the loop (2 env tiles x 3 passes), then the loop body: layer 1 of the next row
-        # tile (6) and two unrolled units of 24
-        assert len(m) == 6 + 6 + 48, (sn, len(m))
-        m = m[6:]                                                # the loop body: from its first MFMA to its last
+        assert len(m) == 48, (sn, len(m))                        # two unrolled k-steps of 24
         body = ins[m[0]:m[-1] + 1]
         mem = [i for i in body if isa.classify(i.mnem) == "vmem"]
         assert mem and all(i.mnem == "global_load_lds_dwordx4" for i in mem), (sn, sorted({i.mnem for i in mem}))
