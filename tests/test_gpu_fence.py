@@ -359,3 +359,41 @@ def test_bench_two_gpus_over_rccl():
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 131072 and "RCCL" in d["config"]["parallelism"]
     assert d["config"]["gathers_in_timed_region"] >= 1 and d["value_kernel"] >= d["value"] > 5e9
     assert len(d["config"]["per_rank"]["kernel_ms"]) == 2
+
+
+@pytest.mark.parametrize("task", ["reach", "push", "pick"])
+def test_half_filled_waves_equal_full_waves(envs, task):
+    """ArmEnvConfig.rollout_lanes_per_wave: 32 envs per wavefront (lanes 32..63 idle; the default for push / pick rollouts of at
+    most 32 x #SIMDs envs) against full wavefronts: the same bits -- outputs, final state, every counter incl. the four fence
+    terms -- on a ragged batch (not a multiple of 32), with external actions and the in-kernel random policy, lockstep and
+    lane-asynchronous, across in-place resets (20-step episodes) and a second launch."""
+    n, T = 2048 + 32 + 7, 45
+    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv, pick=envs.BatchedPickEnv)[task]
+    rng = np.random.default_rng(5)
+    sig = 0.686 if task == "reach" else 0.392
+    acts = torch.from_numpy((rng.standard_normal((T, n, 3)) * sig).clip(-0.7, 0.7).astype(np.float32)).to(DEV)
+    for policy in ("external", "random"):
+        for ready in (0, 62):
+            ref = None
+            for lanes in (64, 32, 0):
+                e = Env(n, device=DEV, seed=17, max_steps=20, rollout_lanes_per_wave=lanes, rollout_ready_lanes=ready, fence_counters=1)
+                if policy == "random":
+                    e.set_policy("random", noise_sigma=sig, noise_clip=0.7)
+                e.reset()
+                out = e.rollout(T, acts if policy == "external" else None, want_actions=True, want_terminal_obs=True, want_ik_updates=True)
+                got = {k: out[k].clone() for k in ("obs", "reward", "done", "success", "actions", "terminal_obs", "ik_updates")}
+                out2 = e.rollout(9, acts[:9].contiguous() if policy == "external" else None)
+                got.update(obs2=out2["obs"].clone(), done2=out2["done"].clone())
+                got.update({"st_" + k: v.clone() for k, v in e.get_state().items()})
+                cnt = e.counters()
+                e.close()
+                if ref is None:
+                    ref, ref_cnt = got, cnt
+                    assert cnt["episodes"] >= 2 * n and cnt["env_steps"] == n * (T + 9)
+                else:
+                    for k in ref:
+                        assert torch.equal(ref[k], got[k]), (task, policy, ready, lanes, k)
+                    assert cnt == ref_cnt, (task, policy, ready, lanes)
+    from armenv import ArmEnvError
+    with pytest.raises(ArmEnvError):
+        Env(64, device=DEV, rollout_lanes_per_wave=16)
