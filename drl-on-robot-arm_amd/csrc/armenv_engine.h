@@ -299,7 +299,7 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
     const int b = lane_block();
     const bool h = half_waves();
     hipLaunchKernelGGL((env_rollout_async_kernel<LaneX, T, POLICY>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), pol, steps,
-                       actions, io0, actions_out, (int32_t)(h && ready_lanes > 32 ? ready_lanes - 32 : ready_lanes));
+                       actions, io0, actions_out, (int32_t)(h ? (ready_lanes + 1) / 2 : ready_lanes));   // half-filled waves: the same share of the live lanes (pick: 62 of 64 -> 31 of 32, measured best: 21.7 us vs 22.3 at 30)
   }
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     // lane-asynchronous form (ArmEnvConfig.rollout_ready_lanes > 0): external actions or the in-kernel random policy
