@@ -14,7 +14,10 @@ MI355X ramps for ~30 ms, tests/tools/clock_ramp.py).  Two launch shapes run the 
                  per-step outputs written to [R][N][...] buffers (the trajectory of R armenv_step calls);
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
                  beside the headline and reported under "step_api".
-Rank 0 prints ONE JSON line.
+Timing: W untimed steps, then barrier + synchronise, the clock, EXACTLY K steps, stream-synchronise, the clock; the closing
+barrier follows.  `value` = all ranks' env-steps / MAX over ranks of that wall time; `value_kernel` = the same steps / MAX over
+ranks of the kernels' own time (HIP events on the launch stream).  Rank 0 prints ONE JSON line; besides the headline it carries
+short legs for the other single-GPU BASELINE configs (config3_actor_f32, config3_actor_f16x3, config4_push).
 The CPU oracle is timed beside it (rank 0, N=1 only) on a bounded sample -- one thread, then every core the process may
 use -- as a baseline, never as the thing measured.  A short extra leg on a second handle with the parity-fence counters on
 reports how often the workload crosses the URDF joint limits / drives the flange below z = 0.05 (where Bullet's
@@ -506,20 +509,20 @@ def main():
             do_gather()              # host work under the running kernels; its device work is behind ev1 / on the side stream
         ev1.synchronize()            # spin on the event: the K steps are done when it returns
         td = p()
-        # The contract's closing bracket: device work of the K steps finished on this rank, then the barrier.  The logging
-        # all-gather runs on a side stream and is NOT part of the K steps: it is waited for after the clock stops and its
-        # latency reported separately (`gather_us`); a device-wide synchronize here would put it back on the critical path.
+        # The contract's closing bracket: device work of the K steps finished on this rank (clock stops), then the barrier.  The
+        # logging all-gather runs on a side stream and is NOT part of the K steps: it is waited for after the clock stops and its
+        # latency reported separately; a device-wide synchronize here would put it back on the critical path.
         cur.synchronize()
+        wall = p() - t0              # this rank's K steps, synchronise to synchronise; the job's time is the MAX over ranks
         te = p()
         if world > 1:
-            dist.barrier()
-        wall = p() - t0
-        tg = p()
+            dist.barrier()           # closes the bracket; every rank started behind the opening barrier, so max-over-ranks of the
+        tg = p()                     # local walls IS the whole job's time and the barrier's own latency (host_us.barrier) is not work
         if world > 1:
             gather.result()
         torch.cuda.synchronize(dev)
         host_us.update(event0_record=(ta - t0) * 1e6, enqueue=(tb - ta) * 1e6, event1_record=(tc - tb) * 1e6,
-                       wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, barrier=(t0 + wall - te) * 1e6,
+                       wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, barrier=(tg - te) * 1e6,
                        gather_wait_after_clock=(p() - tg) * 1e6)
         c1 = env.counters()
         return wall, ev0.elapsed_time(ev1), launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}

@@ -1,8 +1,8 @@
 """BASELINE.json configs[0] plumbing: the reference's single-env loop (main.py:100-128, take_action -> noise -> step ->
 store_step) on the N=1 drop-in class with the build's TD3 counterpart, 1000 steps.  Prints steps/s (one host sync per
 env call: a compatibility path, not a throughput path)."""
-import sys, time, random
-sys.path.insert(0, '/root/repo/drl-on-robot-arm_amd')
+import os, sys, time, random
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "drl-on-robot-arm_amd"))
 import numpy as np, torch
 from armenv import envs, opt
 from armenv.td3 import TD3
