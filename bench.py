@@ -83,6 +83,68 @@ STATE_BYTES = {64: 2 * (56 + 112 + 8) + 12 + 2 * 4, 32: 2 * (28 + 56 + 4) + 12 +
 FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + residual + per-step sincos/reward
 
 
+class HipEvents:
+    """Two HIP timing events driven straight through the HIP runtime torch has loaded (ctypes): hipEventRecord costs ~1 us this
+    way and 5-9 us through torch.cuda.Event.record(), and the first record of the timed region sits between the clock's start
+    and the launch.  Recorded on the stream the kernels are launched on; falls back to torch events if the runtime cannot be
+    found."""
+
+    def __init__(self, dev):
+        import ctypes as C
+        self.C, self.h, self.ev = C, None, None
+        self.stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        try:
+            path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+            h = C.CDLL(path)
+            for f in (h.hipEventCreate, h.hipEventRecord, h.hipEventSynchronize, h.hipEventElapsedTime, h.hipEventDestroy):
+                f.restype = C.c_int
+            h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+            h.hipEventSynchronize.argtypes = [C.c_void_p]
+            h.hipStreamSynchronize.restype, h.hipStreamSynchronize.argtypes = C.c_int, [C.c_void_p]
+            h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+            ev = [C.c_void_p(), C.c_void_p()]
+            if any(h.hipEventCreate(C.byref(e)) != 0 for e in ev):
+                raise OSError("hipEventCreate failed")
+            self.h, self.ev = h, ev
+        except Exception:       # noqa: BLE001
+            self.t = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            for e in self.t:
+                e.record()
+
+    def record(self, k):
+        if self.h is not None:
+            self.h.hipEventRecord(self.ev[k], self.stream)
+        else:
+            self.t[k].record()
+
+    def synchronize(self, k):
+        if self.h is not None:
+            self.h.hipEventSynchronize(self.ev[k])
+        else:
+            self.t[k].synchronize()
+
+    def stream_synchronize(self):
+        if self.h is not None:
+            self.h.hipStreamSynchronize(self.stream)
+        else:
+            torch.cuda.current_stream().synchronize()
+
+    def elapsed_ms(self):
+        if self.h is None:
+            return self.t[0].elapsed_time(self.t[1])
+        ms = self.C.c_float()
+        rc = self.h.hipEventElapsedTime(self.C.byref(ms), self.ev[0], self.ev[1])
+        if rc != 0:
+            raise RuntimeError("hipEventElapsedTime failed: %d" % rc)
+        return float(ms.value)
+
+    def close(self):
+        if self.h is not None:
+            for e in self.ev:
+                self.h.hipEventDestroy(e)
+            self.h = None
+
+
 def algo_bytes_per_launch(task, policy, precision, n, steps_per_launch):
     """Algorithmic bytes one launch moves: caller I/O per env-step + the state read and written once."""
     io_b, st_b = IO_BYTES, STATE_BYTES[precision]
@@ -486,8 +548,8 @@ def main():
 
     def timed(k):
         ops, launches, gathers = plan(k)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(); ev1.record()   # torch creates the HIP event at its first record(): 40 us that do not belong to the region
+        evs = HipEvents(dev)
+        evs.record(0); evs.record(1)  # first use outside the region
         torch.cuda.synchronize(dev)
         c0 = env.counters()
         if world > 1:
@@ -498,21 +560,21 @@ def main():
         trailing = world > 1 and len(ops) > 1 and ops[-1] is do_gather     # the region's last op is a logging gather
         step_ops = ops[:-1] if trailing else ops
         t0 = p()
-        ev0.record()
+        evs.record(0)
         ta = p()
         for op in step_ops:
             op()
         tb = p()
-        ev1.record()                 # closes the K steps on the launch stream (the trailing logging gather is enqueued behind it)
+        evs.record(1)                # closes the K steps on the launch stream (the trailing logging gather is enqueued behind it)
         tc = p()
         if trailing:
             do_gather()              # host work under the running kernels; its device work is behind ev1 / on the side stream
-        ev1.synchronize()            # spin on the event: the K steps are done when it returns
+        evs.synchronize(1)           # the K steps are done when it returns
         td = p()
         # The contract's closing bracket: device work of the K steps finished on this rank (clock stops), then the barrier.  The
         # logging all-gather runs on a side stream and is NOT part of the K steps: it is waited for after the clock stops and its
         # latency reported separately; a device-wide synchronize here would put it back on the critical path.
-        cur.synchronize()
+        evs.stream_synchronize()     # the launch stream is idle: the closing synchronise of the bracket
         wall = p() - t0              # this rank's K steps, synchronise to synchronise; the job's time is the MAX over ranks
         te = p()
         if world > 1:
@@ -525,7 +587,9 @@ def main():
                        wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, barrier=(tg - te) * 1e6,
                        gather_wait_after_clock=(p() - tg) * 1e6)
         c1 = env.counters()
-        return wall, ev0.elapsed_time(ev1), launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}
+        gpu_ms = evs.elapsed_ms()
+        evs.close()
+        return wall, gpu_ms, launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}
 
     prewarm_device(Env, n, dev, args.precision, args.prewarm_ms)
     run(args.warmup)
