@@ -232,8 +232,9 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
 // The f16x3 actor is a WORKGROUP phase (four waves, 256 envs), same transposed decomposition as above:
 //   - one env column tile at a time with all eight neuron tiles (128 accumulators), so that nothing spills inside the
 //     k-loop (scratch traffic there would break the vmcnt accounting of the ring);
-//   - layer 1 on the f32 MFMA (W1aug . [obs, 1]); its accumulator layout is layer 2's B-operand layout up to a
-//     permutation of k inside each k-step, which the packing of W2H / W2L absorbs: only relu + the hi / lo split is VALU;
+//   - layer 1 on the f16 MFMA too (hi / lo split of W1aug and of [obs, 1], three passes); its accumulator layout is layer 2's
+//     B-operand layout up to a permutation of k inside each k-step, which the packing of W2H / W2L absorbs: only relu + the
+//     hi / lo split is VALU;
 //   - the A operands (W2 hi / lo fragments, 16 KB per k-step) reach the four waves through a ring in LDS that the waves
 //     fill cooperatively with direct-to-LDS loads (global_load_lds_dwordx4: 1 KB per wave instruction, scalar base + M0,
 //     no staging registers, no VALU).  Per-wave streaming of the same fragments from L2 left the matrix pipe waiting on
@@ -259,6 +260,23 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
 constexpr int ACTOR_KRES = 4;          // k-steps 0..3 of W2 stay resident in LDS for the whole launch
 constexpr int ACTOR_RING_SLOTS = 4;    // k-steps 4..15 stream through four slots; (16 - KRES) is a multiple of the slot count
 constexpr int ACTOR_RING_UINT4 = (ACTOR_KRES + ACTOR_RING_SLOTS) * 16 * 64;   // 16 KB per k-step: 128 KB
+// layer 1's f16 operand table, staged behind the f32 tables: [8 row tiles][hi | lo][64 lanes] half8 = 16 KB
+constexpr int ACTOR_W1H_FLOATS = 8 * 2 * 64 * 4;
+constexpr int ACTOR_W1_LDS_FLOATS_H = ACTOR_W1_LDS_FLOATS + ACTOR_W1H_FLOATS;
+// W1aug = [W1 | b1 | 0...] split hi / lo in the A-operand order of v_mfma_f32_32x32x16_f16: lane l of row tile R holds
+// W1aug[32 R + (l & 31)][8 (l >> 5) + j], j = 0..7.  Every thread of the block calls this once (before the __syncthreads()
+// that follows actor_stage_w1); w1_lds must have ACTOR_W1_LDS_FLOATS_H floats.
+AE_DEV void actor_stage_w1h(const float *W1P, float4 *w1_lds, int in_dim) {
+  _Float16 *t = reinterpret_cast<_Float16 *>(w1_lds + ACTOR_W1_LDS_FLOATS / 4);
+  for (int i = threadIdx.x; i < 8 * 64 * 8; i += blockDim.x) {
+    const int j = i & 7, l = (i >> 3) & 63, R = i >> 9;
+    const int row = 32 * R + (l & 31), k = 8 * (l >> 5) + j;
+    const float x = k < in_dim ? W1P[row * 12 + k] : (k == in_dim ? W1P[row * 12 + 11] : 0.f);
+    const _Float16 hi = (_Float16)x;
+    t[((R * 2 + 0) * 64 + l) * 8 + j] = hi;
+    t[((R * 2 + 1) * 64 + l) * 8 + j] = (_Float16)(x - (float)hi);
+  }
+}
 // LDS region (in k-step units) that holds k-step ks
 AE_DEV int actor_region(int ks) { return ks < ACTOR_KRES ? ks : ACTOR_KRES + (ks & (ACTOR_RING_SLOTS - 1)); }
 // the streamed k-step two stream positions after ks (ks >= KRES): 4 -> 6, ..., 13 -> 15, 14 -> 4, 15 -> 5
@@ -316,11 +334,11 @@ AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 template <int IN>
 AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, uint4 *ring, int nw,
                                    const float (&s)[IN], float (&out)[3]) {
-  static_assert(IN + 1 <= 2 * ACTOR_NK, "augmented input does not fit ACTOR_NK k-pairs");
+  static_assert(IN + 1 <= 16, "augmented input does not fit one f16 MFMA k-step");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5;
   constexpr int NT = 8;
-  const float *w1a = reinterpret_cast<const float *>(w1_lds) + lane;
+  const half8 *w1h = reinterpret_cast<const half8 *>(w1_lds + ACTOR_W1_LDS_FLOATS / 4) + lane;   // [8 R][hi | lo][64]
   const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;
   const float4 *b2tab = b2w3 + ACTOR_HID;                  // b2 alone, four consecutive neurons per float4
   float z[3] = {0.f, 0.f, 0.f};
@@ -349,30 +367,30 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
   // traffic inside the loop would also break the vmcnt accounting of the ring).  W2 streams through the ring twice.
 #pragma unroll 1
   for (int t = 0; t < 2; ++t) {
-    // Layer 1 on the f32 MFMA: H1^T[32 R + row][env] = W1aug[32 R + row][:] . saug[:][env], saug = [obs, 1, 0..].  B operand
-    // of k-pair m: lane l holds saug[2 m + (l >> 5)] of env (l & 31) + 32 t.
-    float bv[ACTOR_NK];
-    {
-      float sv[2 * ACTOR_NK];
-      static_for<0, 2 * ACTOR_NK>([&](auto DI) {
-        constexpr int d = DI;
-        if constexpr (d < IN) {
-          const float other = __shfl_xor(s[d], 32);
-          sv[d] = (half == t) ? s[d] : other;
-        } else {
-          sv[d] = d == IN ? 1.f : 0.f;
-        }
-      });
-      static_for<0, ACTOR_NK>([&](auto MI) { constexpr int m = MI; bv[m] = half ? sv[2 * m + 1] : sv[2 * m]; });
-    }
+    // Layer 1 on the f16 MFMA as well, three passes like layer 2: H1^T[32 R + row][env] = W1aug[32 R + row][:] . saug[:][env],
+    // saug = [obs, 1, 0..].  B operand: lane l holds saug[8 (l >> 5) + j], j = 0..7, of env (l & 31) + 32 t, split hi / lo.  (As
+    // f32 MFMAs, four k-pairs of 64 cycles each, layer 1 held the matrix pipe for 1.7 us of every env step; as 3 x 32 cycles 0.6 us.)
+    half8 oh, ol;
+    static_for<0, 8>([&](auto JI) {
+      constexpr int j = JI;
+      float v0 = 0.f, v1 = 0.f;   // k = j (lanes 0..31) and k = 8 + j (lanes 32..63)
+      if constexpr (j < IN) { const float other = __shfl_xor(s[j], 32); v0 = (half == t) ? s[j] : other; }
+      else if constexpr (j == IN) v0 = 1.f;
+      if constexpr (8 + j < IN) { const float other = __shfl_xor(s[8 + j], 32); v1 = (half == t) ? s[8 + j] : other; }
+      else if constexpr (8 + j == IN) v1 = 1.f;
+      const float v = half ? v1 : v0;
+      const _Float16 h = (_Float16)v;
+      oh[j] = h;
+      ol[j] = (_Float16)(v - (float)h);
+    });
     auto layer1 = [&](int R) {   // raw layer-1 sums of row tile R: register i <-> neuron 32 R + 8 (i / 4) + 4 half + (i % 4)
+      const half8 *w = w1h + (R < 8 ? R : 7) * 128;
+      const half8 wh = w[0], wl = w[64];
       f32x16 a1;
       static_for<0, 16>([&](auto RI) { constexpr int r = RI; a1[r] = 0.f; });
-      const float *w = w1a + (R < 8 ? R : 7) * (ACTOR_NK * 64);
-      static_for<0, ACTOR_NK>([&](auto MI) {
-        constexpr int m = MI;
-        if constexpr (2 * m <= IN) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m * 64], bv[m], a1, 0, 0, 0);
-      });
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, oh, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ol, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, oh, a1, 0, 0, 0);
       return a1;
     };
     // relu + f16 hi / lo split of registers 8 u + 2 c, 8 u + 2 c + 1 of a1 -> halfs 2 c, 2 c + 1 of k-step u's B operand.

@@ -231,10 +231,10 @@ struct PolicyParams {
 // TD3_MLP.take_action (/root/reference/algo/TD3/TD3_mlp.py:82-97) for n states; MODE 0 exact f32, 1 f16x3.
 template <int IN, int MODE>
 __global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH H, int64_t n, const float *states, float *actions) {
-  __shared__ float4 w1_lds[ACTOR_W1_LDS_FLOATS / 4];
+  __shared__ float4 w1_lds[(MODE == 1 ? ACTOR_W1_LDS_FLOATS_H : ACTOR_W1_LDS_FLOATS) / 4];
   __shared__ uint4 w2_ring[MODE == 1 ? ACTOR_RING_UINT4 : 1];
   actor_stage_w1(A.W1P, w1_lds, A.B2W3, IN);
-  if constexpr (MODE == 1) actor_ring_init(H, w2_ring, 4);
+  if constexpr (MODE == 1) { actor_stage_w1h(A.W1P, w1_lds, IN); actor_ring_init(H, w2_ring, 4); }
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 256
   const int64_t ic = i < n ? i : n - 1;
@@ -870,12 +870,13 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
   constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
   static_assert(WAVES == 1 || (WAVES == 2 && !kActor), "the fused actors need the whole register file");
   constexpr bool kPrefetch = POLICY == ARMENV_POLICY_EXTERNAL && WAVES == 1;
-  __shared__ float4 w1_lds[kActor ? ACTOR_W1_LDS_FLOATS / 4 : 1];
+  __shared__ float4 w1_lds[kActor ? (POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_W1_LDS_FLOATS_H : ACTOR_W1_LDS_FLOATS) / 4 : 1];
   __shared__ uint4 w2_ring[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_RING_UINT4 : 1];
   int nw = 4;   // live waves of this workgroup (the last one may be ragged; num_envs is a multiple of 64)
   if constexpr (kActor) {   // layer-1 / layer-3 tables staged once per launch
     actor_stage_w1(pol.actor.W1P, w1_lds, pol.actor.B2W3, Lane::kObs);
     if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // W2 streams through the ring every step
+      actor_stage_w1h(pol.actor.W1P, w1_lds, Lane::kObs);
       const int64_t left = P.n - (int64_t)blockIdx.x * blockDim.x;
       nw = (int)(((left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x) + 63) >> 6);
       if ((int)(threadIdx.x >> 6) < nw) actor_ring_init(pol.actor_h, w2_ring, nw);

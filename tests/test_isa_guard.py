@@ -124,7 +124,10 @@ def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
     assert len(sel) == 18 + 2             # the fused-actor rollout of every (task, precision, chain) + the two standalone actors
     for sn, md, ins in sel:
         m = [k for k, i in enumerate(ins) if i.mnem == "v_mfma_f32_32x32x16_f16"]
-        assert len(m) == 48, (sn, len(m))                        # two unrolled k-steps of 24
+        # layer 1 of the first row tile ahead of the loop (three f16 passes), then the loop body: two unrolled k-steps of 24 with
+        # layer 1 of the next row tile (3) between them
+        assert len(m) == 3 + 48 + 3, (sn, len(m))
+        m = m[3:]                                                # the loop body: from its first MFMA to its last
         body = ins[m[0]:m[-1] + 1]
         mem = [i for i in body if isa.classify(i.mnem) == "vmem"]
         assert mem and all(i.mnem == "global_load_lds_dwordx4" for i in mem), (sn, sorted({i.mnem for i in mem}))
