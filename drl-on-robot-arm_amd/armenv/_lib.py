@@ -41,7 +41,7 @@ class ArmEnvConfig(C.Structure):
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
         ("fence_z", C.c_double), ("fence_pivot", C.c_double), ("limit_erp", C.c_double), ("rollout_ready_lanes", C.c_int32), ("rollout_waves_per_simd", C.c_int32),
-        ("rollout_lanes_per_wave", C.c_int32), ("reserved0", C.c_int32),
+        ("rollout_lanes_per_wave", C.c_int32), ("rollout_straggler_trips", C.c_int32),
         ("chain", ArmEnvChain),
     ]
 

@@ -288,7 +288,8 @@ class BatchedArmEnv:
         out = (C.c_uint64 * 16)()
         L.check(self._lib.armenv_counters(self._h, C.byref(out), self._stream()))
         return dict(episodes=out[0], successes=out[1], env_steps=out[2], nonfinite=out[3], ik_updates=out[4],
-                    limit_steps=out[5], low_flange_steps=out[6], cap_steps=out[7], illcond_steps=out[8])
+                    limit_steps=out[5], low_flange_steps=out[6], cap_steps=out[7], illcond_steps=out[8],
+                    wave_trips=out[9], wave_rounds=out[10])
 
 
 class BatchedReachEnv(BatchedArmEnv):

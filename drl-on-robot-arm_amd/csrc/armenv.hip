@@ -153,6 +153,9 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   // measured at 32 768 envs, 100-step launches: pick 27.6 -> 23.3 us per step at 62; push and reach are
   // faster in lockstep (their per-wave maxima are close to their means, and every transition round costs a tail block)
   c->rollout_ready_lanes = task == ARMENV_TASK_PICK ? 62 : 0;
+  // the transition rule that lets every lane on its way to the iteration cap run on (round 3; same size: 22.8 -> 21.1 us per
+  // step, 1 000-step launches 16.0 -> 14.3; tests/tools/ready_lanes_sweep.py, profiles/r03_async_schedule.txt)
+  c->rollout_straggler_trips = task == ARMENV_TASK_PICK ? 6 : 0;
   return armenv_builtin_chain(ARMENV_ROBOT_KUKA, &c->chain);
 }
 
@@ -169,6 +172,8 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   if (cfg->clamp_joint_limits == 2 && !(cfg->limit_erp > 0.0 && cfg->limit_erp <= 1.0)) return fail(ARMENV_EINVAL, "armenv_create: limit_erp must be in (0, 1]");
   if (cfg->rollout_lanes_per_wave != 0 && cfg->rollout_lanes_per_wave != 32 && cfg->rollout_lanes_per_wave != 64)
     return fail(ARMENV_EINVAL, "armenv_create: rollout_lanes_per_wave must be 0, 32 or 64");
+  if (cfg->rollout_straggler_trips < 0 || cfg->rollout_straggler_trips > 64)
+    return fail(ARMENV_EINVAL, "armenv_create: rollout_straggler_trips must be in 0..64");
   if (cfg->rollout_waves_per_simd < 0 || cfg->rollout_waves_per_simd > 2) return fail(ARMENV_EINVAL, "armenv_create: rollout_waves_per_simd must be 0, 1 or 2");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

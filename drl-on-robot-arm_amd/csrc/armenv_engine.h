@@ -112,6 +112,7 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
   static constexpr int block = 256;   // four waves: one per SIMD of a CU; the f16x3 actor phase is a 4-wave workgroup
   int cus = 256;
   int ready_lanes = 0;   // > 0: rollouts run lane-asynchronously (env_rollout_async_kernel)
+  int straggler_trips = 0;   // > 0: its transition rule (ArmEnvConfig.rollout_straggler_trips) instead of the count
   int waves_cfg = 0;     // ArmEnvConfig.rollout_waves_per_simd: 0 auto, 1, 2
   // Workgroup size of the env kernels that have no workgroup phase (step, rollout without a fused actor): the IK keeps
   // one wave per SIMD, so a batch that does not fill the chip is launched as smaller workgroups -- the dispatcher then
@@ -220,6 +221,7 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
     waves_cfg = cfg.rollout_waves_per_simd;
     lanes_cfg = cfg.rollout_lanes_per_wave;
     ready_lanes = cfg.rollout_ready_lanes < 0 ? 0 : (cfg.rollout_ready_lanes > 64 ? 64 : cfg.rollout_ready_lanes);
+    straggler_trips = cfg.rollout_straggler_trips < 0 ? 0 : cfg.rollout_straggler_trips;
     fence_on = cfg.fence_counters != 0;
     P.ik.fence_pivot = (T)cfg.fence_pivot;
     P.fence_z = (T)cfg.fence_z;
@@ -293,13 +295,14 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
   void launch_rollout_async(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     if (two_waves()) {
       hipLaunchKernelGGL((env_rollout_async_kernel<LaneX, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
-                         steps, actions, io0, actions_out, (int32_t)ready_lanes);
+                         steps, actions, io0, actions_out, (int32_t)ready_lanes, (int32_t)straggler_trips);
       return;
     }
     const int b = lane_block();
     const bool h = half_waves();
+    // count rule under half-filled waves: the same share of the live lanes (62 of 64 -> 31 of 32; 22.1 us vs 23.2 at 30)
     hipLaunchKernelGGL((env_rollout_async_kernel<LaneX, T, POLICY>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), pol, steps,
-                       actions, io0, actions_out, (int32_t)(h ? (ready_lanes + 1) / 2 : ready_lanes));   // half-filled waves: the same share of the live lanes (pick: 62 of 64 -> 31 of 32, measured best: 21.7 us vs 22.3 at 30)
+                       actions, io0, actions_out, (int32_t)(h ? (ready_lanes + 1) / 2 : ready_lanes), (int32_t)straggler_trips);
   }
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     // lane-asynchronous form (ArmEnvConfig.rollout_ready_lanes > 0): external actions or the in-kernel random policy

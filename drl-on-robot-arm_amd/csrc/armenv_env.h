@@ -102,6 +102,21 @@ AE_DEV void flush_counts(const EnvParams<T> &P, int64_t i, uint32_t n_done, uint
     if (k) row[8] += k;
   }
 }
+// largest v of the wave's active lanes (v < 256): one ballot per bit, scalar unit only
+AE_DEV uint32_t wave_max8(uint32_t v) {
+  uint32_t m = 0;
+  for (int b = 7; b >= 0; --b) { if (__ballot(v >= (m | (1u << b))) != 0ull) m |= 1u << b; }
+  return m;
+}
+// Bookkeeping builds: what the schedule cost this wave -- loop iterations that ran an IK trip (row[9]) and step tails (row[10]).
+AE_DEV void flush_schedule(unsigned long long *counters, uint32_t wave_trips, uint32_t wave_rounds) {
+  // every lane of the wave holds the same two counts; the lowest live lane writes them
+  if (__ffsll((unsigned long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) {
+    unsigned long long *row = counters + kCounterCols * wave_row();
+    row[9] += wave_trips;
+    row[10] += wave_rounds;
+  }
+}
 AE_DEV void flush_env_steps(unsigned long long *counters, int64_t i, unsigned long long env_steps) {
   if (i == 0) counters[2] += env_steps;
 }
@@ -902,6 +917,7 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     asm volatile("" ::"v"(an[0]), "v"(an[1]), "v"(an[2]));
   }
   ActionPrefetch an_next{0.f, 0.f, 0.f};
+  [[maybe_unused]] uint32_t w_trips = 0;
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
     if constexpr (kPrefetch) {
@@ -949,17 +965,21 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     const uint32_t before = L.n_done;
     // the fused actor needs the whole register file between two env steps: the link frames are not carried across it
     if constexpr (kActor) L.have_S = false;
+    int upd;
     if constexpr (kPrefetch) {
-      L.env_step(P, i, a, io, &an_next, &an);
+      upd = L.env_step(P, i, a, io, &an_next, &an);
     } else {
-      L.env_step(P, i, a, io);
+      upd = L.env_step(P, i, a, io);
     }
+    if constexpr (Lane::kFence) w_trips += wave_max8((uint32_t)upd + 1u);   // a lane's trips: its updates + the exit trip
+    else (void)upd;
     if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
       if (L.n_done != before && P.auto_reset) episode += 1u;
     }
   }
   L.store(P, i);
   if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) actor_ring_drain();
+  if constexpr (Lane::kFence) flush_schedule(P.counters, w_trips, (uint32_t)steps);
   flush_env_steps(P.counters, i, (unsigned long long)n * (unsigned long long)steps);
 }
 
@@ -973,14 +993,15 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
 // contains one (12.2 trips per wave-step for 4.45 per env-step, tests/tools/trip_stats.py); push: a 5th trip in one lane
 // of most waves (5.5 for 4.1) -- the wave is held to its slowest lane at EVERY step.  Here a slow lane only delays itself:
 // the wave pays ~max_lane sum_t trips (pick 6.5, push 4.4) plus one tail block per transition round.  ready_lanes trades
-// the two: 64 is lockstep (one tail per step), 1 runs a tail block on nearly every trip.
+// the two: 64 is lockstep (one tail per step), 1 runs a tail block on nearly every trip.  `straggler_trips` > 0 replaces the
+// count by a rule that knows what the slow lanes are (ArmEnvConfig.rollout_straggler_trips; tests/tools/async_policy_sim.py).
 // Per-lane arithmetic, its order and every store are those of env_step: trajectories are bit-identical to the lockstep
 // kernels and to armenv_step launches (tested).  Not used with the fused actors (their MFMA phases are wave-synchronous).
 // WAVES: register budget as for env_rollout_kernel (2: <= 256 registers per lane, for batches with more waves than SIMDs).
 template <class Lane, typename T, int POLICY, int WAVES = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const float *actions, StepIO io0,
-                              float *actions_out, int32_t ready_lanes) {
+                              float *actions_out, int32_t ready_lanes, int32_t straggler_trips) {
   static_assert(POLICY == ARMENV_POLICY_EXTERNAL || POLICY == ARMENV_POLICY_RANDOM, "no wave-synchronous policy phases here");
   const int64_t i = lane_env(P);   // env of this lane (full or half-filled waves, EnvParams::half_waves)
   if (i < 0) return;
@@ -1027,10 +1048,17 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
   };
   load_action(0);
   begin_step();
+  [[maybe_unused]] uint32_t w_trips = 0, w_rounds = 0;
   for (;;) {
+    if constexpr (Lane::kFence) w_trips += __ballot(!ready && t < steps) != 0ull ? 1u : 0u;
     if (!ready && t < steps) ready = ik_trip<C, T, Lane::kFence>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps, L.minpiv);
     const unsigned long long rb = __ballot(ready), ib = __ballot(!ready && t < steps);
-    if (__popcll(rb) >= ready_lanes || ib == 0ull) {       // wave-uniform: a transition round
+    // wave-uniform: a transition round.  Count rule: `ready_lanes` lanes wait.  Straggler rule (straggler_trips > 0): every lane
+    // that has spent fewer than that many trips on its step waits -- lanes on their way to the iteration cap carry on, however
+    // many they are, and the others stay in phase with each other
+    const bool round = straggler_trips > 0 ? __ballot(!ready && t < steps && updates < straggler_trips) == 0ull : __popcll(rb) >= ready_lanes;
+    if (round || ib == 0ull) {
+      if constexpr (Lane::kFence) w_rounds += rb != 0ull ? 1u : 0u;
       if (ready) {
         // the next step's action is requested first: the step's tail (a few hundred instructions) covers most of the
         // load's latency before begin_step consumes it
@@ -1057,6 +1085,7 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
     if (__ballot(t < steps) == 0ull) break;
   }
   L.store(P, i);
+  if constexpr (Lane::kFence) flush_schedule(P.counters, w_trips, w_rounds);
   flush_env_steps(P.counters, i, (unsigned long long)n * (unsigned long long)steps);
 }
 

@@ -156,7 +156,13 @@ typedef struct ArmEnvConfig {
    * slots, and a wave's per-step maximum of IK trips is taken over 32 lanes (push 5.67 -> 5.36 trips per wave-step); same bits.
    * 0 (default): 32 for push / pick when the half-filled waves still get one SIMD each, 64 otherwise.  Ignored with a fused actor. */
   int32_t rollout_lanes_per_wave;
-  int32_t reserved0;
+  /* Transition rule of the lane-asynchronous schedule (rollout_ready_lanes > 0).  0: by count (rollout_ready_lanes lanes wait).
+   * K > 0: a round starts when every lane that has spent fewer than K IK trips on its current step is waiting -- the lanes that
+   * are on their way to Bullet's iteration cap carry on, however many there are, and all the others stay in phase (a count
+   * lets at most 64 - k slow lanes run on, and a lane that merely needs one trip more than its neighbours drops out of phase
+   * with them).  Default: pick 6, others 0.  Occupies the int32 that ABI 3 reserved (must-be-zero) at this place: a caller
+   * that zero-fills it keeps the count rule.  Same bits under every rule. */
+  int32_t rollout_straggler_trips;
 
   ArmEnvChain chain;
 } ArmEnvConfig;
@@ -252,7 +258,11 @@ int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len
  * out[2] env-steps executed, out[3] non-finite joint states seen, out[4] IK (DLS) updates applied, out[5] env steps whose IK
  * result left the URDF joint limits, out[6] env steps that ended with the flange below fence_z, out[7] env steps whose IK
  * call ran to ik_max_iters, out[8] env steps whose IK call passed through an ill-conditioned system (fence_pivot);
- * out[5..8]: the parity fence, counted only with ArmEnvConfig.fence_counters; out[9..15] 0 (reserved). */
+ * out[5..8]: the parity fence, counted only with ArmEnvConfig.fence_counters.  Also only with fence_counters, for
+ * armenv_rollout launches without a fused actor: out[9] IK trips as the wavefronts paid them (a trip of a wave counts once,
+ * however few of its lanes took part; out[9] / (waves * steps) is the schedule's trips per wave-step, to hold against
+ * out[4] / out[2] + 1 per env-step), out[10] step tails as the wavefronts paid them (lockstep: one per step; lane-asynchronous:
+ * one per transition round).  out[11..15] 0 (reserved). */
 int armenv_counters(ArmEnv *env, uint64_t out[16], void *stream);
 
 /* Logging summary computed on the device (no host sync; what main.py:130-160 prints/plots from one env): out_dev f64 [8] =

@@ -386,6 +386,8 @@ def test_half_filled_waves_equal_full_waves(envs, task):
                 got.update(obs2=out2["obs"].clone(), done2=out2["done"].clone())
                 got.update({"st_" + k: v.clone() for k, v in e.get_state().items()})
                 cnt = e.counters()
+                for k in ("wave_trips", "wave_rounds"):      # what the schedule cost the waves: depends on the wave filling
+                    assert cnt.pop(k) > 0
                 e.close()
                 if ref is None:
                     ref, ref_cnt = got, cnt

@@ -759,19 +759,24 @@ def test_benchmarked_launch_shape_free_running_vs_oracle_f32(envs, O, kuka):
 @pytest.mark.parametrize("precision", [64, 32])
 @pytest.mark.parametrize("task", ["reach", "push", "pick"])
 def test_lane_asynchronous_rollout_equals_lockstep(envs, task, precision):
-    """armenv_rollout's two schedules (ArmEnvConfig.rollout_ready_lanes): lockstep (0) and lane-asynchronous with several
-    waiting thresholds -- 1 (a tail block on nearly every trip), 7, 33, 64 (every lane waits for the whole wave) -- give the
-    SAME bits: every per-step output, the final state, the counters.  Ragged batch (not a multiple of 64), 20-step episodes
-    (in-place resets while other lanes of the wave are mid-IK), external actions and the in-kernel random policy."""
+    """armenv_rollout's schedules: lockstep (ArmEnvConfig.rollout_ready_lanes 0) and lane-asynchronous -- by count, with several
+    waiting thresholds: 1 (a tail block on nearly every trip), 7, 33, 64 (every lane waits for the whole wave), and by the
+    straggler rule (rollout_straggler_trips 1, 3, 6) -- give the SAME bits: every per-step output, the final state, the
+    counters.  Ragged batch (not a multiple of 64), 20-step episodes (in-place resets while other lanes of the wave are
+    mid-IK), external actions and the in-kernel random policy.  What differs is what the schedule cost the waves
+    (counters wave_trips / wave_rounds): lockstep pays one tail per step."""
     n, T = 2048 + 64 + 5, 45
     Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv, pick=envs.BatchedPickEnv)[task]
     rng = np.random.default_rng(77)
     sig = 0.686 if task == "reach" else 0.392
     acts = torch.from_numpy((rng.standard_normal((T, n, 3)) * sig).clip(-0.7, 0.7).astype(np.float32)).to(DEV)
+    schedule = ("wave_trips", "wave_rounds")
+    waves = (n + 31) // 32 if task != "reach" else (n + 63) // 64      # push / pick: half-filled waves at this batch size
     for policy in ("external", "random"):
         ref = None
-        for k in (0, 1, 7, 33, 64):
-            e = Env(n, device=DEV, seed=13, precision=precision, max_steps=20, rollout_ready_lanes=k, fence_counters=1)
+        for k, K in ((0, 0), (1, 0), (7, 0), (33, 0), (64, 0), (62, 1), (62, 3), (62, 6)):
+            e = Env(n, device=DEV, seed=13, precision=precision, max_steps=20, rollout_ready_lanes=k, rollout_straggler_trips=K,
+                    fence_counters=1)
             if policy == "random":
                 e.set_policy("random", noise_sigma=sig, noise_clip=0.7)
             e.reset()
@@ -781,14 +786,26 @@ def test_lane_asynchronous_rollout_equals_lockstep(envs, task, precision):
             got.update({"obs2": out2["obs"].clone(), "done2": out2["done"].clone()})
             got.update({"st_" + kk: v.clone() for kk, v in e.get_state().items()})
             cnt = e.counters()
+            sched = {kk: cnt.pop(kk) for kk in schedule}
             e.close()
             if ref is None:
-                ref, ref_cnt = got, cnt
+                ref, ref_cnt, ref_sched = got, cnt, sched
                 assert cnt["episodes"] >= 2 * n and cnt["env_steps"] == n * (T + 7)
+                assert sched["wave_rounds"] == waves * (T + 7), sched
+                # a wave pays at least its mean lane's trips (updates + one exit trip per env-step)
+                assert sched["wave_trips"] * (n / waves) >= cnt["ik_updates"] + cnt["env_steps"], (sched, cnt)
             else:
                 for kk in ref:
-                    assert torch.equal(ref[kk], got[kk]), (task, precision, policy, k, kk)
-                assert cnt == ref_cnt, (task, precision, policy, k)
+                    assert torch.equal(ref[kk], got[kk]), (task, precision, policy, k, K, kk)
+                assert cnt == ref_cnt, (task, precision, policy, k, K)
+                # (a badly chosen rule can cost more trips than lockstep -- reach with K = 3 calls every lane on its exit trip a
+                # straggler and the wave falls out of phase; the bits do not care)
+                assert sched["wave_rounds"] >= ref_sched["wave_rounds"] and sched["wave_trips"] > 0, (task, precision, policy, k, K, sched, ref_sched)
+                if K == 0 and k in (1, 64):      # fully asynchronous / lockstep by another name: never more trips than lockstep
+                    assert sched["wave_trips"] <= ref_sched["wave_trips"], (task, precision, policy, k, sched, ref_sched)
+    from armenv import ArmEnvError
+    with pytest.raises(ArmEnvError):
+        Env(64, device=DEV, rollout_straggler_trips=65)
 
 
 @pytest.mark.parametrize("precision", [64, 32])
