@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects a round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only)
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only,
+#                                                               `bash profiles/collect.sh pick` to redo the pick row alone)
 # Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r03_*).
 # PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
 set -u
@@ -25,6 +26,9 @@ stats push32768 --task push --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
 stats pick32768 --task pick --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
 stats f32engine --precision 32 --steps 1000 --no-cpu-baseline --fence-steps 0 --secondary-legs 0
 fi
+if [ "$MODE" = "pick" ]; then
+stats pick32768 --task pick --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
+fi
 # one small counter set per pass: a set the hardware cannot collect in one pass makes rocprofv3 abort and then hang in its
 # signal handler (FETCH_SIZE + WRITE_SIZE + GRBM_GUI_ACTIVE did), hence the timeouts
 pmc() {   # name, counters..., then -- bench args
@@ -35,6 +39,12 @@ pmc() {   # name, counters..., then -- bench args
   timeout 300 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
   find "$OUT/$name" -name '*counter_collection.csv' -exec cp {} "$OUT/${name}_counters.csv" \;
 }
+if [ "$MODE" = "pick" ]; then
+pmc pmc_pick SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -- --task pick --envs-per-gpu 32768 --steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+ls -la "$OUT"
+exit 0
+fi
 B100="--steps 500 --warmup 50 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"
 B20="--steps 200 --warmup 20 --rollout-steps 20 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"    # the driver's launch shape, ten launches
 if [ "$MODE" = "all" ]; then
