@@ -399,3 +399,41 @@ def test_half_filled_waves_equal_full_waves(envs, task):
     from armenv import ArmEnvError
     with pytest.raises(ArmEnvError):
         Env(64, device=DEV, rollout_lanes_per_wave=16)
+
+
+def test_pick_schedule_counters_at_32768(envs, record_property):
+    """What the three rollout schedules cost pick's wavefronts at its benchmark size (32 768 envs, exploration noise of
+    main.py:484, steady state after 600 steps), by the bookkeeping build's schedule counters (armenv_counters out[9], out[10]):
+    lockstep pays its slowest lane at every step (~8.8 trips per wave-step for 4.4 per env-step), the lane-asynchronous count
+    rule less (~7.2), the straggler rule -- the default -- less again (~6.8), each for a few more step tails; the three
+    trajectories are the same bits.  (timings: profiles/r03_async_schedule.txt.)"""
+    n, T = 32768, 100
+    gen = torch.Generator(device=DEV); gen.manual_seed(1000)
+    pool = torch.randn((1000, n, 3), device=DEV, generator=gen) * 0.392
+    waves = n // 32                      # half-filled waves at this size
+    res, ref = {}, None
+    for name, over in (("lockstep", dict(rollout_ready_lanes=0)), ("count", dict(rollout_straggler_trips=0)), ("straggler", {})):
+        e = envs.BatchedPickEnv(n, device=DEV, seed=0, fence_counters=1, **over)
+        assert name != "straggler" or (e.cfg.rollout_ready_lanes, e.cfg.rollout_straggler_trips) == (62, 6)
+        e.reset()
+        for k in range(6):
+            e.rollout(T, pool[k * T:(k + 1) * T])
+        c0 = e.counters()
+        for k in range(6, 10):
+            e.rollout(T, pool[k * T:(k + 1) * T])
+        c1 = e.counters()
+        q = e.get_state()["q"].clone()
+        e.close()
+        ws = waves * 4 * T
+        res[name] = ((c1["wave_trips"] - c0["wave_trips"]) / ws, (c1["wave_rounds"] - c0["wave_rounds"]) / ws,
+                     (c1["ik_updates"] - c0["ik_updates"]) / (n * 4 * T) + 1.0)
+        if ref is None:
+            ref = q
+        else:
+            assert torch.equal(ref, q), name
+    record_property("pick_schedule", {k: [round(x, 3) for x in v] for k, v in res.items()})
+    print("pick 32768 schedules (wave trips, tails per wave-step; trips per env-step):", res)
+    assert res["lockstep"][1] == 1.0 and res["lockstep"][2] == res["count"][2] == res["straggler"][2]
+    assert 4.2 < res["lockstep"][2] < 4.7
+    assert res["straggler"][0] < res["count"][0] < res["lockstep"][0]
+    assert res["straggler"][0] < 0.82 * res["lockstep"][0] and res["straggler"][1] < 1.4
