@@ -79,6 +79,7 @@ F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X f64 vector (FMA = 2 flop), 1/2 of the 15
 IO_BYTES = 12 + 24 + 4 + 1 + 1                 # action in; obs, reward, done, success out
 # q, (cos q, sin q), ep_return read + written; goal read; step read + written
 STATE_BYTES = {64: 2 * (56 + 112 + 8) + 12 + 2 * 4, 32: 2 * (28 + 56 + 4) + 12 + 2 * 4}
+F64_ISSUE_CYCLES_ONE_WAVE = 6.6   # measured issue interval of f64 vector instructions from ONE wave (nominal pipe rate: 4)
 # algorithmic flops of the f64/f32 reach step: per IK update and per FK-only exit trip
 FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + residual + per-step sincos/reward
 
@@ -182,6 +183,12 @@ def rooflines(task, policy, precision, n, steps_per_launch, launch_us, updates, 
     tf = flops / (launch_us * 1e-6) / 1e12
     valu = {"bound": "valu", "achieved": tf, "peak": vpeak, "unit": "TFLOP/s", "frac": tf / vpeak,
             "ik_updates_per_env_step": updates, "algo_flops_per_launch": flops}
+    if precision == 64:
+        # measured, not nominal (profiles/r03_valu_f64_rate_probe.txt): one wave issues an f64 vector instruction every ~6.6 cycles,
+        # the pipe's 4-cycle rate needs several waves per SIMD; the env kernels run one wave per SIMD (two in large_batch: 5.8)
+        valu["one_wave_per_simd"] = {"cycles_per_f64_instruction": F64_ISSUE_CYCLES_ONE_WAVE, "peak": vpeak * 4.0 / F64_ISSUE_CYCLES_ONE_WAVE,
+                                     "frac": tf / (vpeak * 4.0 / F64_ISSUE_CYCLES_ONE_WAVE),
+                                     "source": "tests/tools/exp/valu_f64_rate_probe.hip, profiles/r03_valu_f64_rate_probe.txt"}
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_key": key, "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
             "binding_bound": "valu", "valu": valu}

@@ -240,8 +240,8 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
 //     no staging registers, no VALU).  Per-wave streaming of the same fragments from L2 left the matrix pipe waiting on
 //     memory: with one wave per SIMD nothing else hides a 1-2 us L2 round trip, and the registers to keep a dozen
 //     k-steps in flight do not exist.
-// Measured (65 536 envs, round 3): 30.4 us per fused env step; the 792 MFMAs of a wave-step take 12.1 us at the rate the chip
-// sustains with every CU busy (15.3 ns each, tests/tools/exp/mfma_rate_probe.hip; 13.3 ns nominal), the LDS-DMA pieces of the
+// Measured (65 536 envs, round 3): 30.4 us per fused env step; the 792 MFMAs of a wave-step take 10.9-12.1 us at the rate the chip
+// sustains with every CU busy (13.7-15.2 ns each, tests/tools/exp/mfma_rate_probe.hip; 13.3 ns nominal), the LDS-DMA pieces of the
 // refill ~6 us of issue, the env step itself 6.9 us.
 // LDS holds k-steps 0..3 of W2 permanently (64 KB, filled once per launch) and streams k-steps 4..15 through a ring of
 // four 16 KB slots (slot = k-step mod 4; 12 streamed k-steps per pass, so the mapping carries over from pass to pass

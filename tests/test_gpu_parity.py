@@ -1963,6 +1963,8 @@ def test_bench_line_contract():
     assert ro["traffic_key"] == "reach_rollout<f64,kuka>|policy=external|T=20|N=65536"
     assert ro["traffic"] is not None and 0.9 < ro["traffic"] / ro["algo_bytes_per_launch"] < 1.3      # PMC pass at this launch shape
     assert ro["binding_bound"] == "valu" and 0.2 < ro["valu"]["frac"] < 1.0 and ro["valu"]["unit"] == "TFLOP/s"
+    one = ro["valu"]["one_wave_per_simd"]        # the measured single-wave f64 issue ceiling beside the nominal peak
+    assert one["cycles_per_f64_instruction"] == 6.6 and abs(one["peak"] - 78.6 * 4 / 6.6) < 1e-9 and 0.6 < one["frac"] < 1.0
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["threads_1"]["cores"] == 1 and cb["threads_1"]["value"] > 5e4 and cb["value"] >= 0.8 * cb["threads_1"]["value"]
     assert cb["cores"] <= cb["host"]["affinity_cpus"]
