@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 NJ = 7
-ABI_VERSION = 3
+ABI_VERSION = 4
 TASK_REACH, TASK_PUSH, TASK_PICK = 0, 1, 2
 ROBOT_KUKA, ROBOT_DIANA = 0, 1
 FK_AUTO, FK_GENERIC = 0, 1
@@ -40,7 +40,8 @@ class ArmEnvConfig(C.Structure):
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
-        ("fence_z", C.c_double), ("fence_pivot", C.c_double), ("limit_erp", C.c_double), ("rollout_ready_lanes", C.c_int32), ("rollout_waves_per_simd", C.c_int32),
+        ("fence_z", C.c_double), ("fence_pivot", C.c_double), ("limit_erp", C.c_double), ("ik_tip_offset", C.c_double * 3),
+        ("rollout_ready_lanes", C.c_int32), ("rollout_waves_per_simd", C.c_int32),
         ("rollout_lanes_per_wave", C.c_int32), ("rollout_straggler_trips", C.c_int32),
         ("chain", ArmEnvChain),
     ]
@@ -68,8 +69,8 @@ SYMBOLS = {
     "armenv_destroy": (None, [_P]),
     "armenv_reset": (C.c_int, [_P, _P, _P, _P]),
     "armenv_reset_with_goal": (C.c_int, [_P, _P, _P, _P, _P]),
-    "armenv_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "armenv_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "armenv_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "armenv_rollout": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "armenv_fk": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P]),
     "armenv_ik": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "armenv_get_state": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),

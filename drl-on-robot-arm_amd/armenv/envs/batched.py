@@ -63,6 +63,7 @@ class BatchedArmEnv:
         self._success = torch.empty(n, dtype=torch.uint8, device=dev)
         self._terminal = None
         self._ik_updates = None
+        self._diag = None
         self.action_space = Box(low=[-0.4, -0.4, -0.6], high=[0.4, 0.4, 0.3])       # rl_reach_env.py:87-90
         self.max_steps_one_episode = int(cfg.max_steps)
 
@@ -108,21 +109,26 @@ class BatchedArmEnv:
             L.check(self._lib.armenv_reset_with_goal(self._h, _ptr(m), _ptr(g), _ptr(self._obs), self._stream()))
         return self._obs
 
-    def step(self, action, want_terminal_obs=False, want_ik_updates=False):
+    def step(self, action, want_terminal_obs=False, want_ik_updates=False, want_diag=False):
         """One env step for all N envs; no host synchronisation.  Returns (obs, reward, done, success)
         -- the same preallocated tensors every call (clone them to keep a history).  With
         want_terminal_obs the pre-reset observation is available as ``self.terminal_obs``; with want_ik_updates the number
-        of DLS updates of every env's IK call as ``self.ik_updates`` (u8; ik_max_iters = the call did not converge)."""
+        of DLS updates of every env's IK call as ``self.ik_updates`` (u8; ik_max_iters = the call did not converge); with
+        want_diag ``self.diag`` f64 [N, 4] = the step's end-effector position and reward before any f32 rounding (the last
+        two need a handle created with fence_counters=1)."""
         if action is not None:          # None: the fused policy installed with set_policy() acts
             self._check_action(action)
         if want_terminal_obs and self._terminal is None:
             self._terminal = torch.empty_like(self._obs)
         if want_ik_updates and self._ik_updates is None:
             self._ik_updates = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        if want_diag and self._diag is None:
+            self._diag = torch.empty((self.num_envs, 4), dtype=torch.float64, device=self.device)
         term = self._terminal if want_terminal_obs else None
         upd = self._ik_updates if want_ik_updates else None
+        dg = self._diag if want_diag else None
         L.check(self._lib.armenv_step(self._h, _ptr(action), _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
-                                      _ptr(self._success), _ptr(term), _ptr(upd), self._stream()))
+                                      _ptr(self._success), _ptr(term), _ptr(upd), _ptr(dg), self._stream()))
         return self._obs, self._reward, self._done.view(torch.bool), self._success.view(torch.bool)
 
     @property
@@ -132,6 +138,10 @@ class BatchedArmEnv:
     @property
     def terminal_obs(self):
         return self._terminal
+
+    @property
+    def diag(self):
+        return self._diag
 
     def set_policy(self, kind="random", action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7, actor_state_dict=None):
         """Install the fused exploration policy of main.py:116-117 for `rollout(actions=None)`:
@@ -157,17 +167,18 @@ class BatchedArmEnv:
         L.check(self._lib.armenv_actor_forward(self._h, st.shape[0], _ptr(st), _ptr(out), self._stream()))
         return out
 
-    def rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, want_ik_updates=False):
+    def rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, want_ik_updates=False,
+                want_diag=False):
         """`steps` env steps of all envs in one kernel launch (the inner loop of main.py:108-128).
         actions: float32 [steps, N, 3] on the device, or None to use the fused policy (set_policy).
-        Returns a dict of [steps, N, ...] tensors: obs, reward, done, success (+ actions, terminal_obs, ik_updates)."""
+        Returns a dict of [steps, N, ...] tensors: obs, reward, done, success (+ actions, terminal_obs, ik_updates, diag)."""
         launch, out = self.bind_rollout(steps, actions, out, want_actions, want_terminal_obs, stream=self._stream(),
-                                        want_ik_updates=want_ik_updates)
+                                        want_ik_updates=want_ik_updates, want_diag=want_diag)
         launch()
         return out
 
     def bind_rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, stream=None,
-                     want_ik_updates=False):
+                     want_ik_updates=False, want_diag=False):
         """Everything `rollout` does except the launch: argument checks, output buffers, pointer and stream resolution.
         Returns (launch, out): `launch()` enqueues the T-step kernel with one ctypes call into armenv_rollout (on the
         stream that was current at bind time, or `stream`), `out` is the dict `rollout` returns.  For callers that issue
@@ -192,12 +203,13 @@ class BatchedArmEnv:
         acts = buf("actions", (T, n, 3), torch.float32) if want_actions else None
         term = buf("terminal_obs", (T, n, self.obs_dim), torch.float32) if want_terminal_obs else None
         upd = buf("ik_updates", (T, n), torch.uint8) if want_ik_updates else None
+        dg = buf("diag", (T, n, 4), torch.float64) if want_diag else None
         out["done"] = done.view(torch.bool)
         out["success"] = succ.view(torch.bool)
         fn, h = self._lib.armenv_rollout, self._h
-        args = (h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(succ), _ptr(acts), _ptr(term), _ptr(upd),
+        args = (h, T, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(succ), _ptr(acts), _ptr(term), _ptr(upd), _ptr(dg),
                 stream if stream is not None else self._stream())
-        keep = (actions, obs, rew, done, succ, acts, term, upd)     # the closure keeps the tensors alive
+        keep = (actions, obs, rew, done, succ, acts, term, upd, dg)     # the closure keeps the tensors alive
 
         def launch(_fn=fn, _args=args, _check=L.check, _keep=keep):
             rc = _fn(*_args)

@@ -59,7 +59,8 @@ class RLReachEnv:
 
     def _make_engine(self):
         self._dv, self._dis = float(opt.reach_ctr), float(opt.reach_dis)
-        self._eng = BatchedReachEnv(1, device=self._device, auto_reset=False, precision=64, fk_path=1,
+        # fence_counters=1: the bookkeeping build of the kernels, whose step also hands out the f64 end-effector position and reward
+        self._eng = BatchedReachEnv(1, device=self._device, auto_reset=False, precision=64, fk_path=1, fence_counters=1,
                                     dv=self._dv, reach_dis=self._dis, max_steps=int(self.max_steps_one_episode))
 
     def _sync_opt(self):
@@ -86,23 +87,22 @@ class RLReachEnv:
         return obs[0].cpu().numpy()                                      # np.float32[6]  :217
 
     def step(self, action):
-        """:219-319 -> (np.float32[6], float reward, bool done, bool is_success).  The step itself is one armenv_step launch (actions
-        and the reward buffer are f32 at that boundary); the reward returned here is recomputed in f64 from the env's f64 joint
-        state -- armenv_fk, then the expressions of :281-309 in numpy -- because the reference returns a Python float computed in
-        f64: it carries all its digits, not an f32 rounding of them."""
+        """:219-319 -> (np.float32[6], float reward, bool done, bool is_success).  One armenv_step launch.  The reward buffer of the C
+        ABI is f32, the reference returns a Python float computed in f64: position, distance and reward are taken from the step's
+        own f64 diagnostics (armenv_step diag_dev) -- the very numbers the kernel derived done / success from, so
+        `self.distance < reach_dis` and `is_success` can never disagree."""
         self._sync_opt()
         a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 3), dtype=torch.float32).to(self._eng.device)
-        obs, reward, done, success = self._eng.step(a)
+        obs, reward, done, success = self._eng.step(a, want_diag=True)
         self.step_counter += 1
         draw_step_unused()
-        pos, _ = self._eng.fk(self._eng.get_state()["q"])
-        packed = torch.cat([obs[0].double(), done.double(), success.double(), pos[0]]).cpu().numpy()     # one host sync
+        packed = torch.cat([obs[0].double(), done.double(), success.double(), self._eng.diag[0]]).cpu().numpy()     # one host sync
         self.terminated = bool(packed[6])
         self.is_success = bool(packed[7])
         self.robot_state = tuple(float(x) for x in packed[8:11])                                 # :271 getLinkState(...)[4]
         goal = self.object_state.astype(np.float64)                                              # :276-278 float32 cube position
         self.distance = float(np.sqrt(np.sum((np.asarray(self.robot_state) - goal) ** 2)))       # :281 (f64)
-        reward = 0.0 if self.is_success else -self.distance * 10                                 # :299-309
+        reward = float(packed[11])                                                               # :299-309, computed in f64 by the kernel
         return packed[:6].astype(np.float32), reward, self.terminated, self.is_success
 
     def close(self):

@@ -141,6 +141,7 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->ik_max_iters = 20;
   c->ik_exit_mode = 0;
   c->ik_angle_f32 = 1;
+  c->ik_tip_offset[0] = c->ik_tip_offset[1] = c->ik_tip_offset[2] = 0.0;   // the URDF link-7 frame (what getLinkState(...)[4] returns)
   c->push_success_dis = 0.05;
   c->push_cube_half = 0.02;
   c->push_eef_radius = 0.03;
@@ -168,6 +169,12 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   if (cfg->precision != 64 && cfg->precision != 32) return fail(ARMENV_EINVAL, "armenv_create: precision must be 32 or 64");
   if (cfg->task < ARMENV_TASK_REACH || cfg->task > ARMENV_TASK_PICK) return fail(ARMENV_EINVAL, "armenv_create: unknown task %d", cfg->task);
   if (cfg->ik_max_iters < 0 || cfg->ik_max_iters > 1000) return fail(ARMENV_EINVAL, "armenv_create: ik_max_iters out of range");
+  const bool tip = cfg->ik_tip_offset[0] != 0.0 || cfg->ik_tip_offset[1] != 0.0 || cfg->ik_tip_offset[2] != 0.0;
+  // the bookkeeping builds report a call's update count in a u8 (ik_updates) and fold a wave's trip maximum over 8 bits
+  if ((cfg->fence_counters || tip) && cfg->ik_max_iters > 254)
+    return fail(ARMENV_EINVAL, "armenv_create: fence_counters / ik_tip_offset need ik_max_iters <= 254 (the per-step update count is a u8)");
+  for (int k = 0; k < 3; ++k)
+    if (!std::isfinite(cfg->ik_tip_offset[k])) return fail(ARMENV_EINVAL, "armenv_create: ik_tip_offset is not finite");
   if (cfg->clamp_joint_limits < 0 || cfg->clamp_joint_limits > 2) return fail(ARMENV_EINVAL, "armenv_create: clamp_joint_limits must be 0, 1 or 2");
   if (cfg->clamp_joint_limits == 2 && !(cfg->limit_erp > 0.0 && cfg->limit_erp <= 1.0)) return fail(ARMENV_EINVAL, "armenv_create: limit_erp must be in (0, 1]");
   if (cfg->rollout_lanes_per_wave != 0 && cfg->rollout_lanes_per_wave != 32 && cfg->rollout_lanes_per_wave != 64)
@@ -184,9 +191,10 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   std::unique_ptr<ArmEnv> env(new (std::nothrow) ArmEnv());
   if (!env) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
   env->cfg = *cfg;
-  env->eng.reset(make_engine(*cfg));
+  if (tip) env->cfg.fence_counters = 1;   // the tip offset lives in the bookkeeping build of the kernels (armenv_kin.h, MODE 2)
+  env->eng.reset(make_engine(env->cfg));
   if (!env->eng) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
-  const int rc = env->eng->init(*cfg);
+  const int rc = env->eng->init(env->cfg);
   if (rc != ARMENV_OK) return rc;
   *out = env.release();
   return ARMENV_OK;
@@ -215,12 +223,14 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
 }
 
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
-                uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, void *stream) {
+                uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, double *diag_dev, void *stream) {
   ENV_ENTER(env);
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_step: NULL output buffer");
-  if (ik_updates_dev && !env->cfg.fence_counters)
-    return fail(ARMENV_ESTATE, "armenv_step: ik_updates_dev needs a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
-  StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev};
+  if ((ik_updates_dev || diag_dev) && !env->cfg.fence_counters)
+    return fail(ARMENV_ESTATE, "armenv_step: ik_updates_dev / diag_dev need a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
+  if (diag_dev && !action_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
+    return fail(ARMENV_ESTATE, "armenv_step: diag_dev is not available with a fused actor");
+  StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};
   if (!action_dev) {   // fused policy: a one-step rollout
     if (env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
       return fail(ARMENV_ESTATE, "armenv_step: action_dev is NULL and no fused policy is installed");
@@ -294,8 +304,8 @@ int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const fl
     if (env->cfg.num_envs % 64 != 0)
       return fail(ARMENV_EINVAL, "armenv_set_policy: the fused actor needs num_envs to be a multiple of 64 (full wavefronts)");
     if (env->cfg.fence_counters)
-      return fail(ARMENV_ESTATE, "armenv_set_policy: the parity-fence bookkeeping (fence_counters) is built for external actions and the "
-                                 "in-kernel random policy, not for the fused actors");
+      return fail(ARMENV_ESTATE, "armenv_set_policy: the bookkeeping builds of the kernels (fence_counters, ik_tip_offset) exist for external "
+                                 "actions and the in-kernel random policy, not for the fused actors");
     const int rc = env->eng->set_actor(W1_dev, b1_dev, W2_dev, b2_dev, W3_dev, b3_dev, armenv_obs_dim(env), action_bound,
                                        static_cast<hipStream_t>(stream));
     if (rc != ARMENV_OK) return rc;
@@ -316,18 +326,18 @@ int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float 
 
 int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,
                    uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev,
-                   uint8_t *ik_updates_dev, void *stream) {
+                   uint8_t *ik_updates_dev, double *diag_dev, void *stream) {
   ENV_ENTER(env);
   if (steps < 0) return fail(ARMENV_EINVAL, "armenv_rollout: steps < 0");
   if (steps == 0) return ARMENV_OK;
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_rollout: NULL output buffer");
   if (!actions_dev && env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
     return fail(ARMENV_ESTATE, "armenv_rollout: actions_dev is NULL and no fused policy is installed");
-  if (ik_updates_dev && !env->cfg.fence_counters)
-    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev needs a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
-  if (ik_updates_dev && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
-    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev is not available with a fused actor");
-  StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev};
+  if ((ik_updates_dev || diag_dev) && !env->cfg.fence_counters)
+    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev / diag_dev need a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
+  if ((ik_updates_dev || diag_dev) && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
+    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev / diag_dev are not available with a fused actor");
+  StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};
   return env->eng->rollout(steps, actions_dev, io, actions_out_dev, static_cast<hipStream_t>(stream));
 }
 

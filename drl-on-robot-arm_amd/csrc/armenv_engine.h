@@ -19,6 +19,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "armenv_env.h"
 
@@ -101,10 +102,14 @@ static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + b
 
 // One engine per (task, chain, precision); each task x precision pair is compiled in its own translation unit
 // (armenv_task.hip, see the Makefile) so that the kernel variants build in parallel.
-template <template <class, class, bool> class LaneT, class C, typename T> struct Engine final : EngineBase {
-  using Lane = LaneT<C, T, false>;
-  using LaneF = LaneT<C, T, true>;   // the bookkeeping build of the same lane (parity-fence counters)
-  bool fence_on = false;
+template <template <class, class, int> class LaneT, class C, typename T> struct Engine final : EngineBase {
+  using Lane = LaneT<C, T, 0>;
+  using LaneF = LaneT<C, T, 1>;   // the bookkeeping build of the same lane (parity-fence counters)
+  using LaneTip = LaneT<C, T, 2>; // the bookkeeping build with the IK evaluated at ArmEnvConfig.ik_tip_offset
+  bool fence_on = false;          // bookkeeping kernels (fence_counters, or implied by a tip offset)
+  bool tip_on = false;
+  // run f with the lane type of the handle's bookkeeping build, passed as a null pointer tag
+  template <class F> void with_book_lane(F &&f) { if (tip_on) f((LaneTip *)nullptr); else f((LaneF *)nullptr); }
   EnvParams<T> P{};
   void *pool = nullptr;
   unsigned long long *counter_totals = nullptr;
@@ -222,7 +227,9 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
     lanes_cfg = cfg.rollout_lanes_per_wave;
     ready_lanes = cfg.rollout_ready_lanes < 0 ? 0 : (cfg.rollout_ready_lanes > 64 ? 64 : cfg.rollout_ready_lanes);
     straggler_trips = cfg.rollout_straggler_trips < 0 ? 0 : cfg.rollout_straggler_trips;
-    fence_on = cfg.fence_counters != 0;
+    tip_on = cfg.ik_tip_offset[0] != 0.0 || cfg.ik_tip_offset[1] != 0.0 || cfg.ik_tip_offset[2] != 0.0;
+    fence_on = cfg.fence_counters != 0 || tip_on;
+    for (int k = 0; k < 3; ++k) P.ik.tip[k] = (T)cfg.ik_tip_offset[k];
     P.ik.fence_pivot = (T)cfg.fence_pivot;
     P.fence_z = (T)cfg.fence_z;
     for (int j = 0; j < NJ; ++j) {
@@ -260,8 +267,11 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
     const bool h = false;
     const int b = 64 * (int)std::min<int64_t>(4, std::max<int64_t>(1, ((P.n + 63) / 64 + cus - 1) / cus));
     if (fence_on) {
-      if (two_waves()) hipLaunchKernelGGL((env_step_kernel<LaneF, T, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
-      else hipLaunchKernelGGL((env_step_kernel<LaneF, T>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), io);
+      with_book_lane([&](auto *tag) {
+        using LX = std::remove_pointer_t<decltype(tag)>;
+        if (two_waves()) hipLaunchKernelGGL((env_step_kernel<LX, T, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
+        else hipLaunchKernelGGL((env_step_kernel<LX, T>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), io);
+      });
     } else {
       if (two_waves()) hipLaunchKernelGGL((env_step_kernel<Lane, T, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, io);
       else hipLaunchKernelGGL((env_step_kernel<Lane, T>), dim3(grid_for(lane_threads(h), b)), dim3(b), 0, s, params(h), io);
@@ -309,8 +319,11 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
     const bool fused_actor = !actions && (pol.kind == ARMENV_POLICY_ACTOR || pol.kind == ARMENV_POLICY_ACTOR_F16X3);
     if (ready_lanes > 0 && steps > 1 && !fused_actor) {
       if (fence_on) {
-        if (actions) launch_rollout_async<ARMENV_POLICY_EXTERNAL, LaneF>(steps, actions, io0, actions_out, s);
-        else launch_rollout_async<ARMENV_POLICY_RANDOM, LaneF>(steps, actions, io0, actions_out, s);
+        with_book_lane([&](auto *tag) {
+          using LX = std::remove_pointer_t<decltype(tag)>;
+          if (actions) launch_rollout_async<ARMENV_POLICY_EXTERNAL, LX>(steps, actions, io0, actions_out, s);
+          else launch_rollout_async<ARMENV_POLICY_RANDOM, LX>(steps, actions, io0, actions_out, s);
+        });
       } else {
         if (actions) launch_rollout_async<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
         else launch_rollout_async<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
@@ -318,8 +331,11 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
       return;
     }
     if (fence_on && !fused_actor) {   // the bookkeeping builds exist for external actions and the in-kernel random policy
-      if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL, LaneF>(steps, actions, io0, actions_out, s);
-      else launch_rollout<ARMENV_POLICY_RANDOM, LaneF>(steps, actions, io0, actions_out, s);
+      with_book_lane([&](auto *tag) {
+        using LX = std::remove_pointer_t<decltype(tag)>;
+        if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL, LX>(steps, actions, io0, actions_out, s);
+        else launch_rollout<ARMENV_POLICY_RANDOM, LX>(steps, actions, io0, actions_out, s);
+      });
       return;
     }
     if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
@@ -338,7 +354,8 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
     return ARMENV_OK;
   }
   int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) override {
-    hipLaunchKernelGGL((ik_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, tgt, q_out, iters);
+    if (tip_on) hipLaunchKernelGGL((ik_kernel<C, T, 2>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, tgt, q_out, iters);
+    else hipLaunchKernelGGL((ik_kernel<C, T>), dim3(grid_for(n, block)), dim3(block), 0, s, P, n, q, tgt, q_out, iters);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }
@@ -379,7 +396,7 @@ template <template <class, class, bool> class LaneT, class C, typename T> struct
 };
 
 
-template <template <class, class, bool> class LaneT, typename T> static EngineBase *make_task_engine(const ArmEnvConfig &cfg) {
+template <template <class, class, int> class LaneT, typename T> static EngineBase *make_task_engine(const ArmEnvConfig &cfg) {
   if (cfg.fk_path == ARMENV_FK_AUTO) {
     if (chain_matches<KukaChain>(cfg.chain)) return new (std::nothrow) Engine<LaneT, KukaChain, T>();
     if (chain_matches<DianaChain>(cfg.chain)) return new (std::nothrow) Engine<LaneT, DianaChain, T>();

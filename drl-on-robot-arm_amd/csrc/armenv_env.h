@@ -33,7 +33,7 @@ template <typename T> struct EnvParams {
   uint32_t *episode;
   int32_t *last_len;
   uint8_t *last_success;
-  unsigned long long *counters;   // [ceil(N / 64)][16]: one row per wave, summed by counters_sum_kernel on read
+  unsigned long long *counters;   // [ceil(N / 32)][16]: one row per wave (half-filled waves carry 32 envs), summed by counters_sum_kernel on read
   T *aux;  // push: [7][N] = cube xyz, target xyz, d_last;  pick: [11][N] = the same + gripper state + hold offset xyz
   T *trig; // [14][N] = cos q[7], sin q[7]: the pair every FK starts from, carried with q (see ReachLane::trig)
   int64_t n;
@@ -170,6 +170,8 @@ struct StepIO {
   uint8_t *success;
   float *terminal_obs;
   uint8_t *updates;   // nullable: DLS updates the step's IK call applied (saturated at 255): the per-step view of counters[4] / [7]
+  double *diag;       // nullable, f64 [N][4]: the step's exit frame position (the numbers its distance, reward and flags were computed
+                      // from) and its reward before the f32 store.  Like `updates` a bookkeeping-build output.
 };
 
 // goal ~ U(box): a + (b - a) * u per axis as random.uniform does (rl_reach_env.py:180-182), then the
@@ -306,8 +308,9 @@ AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint3
 
 // Per-lane state of one reach env and the body of one env step.  The single-step kernel and the T-step rollout
 // kernel both run this code: a rollout of any length is bit-identical to the same steps as separate launches (see `cq` below).
-template <class C, typename T, bool FENCE = false> struct ReachLane {
-  static constexpr bool kFence = FENCE;   // the bookkeeping build of the lane: parity-fence counts (ArmEnvConfig.fence_counters)
+template <class C, typename T, int MODE = 0> struct ReachLane {
+  static constexpr int kMode = MODE;                  // build mode (armenv_kin.h): 0 default, 1 bookkeeping, 2 bookkeeping + IK tip offset
+  static constexpr bool kFence = kFenceOf(MODE);     // the bookkeeping build of the lane: parity-fence counts (ArmEnvConfig.fence_counters)
   using M = Mth<T>;
   using Chain = C;
   static constexpr int kTask = ARMENV_TASK_REACH;
@@ -426,6 +429,9 @@ template <class C, typename T, bool FENCE = false> struct ReachLane {
     else if (dist < P.reach_dis) { reward = T(0); done = true; succ = true; }               // :303-306
     else { reward = -dist * T(10); done = false; succ = false; }                            // :307-309
     ep_ret += reward;
+    if constexpr (kFence) {
+      if (io.diag) { io.diag[4 * i] = (double)S.p[0]; io.diag[4 * i + 1] = (double)S.p[1]; io.diag[4 * i + 2] = (double)S.p[2]; io.diag[4 * i + 3] = (double)reward; }
+    }
 
     bool finite = true;
     {   // one test on the sum: a NaN or an infinity among the seven angles makes it non-finite (inf - inf = NaN), and finite
@@ -478,8 +484,8 @@ template <class C, typename T, bool FENCE = false> struct ReachLane {
     const bool small_steps = P.ik.max_dtheta <= T(0.7854);
     T diff2_prev = T(1e60);
     int updates = 0;
-    while (!ik_trip<C, T, kFence>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :244-257
-    const bool lim_hit = ik_limits<C, T, kFence>(P.chain, P.ik, q, S, cq, sq);
+    while (!ik_trip<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :244-257
+    const bool lim_hit = ik_limits<C, T, kMode>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail(P, i, io, updates, lim_hit);
     return updates;
@@ -539,8 +545,9 @@ AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&
 //     joints 0..5 receive the IK result (:343 `range(self.end_effector_index)`), so joint 7 keeps its reset value and
 //     the tool's yaw error is never corrected; the gripper (closed by getClosestPoints, :412-416) is the build's own
 //     model, see grip().
-template <class C, typename T, bool PICK, bool FENCE = false> struct CubeLane {
-  static constexpr bool kFence = FENCE;
+template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
+  static constexpr int kMode = MODE;
+  static constexpr bool kFence = kFenceOf(MODE);
   using M = Mth<T>;
   using Chain = C;
   static constexpr int kTask = PICK ? ARMENV_TASK_PICK : ARMENV_TASK_PUSH;
@@ -751,6 +758,9 @@ template <class C, typename T, bool PICK, bool FENCE = false> struct CubeLane {
     else { reward = -test * T(100); done = false; }                                             // :427-428
     const bool succ = d_cur < P.push_success_dis;                                               // :430-432
     ep_ret += reward;
+    if constexpr (kFence) {
+      if (io.diag) { io.diag[4 * i] = (double)S.p[0]; io.diag[4 * i + 1] = (double)S.p[1]; io.diag[4 * i + 2] = (double)S.p[2]; io.diag[4 * i + 3] = (double)reward; }
+    }
 
     bool finite = true;
     {   // one test on the sum: a NaN or an infinity among the seven angles makes it non-finite (inf - inf = NaN), and finite
@@ -798,15 +808,15 @@ template <class C, typename T, bool PICK, bool FENCE = false> struct CubeLane {
     const bool small_steps = P.ik.max_dtheta <= T(0.7854);
     T diff2_prev = T(1e60);
     int updates = 0;
-    while (!ik_trip<C, T, kFence>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :339-347
-    const bool lim_hit = ik_limits<C, T, kFence>(P.chain, P.ik, q, S, cq, sq);
+    while (!ik_trip<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :339-347
+    const bool lim_hit = ik_limits<C, T, kMode>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail(P, i, io, updates, lim_hit);
     return updates;
   }
 };
-template <class C, typename T, bool FENCE = false> using PushLane = CubeLane<C, T, false, FENCE>;
-template <class C, typename T, bool FENCE = false> using PickLane = CubeLane<C, T, true, FENCE>;
+template <class C, typename T, int MODE = 0> using PushLane = CubeLane<C, T, false, MODE>;
+template <class C, typename T, int MODE = 0> using PickLane = CubeLane<C, T, true, MODE>;
 
 // reset() of the envs whose mask byte is set (mask == NULL: all).
 template <class Lane, typename T>
@@ -956,7 +966,8 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     io.done = io0.done + (int64_t)t * n;
     io.success = io0.success + (int64_t)t * n;
     io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
-    if constexpr (Lane::kFence) io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; else io.updates = nullptr;
+    if constexpr (Lane::kFence) { io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; }
+    else { io.updates = nullptr; io.diag = nullptr; }
     if (actions_out) {
       float *ao = actions_out + ((int64_t)t * n + i) * 3;
       if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
@@ -1051,7 +1062,7 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
   [[maybe_unused]] uint32_t w_trips = 0, w_rounds = 0;
   for (;;) {
     if constexpr (Lane::kFence) w_trips += __ballot(!ready && t < steps) != 0ull ? 1u : 0u;
-    if (!ready && t < steps) ready = ik_trip<C, T, Lane::kFence>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps, L.minpiv);
+    if (!ready && t < steps) ready = ik_trip<C, T, Lane::kMode>(P.chain, P.ik, L.q, tgt, L.S, L.cq, L.sq, diff2_prev, updates, res2, small_steps, L.minpiv);
     const unsigned long long rb = __ballot(ready), ib = __ballot(!ready && t < steps);
     // wave-uniform: a transition round.  Count rule: `ready_lanes` lanes wait.  Straggler rule (straggler_trips > 0): every lane
     // that has spent fewer than that many trips on its step waits -- lanes on their way to the iteration cap carry on, however
@@ -1063,7 +1074,7 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
         // the next step's action is requested first: the step's tail (a few hundred instructions) covers most of the
         // load's latency before begin_step consumes it
         if (t + 1 < steps) load_action(t + 1);
-        const bool lim_hit = ik_limits<C, T, Lane::kFence>(P.chain, P.ik, L.q, L.S, L.cq, L.sq);
+        const bool lim_hit = ik_limits<C, T, Lane::kMode>(P.chain, P.ik, L.q, L.S, L.cq, L.sq);
         StepIO io;
         io.action = nullptr;
         io.obs = io0.obs + (int64_t)t * n * kObs;
@@ -1071,7 +1082,8 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
         io.done = io0.done + (int64_t)t * n;
         io.success = io0.success + (int64_t)t * n;
         io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
-        if constexpr (Lane::kFence) io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; else io.updates = nullptr;
+        if constexpr (Lane::kFence) { io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; }
+    else { io.updates = nullptr; io.diag = nullptr; }
         const uint32_t before = L.n_done;
         L.step_tail(P, i, io, updates, lim_hit);
         if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
@@ -1109,7 +1121,7 @@ __global__ __launch_bounds__(256) void fk_kernel(EnvParams<T> P, int64_t n, cons
 }
 
 // p.calculateInverseKinematics(body, 6, pos, orn, jointDamping)
-template <class C, typename T>
+template <class C, typename T, int MODE = 0>
 __global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, const double *q_in, const double *tgt_in,
                                                  double *q_out, int32_t *iters) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1118,7 +1130,7 @@ __global__ __launch_bounds__(256) void ik_kernel(EnvParams<T> P, int64_t n, cons
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = (T)q_in[7 * i + j]; });
   static_for<0, 3>([&](auto KI) { constexpr int k = KI; tgt[k] = (T)tgt_in[3 * i + k]; });
   FKState<T> S;
-  const int it = ik_move<C, T, false>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);
+  const int it = ik_move<C, T, false, false, MODE>(P.chain, P.ik, q, tgt, a, P.dv, P.box_lo, P.box_hi, S);
   static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q_out[7 * i + j] = (double)q[j]; });
   if (iters) iters[i] = it;
 }

@@ -11,6 +11,15 @@
 
 namespace armenv {
 
+// Build modes of the per-lane env code (the MODE template parameter of the lanes, ik_trip, dls_update, ik_limits):
+//   0  the default kernels;
+//   1  the bookkeeping build: parity-fence counters, LDL^T pivot minimum, per-step ik_updates / diag outputs
+//      (ArmEnvConfig.fence_counters);
+//   2  the bookkeeping build with the IK evaluated at ArmEnvConfig.ik_tip_offset instead of the URDF link-7 frame.
+// Compile-time, not run-time: a branch in the trip loop cost the default path 3 %.
+constexpr bool kFenceOf(int mode) { return mode >= 1; }
+constexpr bool kTipOf(int mode) { return mode == 2; }
+
 // Runtime chain (generic path): joint-origin translation and row-major 3x3 rotation per joint.
 template <typename T> struct ChainDev {
   T xyz[NJ][3];
@@ -36,6 +45,10 @@ template <typename T> struct IKParams {
   int32_t clamp_limits;
   int32_t pad0;
   T fence_pivot;    // an IK call whose damped system J J^T + lambda I had an LDL^T pivot below this is ill-conditioned
+  // ArmEnvConfig.ik_tip_offset: the point of link 7 (in the link-7 frame) at which the IK takes its position error and its
+  // linear Jacobian.  Read by the MODE 2 builds of the kernels only (kTipOf): the default builds are compiled for the URDF
+  // link frame itself (offset 0), where the last joint's lever arm is an exact zero and is left out.
+  T tip[3];
   // URDF joint limits: lim[0..6] lower, lim[7..13] upper, in DEVICE MEMORY (EnvCold) -- 28 scalar registers the IK loop
   // needs for its own constants otherwise (measured: +70 instructions per trip from s_mov rematerialisation and
   // v_readlane spills with the limits held as kernel arguments).  lim_min = min over joints of min(-lower, upper) (or -1
@@ -291,8 +304,13 @@ AE_DEV float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 AE_DEV double hw_rsq(double x) { return __builtin_amdgcn_rsq(x); }
 AE_DEV float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// ARMENV_EXACT_RCP / _RSQRT / _ACOS / _ROTATE: one-change builds for tests/tools/accuracy_attribution.py (make variants): each
+// replaces ONE of the kernel's fast paths by the library / IEEE operation it approximates.  Never defined in the product build.
 template <typename T>
 AE_DEV T fast_rcp(T d) {
+#ifdef ARMENV_EXACT_RCP
+  return T(1) / d;
+#endif
   T r = hw_rcp(d);
   r = Mth<T>::fma(Mth<T>::fma(-d, r, T(1)), r, r);
   if constexpr (sizeof(T) == 8) r = Mth<T>::fma(Mth<T>::fma(-d, r, T(1)), r, r);
@@ -303,6 +321,9 @@ AE_DEV T fast_rcp(T d) {
 // sqrt-then-divide pair (each a long quarter-rate sequence in f64)
 template <typename T>
 AE_DEV T fast_rsqrt(T x) {
+#ifdef ARMENV_EXACT_RSQRT
+  return T(1) / Mth<T>::sqrt(x);
+#endif
   T r = hw_rsq(x);
   const T hx = T(0.5) * x;
   r = Mth<T>::fma(Mth<T>::fma(-hx * r, r, T(0.5)), r, r);
@@ -343,6 +364,9 @@ AE_DEV void quat_from_frame(const T (&W)[9], T (&q)[4]) {
 // bookkeeping of every region on every trip and keeps the error chain out of the scheduler's reach.  ~1 ulp, and the
 // engine rounds the angle through float anyway (IKParams::angle_f32).
 AE_DEV double acos_branchfree(double x) {
+#ifdef ARMENV_EXACT_ACOS
+  return ::acos(x);
+#endif
   const double ax = ::fabs(x);
   const bool small = ax < 0.5;
   const double z = small ? x * x : ::fma(-0.5, ax, 0.5);
@@ -445,17 +469,20 @@ AE_DEV T jj_term(T a, T b, T acc) {
 // FENCE (the bookkeeping builds of the kernels, ArmEnvConfig.fence_counters): minpiv is lowered to the smallest of the six
 // LDL^T pivots.  A compile-time switch: as a run-time branch in this loop body it cost the one-launch-per-step kernel 3 %
 // with the bookkeeping OFF (A/B inside one GPU session, tests/tools/ab_time.sh).
-template <class C, typename T, bool FENCE = false>
-AE_DEV void dls_update(const FKState<T> &S, const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ], T &minpiv) {
+// pe: the point the IK works at -- S.p (MODE 0 / 1) or S.p + W tip (MODE 2, where the last joint's lever arm is a run-time value
+// and its column stays in).
+template <class C, typename T, int MODE = 0>
+AE_DEV void dls_update(const FKState<T> &S, const T (&pe)[3], const T (&e)[6], const IKParams<T> &P, T (&dth)[NJ], T &minpiv) {
   using M = Mth<T>;
+  constexpr bool FENCE = kFenceOf(MODE);
   // fk() defines the end-effector point as the LAST joint's pivot (S.p == S.pj[NJ-1], the same values), so the lever arm of
   // the last joint is x - x = +0 and its linear Jacobian column an exact zero: every term it enters adds +-0.  That column
   // is left out of the build, of J J^T and of J^T y -- 27 instructions per trip, the same bits for every finite state.
-  constexpr int NL = NJ - 1;
+  constexpr int NL = kTipOf(MODE) ? NJ : NJ - 1;
   T Jl[NL][3];
   static_for<0, NL>([&](auto II) {
     constexpr int i = II;
-    const T r0 = S.p[0] - S.pj[i][0], r1 = S.p[1] - S.pj[i][1], r2 = S.p[2] - S.pj[i][2];
+    const T r0 = pe[0] - S.pj[i][0], r1 = pe[1] - S.pj[i][1], r2 = pe[2] - S.pj[i][2];
     if constexpr (i == 0 && !C::kGeneric) {
       // z_0 = sg e_m:  (z_0 x r)_m = 0,  (z_0 x r)_(m+1) = -sg r_(m+2),  (z_0 x r)_(m+2) = +sg r_(m+1)
       constexpr int m = Axis0<C>::m, sg = Axis0<C>::sg;
@@ -601,14 +628,19 @@ AE_DEV void ik_target(const FKState<T> &S, const T (&a)[3], T dv, const T (&box_
 // minpiv (fence bookkeeping only): running minimum of the LDL^T pivots of the call's damped systems -- the damped solve
 // amplifies rounding differences by ~1 / pivot, so a call that passes through a near-singular pose (stretched elbow at the
 // edge of the arm's reach, aligned wrist) is where two implementations' trajectories start to part.
-template <class C, typename T, bool FENCE = false>
+template <class C, typename T, int MODE = 0>
 AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
                     T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps, T &minpiv) {
   using M = Mth<T>;
-  T e[6];
-  e[0] = tgt[0] - S.p[0];
-  e[1] = tgt[1] - S.p[1];
-  e[2] = tgt[2] - S.p[2];
+  T e[6], pe[3];
+  static_for<0, 3>([&](auto RI) {
+    constexpr int r = RI;
+    if constexpr (kTipOf(MODE)) pe[r] = M::fma(S.W[0 + r], P.tip[0], M::fma(S.W[3 + r], P.tip[1], M::fma(S.W[6 + r], P.tip[2], S.p[r])));
+    else pe[r] = S.p[r];
+  });
+  e[0] = tgt[0] - pe[0];
+  e[1] = tgt[1] - pe[1];
+  e[2] = tgt[2] - pe[2];
   const T diff2 = M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2]));
   const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff2_prev > res2) : !(diff2 > res2));
   if (stop) return true;
@@ -616,8 +648,11 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
   quat_from_frame<T>(S.W, qc);
   orientation_error<T>(P.tq, qc, P.angle_f32, eo);
   e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
-  dls_update<C, T, FENCE>(S, e, P, dth, minpiv);
+  dls_update<C, T, MODE>(S, pe, e, P, dth, minpiv);
   static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
+#ifdef ARMENV_EXACT_ROTATE
+  small_steps = false;
+#endif
   if (small_steps) {
     static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
   } else {
@@ -637,9 +672,10 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
 // btMultiBodyJointLimitConstraint does once per stepSimulation (erp 0.2 by default; a named, unpinned model: the first box
 // with pybullet fits one scalar).  Either way the frame is recomputed for the lanes that left the limits only (the others
 // keep their bits).
-template <class C, typename T, bool FENCE = false>
+template <class C, typename T, int MODE = 0>
 AE_DEV bool ik_limits(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], FKState<T> &S, T (&cq)[NJ], T (&sq)[NJ]) {
   using M = Mth<T>;
+  constexpr bool FENCE = kFenceOf(MODE);
   bool hit = false;
   if (P.clamp_limits || FENCE) {
     T m = M::fabs(q[0]);
@@ -666,7 +702,7 @@ AE_DEV bool ik_limits(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], F
   return hit;
 }
 
-template <class C, typename T, bool FROM_ACTION, bool START_F32 = false>
+template <class C, typename T, bool FROM_ACTION, bool START_F32 = false, int MODE = 0>
 AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&tgt)[3], const T (&a)[3], T dv,
                    const T (&box_lo)[3], const T (&box_hi)[3], FKState<T> &S, T (*p_start)[3] = nullptr,
                    T (*cq_io)[NJ] = nullptr, T (*sq_io)[NJ] = nullptr, bool *limit_hit = nullptr, bool frame_valid = false) {
@@ -689,8 +725,8 @@ AE_DEV int ik_move(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], T (&
     ik_target<T, START_F32>(S, a, dv, box_lo, box_hi, tgt);
   }
   T minpiv = T(1e30);
-  while (!ik_trip<C, T>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps, minpiv)) {}
-  const bool hit = ik_limits<C, T>(ch, P, q, S, cq, sq);
+  while (!ik_trip<C, T, MODE>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps, minpiv)) {}
+  const bool hit = ik_limits<C, T, MODE>(ch, P, q, S, cq, sq);
   if (limit_hit) *limit_hit = hit;
   if (cq_io) { static_for<0, NJ>([&](auto JI) { constexpr int j = JI; (*cq_io)[j] = cq[j]; (*sq_io)[j] = sq[j]; }); }
   return it;

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define ARMENV_NJ 7
-#define ARMENV_ABI_VERSION 3
+#define ARMENV_ABI_VERSION 4
 
 enum {
   ARMENV_OK = 0,
@@ -114,7 +114,8 @@ typedef struct ArmEnvConfig {
                               included: the IK call ran to ik_max_iters without converging (the update oscillates), or one of
                               its damped systems was ill-conditioned (fence_pivot) -- in armenv_counters out[5] / out[6] / out[7] /
                               out[8].  Every parity claim is fenced by these four rates (bench.py reports them for its
-                              workloads).  0 (default): no bookkeeping in the step. */
+                              workloads).  0 (default): no bookkeeping in the step.  Needs ik_max_iters <= 254 (the per-step update
+                              count is reported in a u8, the wave's trip maximum folded over 8 bits). */
 
   /* push task, /root/reference/envs/rl_push_env.py (the pick task, envs/rl_pick_env.py, shares all six) */
   double push_success_dis; /* 0.05  :422 (pick :425) */
@@ -137,6 +138,14 @@ typedef struct ArmEnvConfig {
                                  implementations start to part */
   double limit_erp;           /* clamp_joint_limits == 2: share of a joint-limit violation removed per step (Bullet's default
                                  constraint error-reduction parameter, 0.2) */
+  double ik_tip_offset[3];    /* The point of link 7, in the link-7 frame, at which calculateInverseKinematics (rl_reach_env.py:244-250)
+                                 takes its position error and its linear Jacobian.  Default (0,0,0): the URDF link frame, the point
+                                 p.getLinkState(body, 6)[4] reports (:237).  (0,0,0.02) is the KUKA link-7 inertial origin: Bullet's
+                                 multibody link frames sit at the centre of mass, and whether pybullet 3.0.6 runs the IK there is
+                                 the one unknown of the restatement that had no switch before ABI 4.  The
+                                 target clip (:231-242), the reward and the observation always use the link frame.  A non-zero
+                                 offset selects the bookkeeping build of the kernels (as fence_counters = 1 does; it is a fitting
+                                 switch for tests/tools/fit_bullet.py, not a tuned path) and excludes the fused actors. */
 
   /* armenv_rollout scheduling.  0: lockstep -- the lanes of a wavefront walk through every step together (a step costs the
    * wave its slowest lane's IK trips).  k in 1..64: lane-asynchronous -- a lane whose IK has stopped waits until k lanes of
@@ -201,10 +210,13 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
  * terminal_obs_dev (nullable, f32 [N][obs_dim]) receives the observation of this step before any
  * auto-reset; with auto_reset the obs of a finished env is its next episode's first observation.
  * ik_updates_dev (nullable, u8 [N]) receives the number of DLS updates the step's calculateInverseKinematics call
- * (:244-250) applied, saturated at 255: ik_max_iters means the call did not converge (the cap term of the parity fence).
- * Diagnostics: only on a handle created with fence_counters = 1 (ARMENV_ESTATE otherwise). */
+ * (:244-250) applied: ik_max_iters means the call did not converge (the cap term of the parity fence).
+ * diag_dev (nullable, f64 [N][4]) receives what _reward (:267-309) computed in the reference's number type before anything was
+ * rounded to f32: [0..2] the end-effector position of getLinkState(...)[4] (:271) -- the very numbers this step's distance,
+ * done and success flags come from -- and [3] the reward as a double (the reference returns a Python float).
+ * ik_updates_dev and diag_dev are diagnostics: only on a handle created with fence_counters = 1 (ARMENV_ESTATE otherwise). */
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
-                uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, void *stream);
+                uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, double *diag_dev, void *stream);
 
 /* Replaces the rollout inner loop of /root/reference/main.py:108-128 (take_action -> noise -> step -> store) for
  * `steps` consecutive env steps of all N envs in ONE kernel launch; the env state stays in registers between steps.
@@ -214,13 +226,14 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
  *                NULL: the fused policy installed with armenv_set_policy produces the actions in-kernel.
  *   obs_dev f32 [steps][N][obs_dim], reward_dev f32 [steps][N], done_dev / success_dev u8 [steps][N]: row t holds
  *   what armenv_step would have returned at step t.  actions_out_dev (nullable, f32 [steps][N][3]) receives the
- *   actions taken; terminal_obs_dev (nullable) and ik_updates_dev (nullable, u8 [steps][N]) as in armenv_step, per step.
+ *   actions taken; terminal_obs_dev (nullable), ik_updates_dev (nullable, u8 [steps][N]) and diag_dev (nullable, f64 [steps][N][4])
+ *   as in armenv_step, per step.
  * Waves never synchronise inside the launch, so an env that needs extra IK iterations in one step stalls only its own
  * wavefront for that step (lockstep schedule) or only itself (lane-asynchronous schedule, ArmEnvConfig.rollout_ready_lanes):
  * throughput follows the mean IK cost per step, not the per-launch maximum. */
 int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *obs_dev, float *reward_dev,
                    uint8_t *done_dev, uint8_t *success_dev, float *actions_out_dev, float *terminal_obs_dev,
-                   uint8_t *ik_updates_dev, void *stream);
+                   uint8_t *ik_updates_dev, double *diag_dev, void *stream);
 
 /* Replaces p.getLinkState(body, 6)[4], [5] (call sites rl_reach_env.py:202,237,271): world position
  * f64 [n][3] and orientation quaternion xyzw f64 [n][4] (nullable) of the link-7 frame for joint

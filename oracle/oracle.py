@@ -86,7 +86,7 @@ class OrcConfig(C.Structure):
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
         ("clamp_joint_limits", C.c_int32), ("pad0", C.c_int32), ("lim_lo", C.c_double * NJ), ("lim_hi", C.c_double * NJ),
-        ("fence_z", C.c_double), ("limit_erp", C.c_double), ("fence_pivot", C.c_double),
+        ("fence_z", C.c_double), ("limit_erp", C.c_double), ("fence_pivot", C.c_double), ("ik_tip_offset", C.c_double * 3),
     ]
 
 
@@ -152,6 +152,7 @@ def default_config(task="reach", robot="kuka"):
     c.fence_z = 0.05
     c.limit_erp = 0.2          # Bullet's default constraint ERP; read by clamp_joint_limits == 2 only
     c.fence_pivot = 1e-2       # conditioning term of the parity fence
+    c.ik_tip_offset[:] = [0.0, 0.0, 0.0]      # the URDF link-7 frame (getLinkState(...)[4])
     c.task = {"reach": 0, "push": 1, "pick": 2}[task]
     c.dv = 0.02 if task == "reach" else 0.08
     c.reach_dis = 0.01

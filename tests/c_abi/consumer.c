@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
   CHECK_HIP(hipMemcpy(act, h_act, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
 
   CHECK_ENV(armenv_reset(env, NULL, obs, NULL));
-  for (int t = 0; t < steps; ++t) CHECK_ENV(armenv_step(env, act, obs, rew, done, succ, NULL, NULL, NULL));
+  for (int t = 0; t < steps; ++t) CHECK_ENV(armenv_step(env, act, obs, rew, done, succ, NULL, NULL, NULL, NULL));
   CHECK_HIP(hipDeviceSynchronize());
 
   float h_obs[6];
@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
          (unsigned long long)c[2], (unsigned long long)c[3], armenv_kernel_name(env));
 
   /* error path: a NULL output buffer is refused with a message, nothing aborts */
-  if (armenv_step(env, act, NULL, rew, done, succ, NULL, NULL, NULL) != ARMENV_EINVAL || armenv_last_error()[0] == '\0') return 5;
+  if (armenv_step(env, act, NULL, rew, done, succ, NULL, NULL, NULL, NULL) != ARMENV_EINVAL || armenv_last_error()[0] == '\0') return 5;
   armenv_destroy(env);
   hipFree(obs); hipFree(act); hipFree(rew); hipFree(done); hipFree(succ);
   free(h_act); free(h_rew);

@@ -14,8 +14,14 @@ The first two are about Bullet; the last two are about ANY pair of implementatio
 oracle and this engine included (the oracle's own primal and dual solve forms part ways there: tests/tools/fence_study.py).
 So the free-running tests below follow every env of BASELINE config 4 (push, 32 768 envs) and of the pick task at the same
 size under the reference's own exploration noise (main.py:484, unclipped N(0, 0.392)) for six 100-step launches and 501-step
-episodes, and assert 100 % agreement with the oracle on every env-step whose env has had no capped or ill-conditioned IK
-call since its last reset.
+episodes, and assert in two tiers:
+  strict      100 % agreement with the oracle (observation 1e-4, flags, IK update counts) on every env-step whose env has had no
+              capped or ill-conditioned IK call since its last reset (FenceBook);
+  task space  on EVERY env-step whose env is still in the same episode as its oracle twin -- the excluded ones included -- the
+              observation stays within a loose bound, all but a stated share within 1e-4, and wherever the observations agree the
+              done / success flags do: past an ill-conditioned call the two sides part in the arm's null space (radians in q),
+              not in what the task observes (tests/tools/fence_study.py).  Pick's capped calls do not converge at all (target
+              out of reach): there the end-effector itself parts, and the tier states how much of the run that touches.
 """
 import numpy as np
 import pytest
@@ -48,6 +54,9 @@ class FenceBook:
         self.clean = np.ones(n, dtype=bool)
         self.checked = self.tainted = self.desynced = self.total = 0
         self.cap_calls = self.cond_calls = 0
+        # task-space tier: every env-step of an env that is in step with its twin (clean or not)
+        self.t2_steps = self.t2_within_1e4 = self.t2_within_1e3 = self.t2_flags = 0
+        self.t2_worst = self.t2_worst_eef = 0.0
 
     def comparable(self, iters_o, minpiv_o):
         """mask of the envs to compare at this step (call before `advance`)"""
@@ -60,6 +69,18 @@ class FenceBook:
         self.tainted += int((self.sync & ~self.clean).sum())
         self.desynced += int((~self.sync).sum())
         return chk
+
+    def task_space(self, d_obs, flags_differ, d_eef=None):
+        """second tier (call before `advance`): d_obs = max |obs_gpu - obs_oracle| per env (d_eef: over the end-effector part
+        only), flags_differ = done or success differ"""
+        m = self.sync
+        if d_eef is not None:
+            self.t2_worst_eef = max(self.t2_worst_eef, float(d_eef[m].max(initial=0.0)))
+        self.t2_steps += int(m.sum())
+        self.t2_within_1e4 += int((d_obs[m] < 1e-4).sum())
+        self.t2_within_1e3 += int((d_obs[m] < 1e-3).sum())
+        self.t2_worst = max(self.t2_worst, float(d_obs[m].max(initial=0.0)))
+        self.t2_flags += int((flags_differ & m & (d_obs < 1e-4)).sum())
 
     def advance(self, done_g, done_o):
         self.sync &= done_g == done_o
@@ -97,7 +118,9 @@ def _free_run(envs, O, kuka, task, n, launches, R, sigma, seed, max_steps=500, s
             done_o = done_o.astype(bool)
             d = np.abs(obs_g[t] - obs_o).max(1)
             worst_obs = max(worst_obs, float(d[chk].max(initial=0.0)))
-            flag_mismatch += int(((done_g[t] != done_o) | (succ_g[t] != succ_o.astype(bool)))[chk].sum())
+            fl = (done_g[t] != done_o) | (succ_g[t] != succ_o.astype(bool))
+            flag_mismatch += int(fl[chk].sum())
+            book.task_space(d, fl, np.abs(obs_g[t][:, :3] - obs_o[:, :3]).max(1))
             same = chk & (done_g[t] == done_o)
             worst_rew = max(worst_rew, float(np.abs(rew_g[t].astype(np.float64) - rew_o)[same].max(initial=0.0)))
             upd_mismatch += int((upd_g[t].astype(np.int32) != iters)[chk].sum())
@@ -116,29 +139,41 @@ def _report(task, r):
             f"({100.0 * b.desynced / b.total:.3f} %); capped calls oracle {b.cap_calls} gpu {r['gpu_cap']} (counter {c['cap_steps']}), "
             f"ill-conditioned calls oracle {b.cond_calls} gpu counter {c['illcond_steps']}; worst |obs| {r['worst_obs']:.2e} "
             f"worst |reward| {r['worst_rew']:.2e}; IK update counts differing {r['upd_mismatch']}; flags differing {r['flag_mismatch']}; "
-            f"episodes gpu {r['ep_g']} oracle {r['ep_o']}")
+            f"episodes gpu {r['ep_g']} oracle {r['ep_o']} || task-space tier: {b.t2_steps} env-steps ({100.0 * b.t2_steps / b.total:.3f} %), "
+            f"within 1e-4 {100.0 * b.t2_within_1e4 / max(1, b.t2_steps):.4f} %, within 1e-3 {100.0 * b.t2_within_1e3 / max(1, b.t2_steps):.4f} %, "
+            f"worst |obs| {b.t2_worst:.2e} (end-effector part {b.t2_worst_eef:.2e}), flags differing where obs agree {b.t2_flags}")
 
 
-def test_push_config4_free_running_vs_oracle(envs, O, kuka, record_property):
+@pytest.mark.parametrize("seed", [6, 16, 26])
+def test_push_config4_free_running_vs_oracle(envs, O, kuka, record_property, seed):
     """BASELINE config 4 at its own size: rl_push_env, 32 768 envs, train_push_with_TD3's exploration noise (main.py:484),
-    501-step episodes (rl_push_env.py:418), 6 x armenv_rollout(100) against push_step_autoreset.  Every env that has had no
-    capped or ill-conditioned IK call since its last reset: observation (eef, cube, target) within 1e-4 at every step,
-    identical done / success flags, reward within 2e-2 (= -100 x the change of a distance between two positions that are
-    within 1e-4), the same IK update counts.  Matches /root/reference/envs/rl_push_env.py:310-356."""
+    501-step episodes (rl_push_env.py:418), 6 x armenv_rollout(100) against push_step_autoreset, three seeds.
+    Strict tier -- every env that has had no capped or ill-conditioned IK call since its last reset: observation (eef, cube,
+    target) within 1e-4 at every step, identical done / success flags, reward within 2e-2 (= -100 x the change of a distance
+    between two positions that are within 1e-4), the same IK update counts.
+    Task-space tier -- EVERY env-step (the excluded ones too; nothing is out of step on this task): end-effector within 1e-3
+    (measured 3e-4 .. 4e-4 on the three seeds), the whole observation within 1e-4 on 99.9 % of them, no flag differing where
+    the observations agree.  The cube part of the observation has no per-step bound: the build-defined contact model is
+    discontinuous (the tool sphere touches the cube or misses it), so an end-effector difference of 1e-4 at a grazing contact
+    moves the cube by centimetres on one side only -- 3 to 4 env-steps per million.
+    Matches /root/reference/envs/rl_push_env.py:310-356."""
     n = 32768
-    r = _free_run(envs, O, kuka, "push", n, 6, 100, 0.4 * 0.98, seed=6)
-    msg = _report("push", r)
+    r = _free_run(envs, O, kuka, "push", n, 6, 100, 0.4 * 0.98, seed=seed)
+    msg = _report("push seed %d" % seed, r)
     print(msg); record_property("fence", msg)
     b = r["book"]
     assert r["worst_obs"] < 1e-4 and r["flag_mismatch"] == 0, msg
     assert r["worst_rew"] < 2e-2, msg
     assert r["upd_mismatch"] <= 1e-4 * b.checked, msg            # a residual within rounding of 1e-4 may flip one trip
-    assert b.checked >= 0.7 * b.total, msg                      # 0.57 % of push's IK calls are ill-conditioned (the table-height corners of the box)
+    assert b.checked >= 0.72 * b.total, msg                     # 0.57 % of push's IK calls are ill-conditioned (the table-height corners of the box)
     assert r["counters"]["cap_steps"] == r["gpu_cap"], msg      # the counter is the sum of the per-step view
     assert abs(r["gpu_cap"] - b.cap_calls) <= max(8, 0.05 * b.cap_calls), msg
     assert abs(r["counters"]["illcond_steps"] - b.cond_calls) <= max(8, 0.05 * b.cond_calls), msg
     assert r["ep_g"] >= n and abs(r["ep_g"] - r["ep_o"]) <= 1e-3 * r["ep_o"], msg
     assert r["counters"]["nonfinite"] == 0
+    # task-space tier over 100 % of the env-steps
+    assert b.t2_steps >= 0.9999 * b.total, msg
+    assert b.t2_worst_eef < 1e-3 and b.t2_within_1e4 >= 0.999 * b.t2_steps and b.t2_within_1e3 >= 0.9999 * b.t2_steps and b.t2_flags == 0, msg
 
 
 def test_pick_32768_free_running_vs_oracle(envs, O, kuka, record_property):
@@ -155,7 +190,13 @@ def test_pick_32768_free_running_vs_oracle(envs, O, kuka, record_property):
     assert r["worst_obs"] < 1e-4 and r["flag_mismatch"] == 0, msg
     assert r["worst_rew"] < 2e-2, msg
     assert r["upd_mismatch"] <= 1e-4 * b.checked, msg
-    assert b.checked >= 0.25 * b.total, msg                     # the comparison covers the head of every episode
+    assert b.checked >= 0.58 * b.total, msg                     # the comparison covers the head of every episode
+    # task-space tier: every env-step of an env still in the same episode as its twin.  A capped call does not converge (the
+    # target is out of the arm's reach with the tool orientation asked for): twenty oscillating updates end centimetres apart
+    # on the two sides, and the env carries that offset to its next reset -- so the tier states what share of the run agrees
+    # (thresholds set from the measured line, recorded in profiles/r04_fence_free_running.txt) instead of a per-step bound
+    assert b.t2_steps >= 0.995 * b.total, msg
+    assert b.t2_within_1e4 >= 0.80 * b.t2_steps and b.t2_flags <= 1e-5 * b.t2_steps, msg
     assert r["counters"]["cap_steps"] == r["gpu_cap"], msg
     assert abs(r["gpu_cap"] - b.cap_calls) <= 0.05 * b.cap_calls, msg       # the cap RATE is a property of the workload
     assert abs(r["counters"]["illcond_steps"] - b.cond_calls) <= 0.05 * b.cond_calls, msg

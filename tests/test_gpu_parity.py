@@ -1139,12 +1139,16 @@ def test_pick_step_teacher_forced(envs, O, kuka, precision):
     e.close()
 
 
-def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka):
+@pytest.mark.parametrize("sigma", [0.4 * 0.98, 0.1])
+def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka, sigma):
     """Free-running pick episodes with auto-reset (time-outs at 25 steps; scripted envs finish with +100) against
     the oracle, and the rollout kernel against step launches bit for bit.  The random envs act with the reference's own
     exploration noise (main.py:552: N(0, 0.392), unclipped); some of them wander to the top of the 0.807 m box within 15
     steps, where the IK runs into its 20-iteration cap -- the cap term of the parity fence (tests/test_gpu_fence.py): an
-    env is left out of the comparison from a capped call to its next reset, every other env-step agrees."""
+    env is left out of the comparison from a capped call to its next reset, every other env-step agrees; an env that IS left
+    out still stays within a loose bound of its twin while both are in the same episode (a divergence that starts at a
+    near-singular pose for any other reason than the fence's -- a pivot-ordering bug, say -- would break that bound).
+    sigma = 0.1: the same run with gentle exploration, where no call is capped and NO env is masked."""
     from test_gpu_fence import FenceBook
     n, T = 256, 80
     rng = np.random.default_rng(91)
@@ -1160,8 +1164,9 @@ def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka):
     n_done = n_succ = 0
     book = FenceBook(n, 20, cfg.fence_pivot)
     iters, minpiv = np.zeros(n, dtype=np.int32), np.zeros(n)
+    loose_worst, n_masked = 0.0, 0
     for t in range(T):
-        a = _pick_actions(obs_r, st.aux, rng=rng, scripted=scripted)
+        a = _pick_actions(obs_r, st.aux, rng=rng, scripted=scripted, sigma=sigma)
         acts.append(a)
         obs, rew, done, succ = e.step(torch.from_numpy(a).to(DEV), want_terminal_obs=True, want_ik_updates=True)
         obs_r, rew_r, done_r, succ_r, term_r = O.pick_step_autoreset(kuka, cfg, st, a, seed=12, iters=iters, minpiv=minpiv)
@@ -1170,10 +1175,19 @@ def test_pick_trajectory_autoreset_and_rollout(envs, O, kuka):
         assert np.array_equal(_np(e.ik_updates)[chk], iters[chk]), t
         assert np.abs(_np(obs) - obs_r)[chk].max() < 1e-5 and np.abs(_np(e.terminal_obs) - term_r)[chk].max() < 1e-5, t
         assert np.abs(_np(rew) - rew_r)[chk].max() < 1e-3, t
+        masked = book.sync & ~chk                     # excluded by the fence, still in the same episode as the twin
+        loose_worst = max(loose_worst, float(np.abs(_np(obs) - obs_r)[masked].max(initial=0.0)))
+        n_masked += int(masked.sum())
         n_done += int(done_r.sum()); n_succ += int((rew_r == 100).sum())
         book.advance(_np(done), done_r.astype(bool))
     assert n_done >= 3 * n and n_succ >= n // 2
-    assert book.checked >= 0.9 * book.total and book.cap_calls > 0, (book.checked, book.total, book.cap_calls)
+    if sigma < 0.2:       # gentle exploration: nothing capped, (next to) nothing ill-conditioned: (nearly) every env compared at every step
+        assert book.cap_calls == 0 and book.checked >= 0.99 * book.total, (book.cap_calls, book.cond_calls, book.checked, book.total)
+    else:
+        assert book.checked >= 0.9 * book.total and book.cap_calls > 0, (book.checked, book.total, book.cap_calls)
+        # a capped call leaves the two sides a few cm apart at most (the arm is at the edge of its reach, twenty clamped
+        # updates each): bounded, not skipped
+        assert n_masked > 0 and loose_worst < 0.15, (n_masked, loose_worst)
     s = e.get_state()
     ok = book.sync & book.clean
     assert np.abs(_np(s["aux"])[ok, :11] - st.aux[ok, :11]).max() < 1e-6 and np.array_equal(_np(s["step"])[book.sync], st.step[book.sync])

@@ -37,14 +37,16 @@ def test_struct_layout_matches_header():
 int main(void){
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(ArmEnvConfig), sizeof(ArmEnvChain), offsetof(ArmEnvConfig, seed),
          offsetof(ArmEnvConfig, q_init), offsetof(ArmEnvConfig, push_success_dis), offsetof(ArmEnvConfig, chain));
-  printf("%zu\n", offsetof(ArmEnvConfig, pick_gripper_length));
+  printf("%zu %zu %zu\n", offsetof(ArmEnvConfig, pick_gripper_length), offsetof(ArmEnvConfig, ik_tip_offset),
+         offsetof(ArmEnvConfig, rollout_ready_lanes));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     want = [C.sizeof(L.ArmEnvConfig), C.sizeof(L.ArmEnvChain), L.ArmEnvConfig.seed.offset, L.ArmEnvConfig.q_init.offset,
-            L.ArmEnvConfig.push_success_dis.offset, L.ArmEnvConfig.chain.offset, L.ArmEnvConfig.pick_gripper_length.offset]
+            L.ArmEnvConfig.push_success_dis.offset, L.ArmEnvConfig.chain.offset, L.ArmEnvConfig.pick_gripper_length.offset,
+            L.ArmEnvConfig.ik_tip_offset.offset, L.ArmEnvConfig.rollout_ready_lanes.offset]
     assert [int(x) for x in out] == want
 
 

@@ -162,6 +162,55 @@ def test_ik_postconditions(O, kuka, mode):
     assert hist.max() <= 20
 
 
+@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("off", [(0.0, 0.0, 0.02), (0.01, -0.02, 0.03)])
+def test_ik_tip_offset_switch(O, kuka, off, form):
+    """OrcConfig.ik_tip_offset: the IK's position error and linear Jacobian are taken at the point p + R * offset of link 7
+    ((0,0,0.02) = the KUKA link-7 inertial origin, where Bullet's multibody keeps its link frame; (0,0,0) = the URDF link
+    frame getLinkState(...)[4] reports, /root/reference/envs/rl_reach_env.py:237,244-250).  Post-conditions: THAT point ends
+    within the residual of the target, the link frame ends offset from it by R * offset, the tool orientation is still the
+    target quaternion, a zero offset changes no bit, and the primal and dual solve forms agree."""
+    rng = np.random.default_rng(11)
+    n = 512
+    cfg0 = O.default_config(); cfg0.ik_form = form
+    cfg = O.default_config(); cfg.ik_form = form; cfg.ik_tip_offset[:] = list(off)
+    st = O.ReachState(n); O.reach_reset(kuka, cfg0, st, seed=2)
+    for _ in range(4):
+        O.reach_step(kuka, cfg0, st, np.clip(rng.normal(0, 0.686, (n, 3)), -0.7, 0.7))
+    q0 = st.q.copy()
+    p0, _ = O.fk(kuka, q0)
+    tgt = p0 + rng.normal(0, 0.01, (n, 3))
+    q1, it1 = O.ik(kuka, cfg, q0, tgt)
+    for _ in range(2):                       # settle the one-update-past-the-test exit of Bullet's loop
+        q1, _ = O.ik(kuka, cfg, q1, tgt)
+    o = np.array(off)
+    tip = np.empty((n, 3)); quat = np.empty((n, 4))
+    for i in range(n):
+        p, R, _, _ = O.fk_full(kuka, q1[i])
+        tip[i] = p + R @ o
+    _, quat = O.fk(kuka, q1)
+    assert np.linalg.norm(tip - tgt, axis=1).max() < 1e-4
+    p1, _ = O.fk(kuka, q1)
+    assert np.abs(np.linalg.norm(p1 - tgt, axis=1) - np.linalg.norm(o)).max() < 1e-4
+    qt = np.array(cfg.target_quat[:])
+    assert np.minimum(np.abs(quat - qt).max(1), np.abs(quat + qt).max(1)).max() < 1e-4
+    # the switch at zero is the old code path, bit for bit
+    z = O.default_config(); z.ik_form = form; z.ik_tip_offset[:] = [0.0, 0.0, 0.0]
+    qa, ita = O.ik(kuka, cfg0, q0, tgt); qb, itb = O.ik(kuka, z, q0, tgt)
+    assert np.array_equal(qa, qb) and np.array_equal(ita, itb)
+    # and the other solve form reaches the same joints
+    other = O.default_config(); other.ik_form = 1 - form; other.ik_tip_offset[:] = list(off)
+    qo, ito = O.ik(kuka, other, q0, tgt)
+    qs, its = O.ik(kuka, cfg, q0, tgt)
+    same = ito == its
+    assert same.mean() > 0.99 and np.abs(qo - qs)[same].max() < 1e-6
+    # (0,0,0.02) lies on joint 7's axis: the IK's working point does not move with q7 either
+    if off == (0.0, 0.0, 0.02):
+        q2 = q1.copy(); q2[:, 6] += 0.7
+        p2 = np.array([O.fk_full(kuka, q2[i])[0] + O.fk_full(kuka, q2[i])[1] @ o for i in range(8)])
+        assert np.abs(p2 - tip[:8]).max() < 1e-12
+
+
 def test_ik_iteration_cap(O, kuka):
     cfg = O.default_config(); cfg.ik_max_iters = 2
     q, it = O.ik(kuka, cfg, O.INIT_Q, [0.3, 0.2, 0.1])

@@ -83,14 +83,15 @@ def short_name(demangled):
     if not m:
         return demangled.split("(")[0]
     kern, targs = m.group(1), m.group(2)
-    # ReachLane<Chain, T, FENCE>, CubeLane<Chain, T, PICK, FENCE>: FENCE = the bookkeeping build of the lane (parity-fence counters)
-    lane, fence = "", False
-    m3 = re.search(r"ReachLane<[^,<>]+, \w+, (true|false)>", targs)
-    m4 = re.search(r"CubeLane<[^,<>]+, \w+, (true|false), (true|false)>", targs)
+    # ReachLane<Chain, T, MODE>, CubeLane<Chain, T, PICK, MODE>: MODE 1 = the bookkeeping build of the lane (parity-fence counters),
+    # 2 = the bookkeeping build with the IK at ArmEnvConfig.ik_tip_offset
+    lane, mode = "", 0
+    m3 = re.search(r"ReachLane<[^,<>]+, \w+, (\d)>", targs)
+    m4 = re.search(r"CubeLane<[^,<>]+, \w+, (true|false), (\d)>", targs)
     if m3:
-        lane, fence = "reach", m3.group(1) == "true"
+        lane, mode = "reach", int(m3.group(1))
     elif m4:
-        lane, fence = ("pick" if m4.group(1) == "true" else "push"), m4.group(2) == "true"
+        lane, mode = ("pick" if m4.group(1) == "true" else "push"), int(m4.group(2))
     elif "ReachLane" in targs:
         lane = "reach"
     elif "CubeLane" in targs:
@@ -117,8 +118,8 @@ def short_name(demangled):
                 parts.append("w" + m2.group(2))
     if kern == "actor_kernel":
         parts.append(targs.replace(", ", "_"))
-    if fence:
-        parts.append("fence")
+    if mode:
+        parts.append("fence" if mode == 1 else "tip")
     return "_".join(parts)
 
 
