@@ -14,9 +14,12 @@ MI355X ramps for ~30 ms, tests/tools/clock_ramp.py).  Two launch shapes run the 
                  per-step outputs written to [R][N][...] buffers (the trajectory of R armenv_step calls);
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
                  beside the headline and reported under "step_api".
-Timing: W untimed steps, then barrier + synchronise, the clock, EXACTLY K steps, stream-synchronise, the clock; the closing
-barrier follows.  `value` = all ranks' env-steps / MAX over ranks of that wall time; `value_kernel` = the same steps / MAX over
-ranks of the kernels' own time (HIP events on the launch stream).  Rank 0 prints ONE JSON line; besides the headline it carries
+Timing: W untimed steps, then barrier + synchronise, the clock, EXACTLY K steps, synchronise (incl. the logging all-gather of a
+multi-rank run) + barrier, the clock.  `value` = all ranks' env-steps / MAX over ranks of that wall time; `value_steps` = the same
+with each rank's clock stopped when its own launch stream is idle (no collective, no barrier); `value_kernel` = the same steps /
+MAX over ranks of the kernels' own time (HIP events on the launch stream).  Single-GPU runs repeat the identical region 15 more
+times on fresh action rows and report the spread (value_median / value_min / value_max, launch_us_samples) beside the
+contract's first region.  Rank 0 prints ONE JSON line; besides the headline it carries
 short legs for the other single-GPU BASELINE configs (config3_actor_f32, config3_actor_f16x3, config4_push).
 The CPU oracle is timed beside it (rank 0, N=1 only) on a bounded sample -- one thread, then every core the process may
 use -- as a baseline, never as the thing measured.  A short extra leg on a second handle with the parity-fence counters on
@@ -79,7 +82,7 @@ F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X f64 vector (FMA = 2 flop), 1/2 of the 15
 IO_BYTES = 12 + 24 + 4 + 1 + 1                 # action in; obs, reward, done, success out
 # q, (cos q, sin q), ep_return read + written; goal read; step read + written
 STATE_BYTES = {64: 2 * (56 + 112 + 8) + 12 + 2 * 4, 32: 2 * (28 + 56 + 4) + 12 + 2 * 4}
-F64_ISSUE_CYCLES_ONE_WAVE = 6.6   # measured issue interval of f64 vector instructions from ONE wave (nominal pipe rate: 4)
+F64_ISSUE_CYCLES_ONE_WAVE = 6.6   # issue interval of f64 vector instructions from ONE wave (nominal pipe rate: 4): a builder probe of round 3, a constant here
 # algorithmic flops of the f64/f32 reach step: per IK update and per FK-only exit trip
 FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + residual + per-step sincos/reward
 
@@ -188,7 +191,8 @@ def rooflines(task, policy, precision, n, steps_per_launch, launch_us, updates, 
         # the pipe's 4-cycle rate needs several waves per SIMD; the env kernels run one wave per SIMD (two in large_batch: 5.8)
         valu["one_wave_per_simd"] = {"cycles_per_f64_instruction": F64_ISSUE_CYCLES_ONE_WAVE, "peak": vpeak * 4.0 / F64_ISSUE_CYCLES_ONE_WAVE,
                                      "frac": tf / (vpeak * 4.0 / F64_ISSUE_CYCLES_ONE_WAVE),
-                                     "source": "tests/tools/exp/valu_f64_rate_probe.hip, profiles/r03_valu_f64_rate_probe.txt"}
+                                     "source": "builder probe of round 3 (tests/tools/exp/valu_f64_rate_probe.hip, profiles/r03_valu_f64_rate_probe.txt), "
+                                               "NOT measured in this run; the nominal peak above is the creditable one"}
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_key": key, "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
             "binding_bound": "valu", "valu": valu}
@@ -437,6 +441,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--gather-every", type=int, default=100, help="steps between episode-return all-gathers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeat-regions", type=int, default=15,
+                    help="single-GPU runs: after the contract's timed region, the identical region this many more times on fresh "
+                         "action rows -> value_median / value_min / value_max / launch_us_samples (0 = skip)")
     ap.add_argument("--state-digest", action="store_true",
                     help="add config.state_digest: per rank, the sha256 of the joint angles of its envs right after the timed "
                          "region (tests: rank shards reproduce the single-handle trajectory)")
@@ -578,41 +585,56 @@ def main():
             do_gather()              # host work under the running kernels; its device work is behind ev1 / on the side stream
         evs.synchronize(1)           # the K steps are done when it returns
         td = p()
-        # The contract's closing bracket: device work of the K steps finished on this rank (clock stops), then the barrier.  The
-        # logging all-gather runs on a side stream and is NOT part of the K steps: it is waited for after the clock stops and its
-        # latency reported separately; a device-wide synchronize here would put it back on the critical path.
-        evs.stream_synchronize()     # the launch stream is idle: the closing synchronise of the bracket
-        wall = p() - t0              # this rank's K steps, synchronise to synchronise; the job's time is the MAX over ranks
+        # The K steps are done on this rank when its launch stream is idle (wall_steps).  The contract's closing bracket is a device
+        # synchronise + barrier: with several ranks that also waits for the logging all-gather on the side stream and for the
+        # slowest rank -- `value` is computed from THAT clock (as in rounds 1-2: the collective belongs to the region it is issued
+        # in), the rank-local figure is reported beside it as value_steps.
+        evs.stream_synchronize()
+        wall_steps = p() - t0
         te = p()
         if world > 1:
-            dist.barrier()           # closes the bracket; every rank started behind the opening barrier, so max-over-ranks of the
-        tg = p()                     # local walls IS the whole job's time and the barrier's own latency (host_us.barrier) is not work
+            gather.result()          # orders the launch stream behind the collective ...
+            torch.cuda.synchronize(dev)   # ... and the device synchronise of the bracket waits for it
+        tf = p()
         if world > 1:
-            gather.result()
-        torch.cuda.synchronize(dev)
+            dist.barrier()
+        wall = p() - t0              # barrier + synchronise to synchronise + barrier: the contract's clock
+        tg = p()
         host_us.update(event0_record=(ta - t0) * 1e6, enqueue=(tb - ta) * 1e6, event1_record=(tc - tb) * 1e6,
-                       wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, barrier=(tg - te) * 1e6,
-                       gather_wait_after_clock=(p() - tg) * 1e6)
+                       wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, gather_wait=(tf - te) * 1e6,
+                       barrier=(tg - tf) * 1e6)
         c1 = env.counters()
         gpu_ms = evs.elapsed_ms()
         evs.close()
-        return wall, gpu_ms, launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}
+        return wall, gpu_ms, launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}, wall_steps
 
     prewarm_device(Env, n, dev, args.precision, args.prewarm_ms)
     run(args.warmup)
-    wall, gpu_ms, launches, gathers, dc = timed(args.steps)
+    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps)
     host_us_main = dict(host_us)
 
-    t = torch.tensor([wall, gpu_ms * 1e-3], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    # The headline is ONE sample of a short region (the driver's 20 steps are one 132 us launch): the identical region again,
+    # 15 times on fresh rows of the action pool (same handle, same launch shape, same bracket), for the spread.  `value` stays
+    # the first region -- the contract's -- and the repeats are reported beside it.
+    repeats = []
+    if world == 1 and args.repeat_regions > 0:
+        for _ in range(args.repeat_regions):
+            w_, g_, l_, _, _, _ = timed(args.steps)
+            repeats.append((w_, g_ * 1e3 / l_))
+
+    t = torch.tensor([wall, gpu_ms * 1e-3, wall_steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     per_rank = None
     if world > 1:       # every rank's wall clock and kernel time of the region (stragglers show here); value uses the MAX wall
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
-        per_rank = {"wall_ms": [float(x[0]) * 1e3 for x in allt], "kernel_ms": [float(x[1]) * 1e3 for x in allt]}
+        per_rank = {"wall_ms": [float(x[0]) * 1e3 for x in allt], "kernel_ms": [float(x[1]) * 1e3 for x in allt],
+                    "wall_steps_ms": [float(x[2]) * 1e3 for x in allt]}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t[0].item())
+    wall_steps_max = float(t[2].item())
     counters = env.counters()
     digests = None
+    gathered = None
     if args.state_digest:
         import hashlib
         mine = hashlib.sha256(env.get_state()["q"].cpu().numpy().tobytes()).hexdigest()
@@ -620,13 +642,17 @@ def main():
         if world > 1:
             digests = [None] * world
             dist.all_gather_object(digests, mine)
+            # one more logging all-gather, of the returns as they stand after the run: what every rank now holds
+            do_gather()
+            g_all = gather.result().detach().float().cpu().numpy()
+            gathered = {"sha256": hashlib.sha256(g_all.tobytes()).hexdigest(), "mean": float(g_all.astype(np.float64).mean())}
 
     step_api = None
     if args.mode == "rollout" and world == 1 and args.policy == "external":
         args.mode = "step"                      # the gym-style one-launch-per-step path, timed beside the headline
         k2 = min(args.steps, 500)
         run(10)
-        w2, g2, _, _, _ = timed(k2)
+        w2, g2, _, _, _, _ = timed(k2)
         step_api = {"value": n * k2 / w2, "unit": "env-steps/s", "steps": k2, "avg_launch_us": g2 * 1e3 / k2,
                     "kernel": env.kernel_name}
         # the same launches replayed from a hipGraph (50 armenv_step calls per graph): host launch cost removed
@@ -679,19 +705,26 @@ def main():
                     }[args.task] % (n, pol_txt[args.policy] % noise)
         line = {
             "metric": "env-steps/sec at N parallel envs (rl_%s_env)" % args.task,
-            "value": value, "value_kernel": value_kernel, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "value_kernel": value_kernel, "value_steps": total_envs * args.steps / wall_steps_max,
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
                        "gathers_in_timed_region": gathers, "state_digest": digests, "per_rank": per_rank,
+                       "gathered_returns_sha256": gathered["sha256"] if gathered else None,
+                       "gathered_returns_mean": gathered["mean"] if gathered else None,
+                       # what torch.distributed reports about the job this line was measured in (an 8-GPU node shows 8 / "nccl" = RCCL)
+                       "rccl_ranks_seen": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                                           "backend": dist.get_backend() if dist.is_initialized() else None},
                        # where the wall clock of the timed region went on the host (us): recording the two HIP events,
                        # enqueueing the launches, waiting for the GPU, the closing stream synchronisation, the barrier; and,
                        # outside the clock, the wait for the logging all-gather
                        "host_us": host_us_main,
                        "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps and at least once per "
-                                      "timed region (logging only, side stream, waited for after the clock: host_us.gather_wait_after_clock)"
+                                      "timed region (logging only, side stream; waited for INSIDE the clock of `value` -- host_us.gather_wait -- "
+                                      "and outside the clock of `value_steps`)"
                                       % (world, "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: debug)", args.gather_every)
                                       if world > 1 else "single GPU"},
             # `roofline.binding_bound` / `roofline.valu`: the bound that BINDS: 29 flop/B
@@ -702,6 +735,13 @@ def main():
         }
         if mfma:
             line["roofline_mfma"] = mfma
+        if repeats:
+            vals = sorted([value] + [total_envs * args.steps / w_ for w_, _ in repeats])
+            us = [launch_us] + [u_ for _, u_ in repeats]
+            line.update({"value_median": vals[len(vals) // 2], "value_min": vals[0], "value_max": vals[-1],
+                         "regions": 1 + len(repeats),
+                         "launch_us_samples": [round(u_, 2) for u_ in us],
+                         "launch_us_median": sorted(us)[len(us) // 2], "launch_us_min": min(us), "launch_us_max": max(us)})
         if step_api:
             line["step_api"] = step_api
         if in_kernel:

@@ -4,5 +4,6 @@ from .rl_reach_env import RLReachEnv
 from .rl_push_env import RLPushEnv
 from .rl_pick_env import RLPickEnv
 from .batched import BatchedArmEnv, BatchedReachEnv, BatchedPushEnv, BatchedPickEnv, diana_cam_reach_kinematics
+from .pipelined import PipelinedEnv
 
-__all__ = ["RLReachEnv", "RLPushEnv", "RLPickEnv", "BatchedArmEnv", "BatchedReachEnv", "BatchedPushEnv", "BatchedPickEnv", "diana_cam_reach_kinematics"]
+__all__ = ["RLReachEnv", "RLPushEnv", "RLPickEnv", "BatchedArmEnv", "BatchedReachEnv", "BatchedPushEnv", "BatchedPickEnv", "diana_cam_reach_kinematics", "PipelinedEnv"]

@@ -64,11 +64,14 @@ class BatchedArmEnv:
         self._terminal = None
         self._ik_updates = None
         self._diag = None
+        self._fixed_stream = None     # set by PipelinedEnv: this handle always launches on its own stream
         self.action_space = Box(low=[-0.4, -0.4, -0.6], high=[0.4, 0.4, 0.3])       # rl_reach_env.py:87-90
         self.max_steps_one_episode = int(cfg.max_steps)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
+        if self._fixed_stream is not None:
+            return self._fixed_stream
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @property
@@ -130,6 +133,19 @@ class BatchedArmEnv:
         L.check(self._lib.armenv_step(self._h, _ptr(action), _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
                                       _ptr(self._success), _ptr(term), _ptr(upd), _ptr(dg), self._stream()))
         return self._obs, self._reward, self._done.view(torch.bool), self._success.view(torch.bool)
+
+    def bind_step(self, action, stream=None):
+        """Everything `step` does except the launch (argument checks, pointer and stream resolution): returns `launch()`, one
+        ctypes call into armenv_step on the stream current at bind time (or `stream`); outputs go to the tensors `step` returns."""
+        self._check_action(action)
+        fn, args = self._lib.armenv_step, (self._h, _ptr(action), _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
+                                           _ptr(self._success), None, None, None, stream if stream is not None else self._stream())
+
+        def launch(_fn=fn, _args=args, _check=L.check, _keep=action):
+            rc = _fn(*_args)
+            if rc:
+                _check(rc)
+        return launch
 
     @property
     def ik_updates(self):

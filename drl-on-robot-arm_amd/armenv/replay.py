@@ -102,6 +102,16 @@ class TrajectoryStore:
                    done_u8=torch.as_tensor(np.asarray(traj.dones, dtype=np.uint8), device=dev)[:, None].contiguous())
         acts = torch.as_tensor(np.asarray(traj.actions, dtype=np.float32), device=dev)[:, None, :].contiguous()
         first = self._ring is None
+        if not first:
+            # The sampler reads an episode's first state from obs_after of the step before it (auto-reset semantics: the observation
+            # after a finishing step is the next episode's first one) and only the window's very first episode from obs0.  A host
+            # trajectory brings its own first state: write it where the kernel looks for it, over the previous episode's last
+            # obs_after row (that episode's own last next_state lives in next_obs and is not touched).  (without this
+            # every episode after the first started, for the sampler, at the previous episode's terminal observation.)
+            r = self._ring
+            if r["N"] != 1 or r["T"] < 1:
+                raise RuntimeError("TrajectoryStore.add_trajectory: the ring holds a batched rollout, not single-env trajectories")
+            r["obs_after"][(r["base"] + r["T"] - 1) % r["cap"], 0].copy_(st[0])
         self.add_rollout(st[0:1].contiguous(), out, actions=acts, starts_at_reset=first)
 
     def _index(self):

@@ -26,6 +26,9 @@ reference's importable Python (config, algo.TD3) -- never reference source text.
                                EXECUTING the reference's own rejection-sampling loop (envs/rl_push_env.py:195-214,
                                envs/rl_pick_env.py:190-208; extracted from the module's AST because the module itself
                                imports pybullet) under random.seed(0)
+  G12 visdata_reach_td3.json   the y values of visdata/reach/TD3_0.01/Reach_TD3.json: per-episode return (351), 10-episode mean
+                               return (35), 25-episode success rate (14) of one train_reach_with_TD3 run (main.py:165-231) --
+                               the reference's only record of how this env BEHAVES (tests/tools/learning_curve_check.py)
 """
 import ast
 import json
@@ -431,6 +434,23 @@ def g11_ddpg_datd3_take_action():
     np.savez_compressed(os.path.join(OUT, "datd3_take_action_seed0.npz"), **out)
 
 
+def g12_visdata_reach_td3():
+    """The only dynamics data the reference holds for this env: the visdom export of one `train_reach_with_TD3` run at reach_dis = 0.01
+    (visdata/reach/TD3_0.01/Reach_TD3.json; main.py:165-231 is the function whose plotting pattern -- "return" every episode,
+    "avg_return" every 10, "success_rate" every 25 -- matches the three series' lengths 351 / 35 / 14).  Numbers only."""
+    d = json.load(open(os.path.join(REF, "visdata", "reach", "TD3_0.01", "Reach_TD3.json")))["jsons"]
+    ys = {k: [float(v) for v in d[k]["content"]["data"][0]["y"]] for k in ("return", "avg_return", "success_rate")}
+    assert (len(ys["return"]), len(ys["avg_return"]), len(ys["success_rate"])) == (351, 35, 14)
+    out = {"source": "visdata/reach/TD3_0.01/Reach_TD3.json (visdom export; y values of the three plot windows)",
+           "protocol": "main.py:165-231 train_reach_with_TD3: one env, a = actor(s) + N(0, 1 * opt.gamma = 0.98) unclipped, n_train = 40 updates "
+                       "per episode once 5 episodes are stored, batch 256, HER ratio 0.8 (x 0.75 whenever a 25-episode success rate is a new maximum), "
+                       "reach_dis = 0.01 (directory name), 501-step episodes",
+           "return_per_episode": ys["return"], "avg_return_every_10_episodes": ys["avg_return"],
+           "success_rate_every_25_episodes": ys["success_rate"]}
+    json.dump(out, open(os.path.join(OUT, "visdata_reach_td3.json"), "w"))
+
+
 if __name__ == "__main__":
+    g12_visdata_reach_td3()
     g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements(); g10_config_fields(); g11_ddpg_datd3_take_action()
     print("fixtures written to", OUT)

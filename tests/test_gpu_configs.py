@@ -203,3 +203,32 @@ def test_config2_fused_actor_65536_envs_vs_oracle(envs, O, kuka, kind):
     c = e.counters()
     assert c["env_steps"] == n * 2 * T and c["nonfinite"] == 0
     e.close()
+
+
+def test_n1_env_reproduces_the_reference_runs_first_episodes(envs):
+    """BASELINE configs[0] against the reference's own numbers: the first five episodes of the recorded train_reach_with_TD3 run
+    (tests/golden/visdata_reach_td3.json; real PyBullet, opt.random_seed = 0; see tests/reference_run.py) through the N=1 drop-in
+    `envs.RLReachEnv` -- every env step an armenv_step launch of the HIP engine -- with the protocol of main.py:176-204: the
+    untrained TD3 actor of torch.manual_seed(0) (golden G3), a + N(0, 0.98) unclipped from np.random.seed(0), goals from
+    random.seed(0).  Episode lengths 64 (success) / 501 x 4 and the five returns to 2e-3 (measured 6e-4 = 4e-7 relative)."""
+    import reference_run as R
+    from armenv.td3 import TD3
+    fx = R.fixture_returns()
+    env = envs.RLReachEnv(is_render=False, is_good_view=False)                     # main.py:171 (its reset precedes the seeding)
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)                        # main.py:176-178
+    agent = TD3(6, 3, 0.7, device=DEV)
+    agent.actor.load_state_dict({k: torch.from_numpy(v) for k, v in R.actor_weights().items()})
+    got = []
+    for ep in range(5):
+        state = env.reset(); done, ret, n = False, 0.0, 0
+        while not done:
+            action = agent.take_action(state) + np.random.normal(0, 1 * 0.98, size=3)          # main.py:199-200
+            state, reward, done, is_success = env.step(action)
+            ret += reward; n += 1
+        got.append((ret, n, is_success))
+    c = env._eng.counters()
+    env.close()
+    assert [n for _, n, _ in got] == [64, 501, 501, 501, 501] and [s for _, _, s in got] == [True, False, False, False, False]
+    diffs = [abs(r - x) for (r, _, _), x in zip(got, fx)]
+    assert max(diffs) < 2e-3, diffs
+    assert c["limit_steps"] > 200 and c["low_flange_steps"] > 200 and c["cap_steps"] == 0

@@ -1977,8 +1977,13 @@ def test_bench_line_contract():
     assert ro["traffic_key"] == "reach_rollout<f64,kuka>|policy=external|T=20|N=65536"
     assert ro["traffic"] is not None and 0.9 < ro["traffic"] / ro["algo_bytes_per_launch"] < 1.3      # PMC pass at this launch shape
     assert ro["binding_bound"] == "valu" and 0.2 < ro["valu"]["frac"] < 1.0 and ro["valu"]["unit"] == "TFLOP/s"
-    one = ro["valu"]["one_wave_per_simd"]        # the measured single-wave f64 issue ceiling beside the nominal peak
+    one = ro["valu"]["one_wave_per_simd"]        # the single-wave f64 issue ceiling beside the nominal peak: labelled as a builder probe
     assert one["cycles_per_f64_instruction"] == 6.6 and abs(one["peak"] - 78.6 * 4 / 6.6) < 1e-9 and 0.6 < one["frac"] < 1.0
+    assert "NOT measured in this run" in one["source"]
+    # the headline as a distribution: the identical 20-step region 15 more times on fresh action rows
+    assert d["regions"] == 16 and len(d["launch_us_samples"]) == 16 and d["value_min"] <= d["value_median"] <= d["value_max"]
+    assert d["value_min"] <= d["value"] <= d["value_max"] and d["launch_us_samples"][0] == pytest.approx(ro["avg_launch_us"], abs=0.01)
+    assert d["launch_us_max"] < 1.25 * d["launch_us_min"], d["launch_us_samples"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["threads_1"]["cores"] == 1 and cb["threads_1"]["value"] > 5e4 and cb["value"] >= 0.8 * cb["threads_1"]["value"]
     assert cb["cores"] <= cb["host"]["affinity_cpus"]
@@ -2047,5 +2052,44 @@ def test_bench_driver_shape_with_gathers_every_region():
     # a kernel-time figure beside the wall-clock one, and the host-side costs of the bracket (barrier, gather wait) stated
     assert d["value_kernel"] >= d["value"] > 0 and len(d["config"]["per_rank"]["kernel_ms"]) == 2
     assert d["value_kernel"] == pytest.approx(16384 * 20 / (max(d["config"]["per_rank"]["kernel_ms"]) * 1e-3), rel=1e-6)
-    for k in ("barrier", "closing_sync", "gather_wait_after_clock", "enqueue", "wait_for_gpu"):
+    for k in ("barrier", "closing_sync", "gather_wait", "enqueue", "wait_for_gpu"):
         assert k in d["config"]["host_us"], k
+    # `value` runs on the contract's bracket (closing synchronise incl. the logging collective, then the barrier);
+    # the rank-local clock is a separate key
+    assert d["value_steps"] >= d["value"] and len(d["config"]["per_rank"]["wall_steps_ms"]) == 2
+    assert max(d["config"]["per_rank"]["wall_steps_ms"]) <= max(d["config"]["per_rank"]["wall_ms"])
+    assert d["config"]["rccl_ranks_seen"] == {"world_size": 2, "backend": "gloo"}
+
+
+def test_bench_eight_ranks_on_one_gpu_config5_control_flow(envs):
+    """BASELINE configs[4] -- rl_reach_env sharded across 8 ranks, an all-gather of episode returns -- at world = 8 on this ONE
+    GPU (the ranks share it, the logging collective falls back to gloo; on an 8-GPU node the same command runs one rank per GPU
+    over RCCL): env_id_offset up to 7 x N, the 8-way gather inside the timed region, max-over-ranks timing.  The eight shard
+    digests equal the eight slices of ONE 8 x N-env handle, and the gathered vector of episode returns equals that handle's
+    armenv_episode_stats."""
+    import hashlib
+    n, K, W, world = 8192, 700, 5, 8          # 700 steps: every env finishes its first 501-step episode, so the returns are live
+    d = _run_bench(["--gpus", str(world), "--steps", str(K), "--warmup", str(W), "--envs-per-gpu", str(n), "--state-digest",
+                    "--prewarm-ms", "0", "--gather-every", "100"], nproc=world, timeout=1200)
+    assert d["n_gpus"] == world and d["config"]["total_envs"] == world * n and d["config"]["gathers_in_timed_region"] >= 7
+    assert d["config"]["rccl_ranks_seen"] == {"world_size": world, "backend": "gloo"} and "gloo" in d["config"]["parallelism"]
+    assert len(d["config"]["per_rank"]["kernel_ms"]) == world and d["value_steps"] >= d["value"] > 0
+    S = 1000
+    pools = []
+    for r in range(world):
+        gen = torch.Generator(device=DEV); gen.manual_seed(1000 + r)
+        pools.append((torch.randn((S, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7))
+    e = _mk(envs, world * n, seed=0)
+    e.reset()
+    t = 0
+    for r in [W] + [100] * (K // 100):
+        a = torch.cat([p_[t:t + r] for p_ in pools], dim=1).contiguous()
+        e.rollout(r, a)
+        t += r
+    q = _np(e.get_state()["q"])
+    want = [hashlib.sha256(q[k * n:(k + 1) * n].tobytes()).hexdigest() for k in range(world)]
+    assert d["config"]["state_digest"] == want
+    ret = _np(e.episode_stats()[0]).astype(np.float32)
+    assert d["config"]["gathered_returns_sha256"] == hashlib.sha256(ret.tobytes()).hexdigest()
+    assert abs(d["config"]["gathered_returns_mean"] - float(ret.astype(np.float64).mean())) < 1e-6 and ret.min() < 0.0
+    e.close()

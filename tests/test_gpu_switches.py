@@ -200,3 +200,97 @@ def test_create_rejects_what_the_bookkeeping_cannot_represent(envs):
         t.set_policy("actor", actor_state_dict=sd)
     t.set_policy("random")
     t.reset(); t.rollout(5, None); t.close()
+
+
+def test_add_trajectory_keeps_every_episodes_own_first_state():
+    """TrajectoryStore.add_trajectory (rl_utils.py:112-113 for the single-env loops of main.py:108-129) stored an
+    episode's first state only for the very first trajectory; every later one started, for the sampler, at the previous
+    episode's terminal observation.  Three trajectories with distinct first states, a ring small enough to wrap, then samples
+    of (episode e, step 0) without HER: states must be traj.states[0], next_states traj.states[1]; and the last step of the
+    PREVIOUS episode still returns its own terminal next_state."""
+    from armenv.replay import Trajectory, TrajectoryStore
+    rng = np.random.default_rng(0)
+    store = TrajectoryStore(device=DEV, seed=1, capacity_steps=16)
+    trajs = []
+    for e in range(4):
+        L_ = 5 + e
+        tr = Trajectory(rng.uniform(0.2, 0.5, 6).astype(np.float32) + 10.0 * (e + 1))     # unmistakable first states
+        for t in range(L_):
+            tr.store_step(rng.normal(0, 0.3, 3).astype(np.float32), rng.uniform(0.2, 0.5, 6).astype(np.float32) + 10.0 * (e + 1) + t + 1,
+                          float(-t), t == L_ - 1)
+        trajs.append(tr)
+        store.add_trajectory(tr)
+    assert store.size() >= 2                       # 5 + 6 + 7 + 8 = 26 steps through a 16-step ring: the oldest fell out
+    eps = _np(store.chunk["episodes"][: store.size()])
+    kept = trajs[-store.size():]                   # complete episodes still in the window, oldest first
+    assert [int(x) for x in eps[:, 2]] == [t.length for t in kept]
+    picks = []
+    for e, tr in enumerate(kept):
+        picks += [[e, 0, 0, 0], [e, tr.length - 1, 0, 0]]
+    out = store.sample(len(picks), use_her=False, picks=np.asarray(picks, dtype=np.int32))
+    st, nx, ac = _np(out["states"]), _np(out["next_states"]), _np(out["actions"])
+    for e, tr in enumerate(kept):
+        assert np.array_equal(st[2 * e], np.asarray(tr.states[0], dtype=np.float32)), e
+        assert np.array_equal(nx[2 * e], np.asarray(tr.states[1], dtype=np.float32)), e
+        assert np.array_equal(ac[2 * e], np.asarray(tr.actions[0], dtype=np.float32)), e
+        assert np.array_equal(st[2 * e + 1], np.asarray(tr.states[-2], dtype=np.float32)), e
+        assert np.array_equal(nx[2 * e + 1], np.asarray(tr.states[-1], dtype=np.float32)), e      # the episode's own terminal state
+
+
+@pytest.mark.parametrize("task,parts", [("reach", 2), ("reach", 4), ("push", 2)])
+def test_pipelined_env_equals_the_single_handle_bitwise(envs, task, parts):
+    """armenv.envs.PipelinedEnv: the batch cut into `parts` handles on `parts` HIP streams (a part's launch
+    t+1 runs under the other parts' launch-t tails; a closed-loop policy's kernels for part A under part B's step).  Same
+    trajectory as ONE handle, bit for bit: outputs of every step, final state, counters -- with the open-loop step(), with the
+    bare bound launches, and closed loop through a torch policy; across in-place resets (30-step episodes).
+    Matches /root/reference/main.py:111-128."""
+    n, T = 4096, 70
+    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv)[task]
+    gen = torch.Generator(device=DEV); gen.manual_seed(3)
+    sig = 0.686 if task == "reach" else 0.392
+    acts = (torch.randn((T, n, 3), device=DEV, generator=gen) * sig).clamp_(-0.7, 0.7).contiguous()
+    one = Env(n, device=DEV, seed=11, max_steps=30)
+    ref_obs = one.reset().clone()
+    ref = []
+    for t in range(T):
+        o, r, d, s = one.step(acts[t])
+        ref.append((o.clone(), r.clone(), d.clone(), s.clone()))
+    st_one, c_one = one.get_state(), one.counters()
+    # open loop through step()
+    pe = envs.PipelinedEnv(Env, n, parts=parts, device=DEV, seed=11, max_steps=30)
+    assert torch.equal(pe.reset(), ref_obs)
+    for t in range(T):
+        o, r, d, s = pe.step(acts[t])
+        for x, y in zip((o, r, d, s), ref[t]):
+            assert torch.equal(x, y), (task, parts, t)
+    st = pe.get_state()
+    for k in st_one:
+        assert torch.equal(st[k], st_one[k]), k
+    c = pe.counters()
+    assert {k: c[k] for k in ("episodes", "successes", "env_steps", "ik_updates")} == {k: c_one[k] for k in ("episodes", "successes", "env_steps", "ik_updates")}
+    pe.close()
+    # the bare bound launches, no per-step stream traffic
+    pe = envs.PipelinedEnv(Env, n, parts=parts, device=DEV, seed=11, max_steps=30)
+    pe.reset()
+    torch.cuda.synchronize()
+    for f in pe.bind_steps(acts):
+        f()
+    pe.join()
+    for x, y in zip((pe._obs, pe._reward), ref[-1][:2]):
+        assert torch.equal(x, y)
+    assert torch.equal(pe.get_state()["q"], st_one["q"])
+    pe.close()
+    # closed loop: a deterministic torch policy of the observation
+    W = torch.linspace(-1.0, 1.0, 3 * one.obs_dim, device=DEV).reshape(one.obs_dim, 3)
+    policy = lambda o: (torch.tanh(o @ W) * 0.5).contiguous()
+    one.close()
+    one = Env(n, device=DEV, seed=11, max_steps=30)          # a fresh handle: the goal stream is keyed by the env's reset count
+    o = one.reset()
+    for t in range(40):
+        o, r, d, s = one.step(policy(o))
+    want = (o.clone(), r.clone(), one.get_state()["q"].clone())
+    pe = envs.PipelinedEnv(Env, n, parts=parts, device=DEV, seed=11, max_steps=30)
+    pe.reset()
+    o2, r2, _, _ = pe.run_closed_loop(policy, 40)
+    assert torch.equal(o2, want[0]) and torch.equal(r2, want[1]) and torch.equal(pe.get_state()["q"], want[2])
+    pe.close(); one.close()
