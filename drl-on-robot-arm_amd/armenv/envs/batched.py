@@ -118,7 +118,7 @@ class BatchedArmEnv:
         want_terminal_obs the pre-reset observation is available as ``self.terminal_obs``; with want_ik_updates the number
         of DLS updates of every env's IK call as ``self.ik_updates`` (u8; ik_max_iters = the call did not converge); with
         want_diag ``self.diag`` f64 [N, 4] = the step's end-effector position and reward before any f32 rounding (the last
-        two need a handle created with fence_counters=1)."""
+        two need a handle created with fence_counters >= 1 / = 2)."""
         if action is not None:          # None: the fused policy installed with set_policy() acts
             self._check_action(action)
         if want_terminal_obs and self._terminal is None:

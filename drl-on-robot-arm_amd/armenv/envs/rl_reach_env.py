@@ -59,8 +59,8 @@ class RLReachEnv:
 
     def _make_engine(self):
         self._dv, self._dis = float(opt.reach_ctr), float(opt.reach_dis)
-        # fence_counters=1: the bookkeeping build of the kernels, whose step also hands out the f64 end-effector position and reward
-        self._eng = BatchedReachEnv(1, device=self._device, auto_reset=False, precision=64, fk_path=1, fence_counters=1,
+        # fence_counters=2: the bookkeeping build of the kernels whose step also hands out the f64 end-effector position and reward
+        self._eng = BatchedReachEnv(1, device=self._device, auto_reset=False, precision=64, fk_path=1, fence_counters=2,
                                     dv=self._dv, reach_dis=self._dis, max_steps=int(self.max_steps_one_episode))
 
     def _sync_opt(self):

@@ -175,6 +175,7 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
     return fail(ARMENV_EINVAL, "armenv_create: fence_counters / ik_tip_offset need ik_max_iters <= 254 (the per-step update count is a u8)");
   for (int k = 0; k < 3; ++k)
     if (!std::isfinite(cfg->ik_tip_offset[k])) return fail(ARMENV_EINVAL, "armenv_create: ik_tip_offset is not finite");
+  if (cfg->fence_counters < 0 || cfg->fence_counters > 2) return fail(ARMENV_EINVAL, "armenv_create: fence_counters must be 0, 1 or 2");
   if (cfg->clamp_joint_limits < 0 || cfg->clamp_joint_limits > 2) return fail(ARMENV_EINVAL, "armenv_create: clamp_joint_limits must be 0, 1 or 2");
   if (cfg->clamp_joint_limits == 2 && !(cfg->limit_erp > 0.0 && cfg->limit_erp <= 1.0)) return fail(ARMENV_EINVAL, "armenv_create: limit_erp must be in (0, 1]");
   if (cfg->rollout_lanes_per_wave != 0 && cfg->rollout_lanes_per_wave != 32 && cfg->rollout_lanes_per_wave != 64)
@@ -191,7 +192,7 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   std::unique_ptr<ArmEnv> env(new (std::nothrow) ArmEnv());
   if (!env) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
   env->cfg = *cfg;
-  if (tip) env->cfg.fence_counters = 1;   // the tip offset lives in the bookkeeping build of the kernels (armenv_kin.h, MODE 2)
+  if (tip) env->cfg.fence_counters = 2;   // the tip offset lives in the MODE 2 bookkeeping build of the kernels (armenv_kin.h)
   env->eng.reset(make_engine(env->cfg));
   if (!env->eng) return fail(ARMENV_ENOMEM, "armenv_create: host allocation failed");
   const int rc = env->eng->init(env->cfg);
@@ -226,8 +227,10 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
                 uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, double *diag_dev, void *stream) {
   ENV_ENTER(env);
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_step: NULL output buffer");
-  if ((ik_updates_dev || diag_dev) && !env->cfg.fence_counters)
-    return fail(ARMENV_ESTATE, "armenv_step: ik_updates_dev / diag_dev need a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
+  if (ik_updates_dev && !env->cfg.fence_counters)
+    return fail(ARMENV_ESTATE, "armenv_step: ik_updates_dev needs a handle created with fence_counters >= 1 (the bookkeeping build of the kernels)");
+  if (diag_dev && env->cfg.fence_counters != 2)
+    return fail(ARMENV_ESTATE, "armenv_step: diag_dev needs a handle created with fence_counters = 2");
   if (diag_dev && !action_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
     return fail(ARMENV_ESTATE, "armenv_step: diag_dev is not available with a fused actor");
   StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};
@@ -333,8 +336,10 @@ int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *
   if (!obs_dev || !reward_dev || !done_dev || !success_dev) return fail(ARMENV_EINVAL, "armenv_rollout: NULL output buffer");
   if (!actions_dev && env->eng->pol.kind == ARMENV_POLICY_EXTERNAL)
     return fail(ARMENV_ESTATE, "armenv_rollout: actions_dev is NULL and no fused policy is installed");
-  if ((ik_updates_dev || diag_dev) && !env->cfg.fence_counters)
-    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev / diag_dev need a handle created with fence_counters = 1 (the bookkeeping build of the kernels)");
+  if (ik_updates_dev && !env->cfg.fence_counters)
+    return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev needs a handle created with fence_counters >= 1 (the bookkeeping build of the kernels)");
+  if (diag_dev && env->cfg.fence_counters != 2)
+    return fail(ARMENV_ESTATE, "armenv_rollout: diag_dev needs a handle created with fence_counters = 2");
   if ((ik_updates_dev || diag_dev) && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
     return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev / diag_dev are not available with a fused actor");
   StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};

@@ -105,7 +105,7 @@ static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + b
 template <template <class, class, int> class LaneT, class C, typename T> struct Engine final : EngineBase {
   using Lane = LaneT<C, T, 0>;
   using LaneF = LaneT<C, T, 1>;   // the bookkeeping build of the same lane (parity-fence counters)
-  using LaneTip = LaneT<C, T, 2>; // the bookkeeping build with the IK evaluated at ArmEnvConfig.ik_tip_offset
+  using LaneTip = LaneT<C, T, 2>; // the bookkeeping build with the IK evaluated at ArmEnvConfig.ik_tip_offset + the f64 step diagnostics
   bool fence_on = false;          // bookkeeping kernels (fence_counters, or implied by a tip offset)
   bool tip_on = false;
   // run f with the lane type of the handle's bookkeeping build, passed as a null pointer tag
@@ -227,7 +227,8 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
     lanes_cfg = cfg.rollout_lanes_per_wave;
     ready_lanes = cfg.rollout_ready_lanes < 0 ? 0 : (cfg.rollout_ready_lanes > 64 ? 64 : cfg.rollout_ready_lanes);
     straggler_trips = cfg.rollout_straggler_trips < 0 ? 0 : cfg.rollout_straggler_trips;
-    tip_on = cfg.ik_tip_offset[0] != 0.0 || cfg.ik_tip_offset[1] != 0.0 || cfg.ik_tip_offset[2] != 0.0;
+    // MODE 2 of the lanes: a tip offset, or the f64 step diagnostics (fence_counters = 2)
+    tip_on = cfg.ik_tip_offset[0] != 0.0 || cfg.ik_tip_offset[1] != 0.0 || cfg.ik_tip_offset[2] != 0.0 || cfg.fence_counters == 2;
     fence_on = cfg.fence_counters != 0 || tip_on;
     for (int k = 0; k < 3; ++k) P.ik.tip[k] = (T)cfg.ik_tip_offset[k];
     P.ik.fence_pivot = (T)cfg.fence_pivot;

@@ -171,7 +171,7 @@ struct StepIO {
   float *terminal_obs;
   uint8_t *updates;   // nullable: DLS updates the step's IK call applied (saturated at 255): the per-step view of counters[4] / [7]
   double *diag;       // nullable, f64 [N][4]: the step's exit frame position (the numbers its distance, reward and flags were computed
-                      // from) and its reward before the f32 store.  Like `updates` a bookkeeping-build output.
+                      // from) and its reward before the f32 store.  An output of the MODE 2 bookkeeping build only.
 };
 
 // goal ~ U(box): a + (b - a) * u per axis as random.uniform does (rl_reach_env.py:180-182), then the
@@ -429,7 +429,7 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
     else if (dist < P.reach_dis) { reward = T(0); done = true; succ = true; }               // :303-306
     else { reward = -dist * T(10); done = false; succ = false; }                            // :307-309
     ep_ret += reward;
-    if constexpr (kFence) {
+    if constexpr (kTipOf(kMode)) {
       if (io.diag) { io.diag[4 * i] = (double)S.p[0]; io.diag[4 * i + 1] = (double)S.p[1]; io.diag[4 * i + 2] = (double)S.p[2]; io.diag[4 * i + 3] = (double)reward; }
     }
 
@@ -758,7 +758,7 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     else { reward = -test * T(100); done = false; }                                             // :427-428
     const bool succ = d_cur < P.push_success_dis;                                               // :430-432
     ep_ret += reward;
-    if constexpr (kFence) {
+    if constexpr (kTipOf(kMode)) {
       if (io.diag) { io.diag[4 * i] = (double)S.p[0]; io.diag[4 * i + 1] = (double)S.p[1]; io.diag[4 * i + 2] = (double)S.p[2]; io.diag[4 * i + 3] = (double)reward; }
     }
 
@@ -966,8 +966,8 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     io.done = io0.done + (int64_t)t * n;
     io.success = io0.success + (int64_t)t * n;
     io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
-    if constexpr (Lane::kFence) { io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; }
-    else { io.updates = nullptr; io.diag = nullptr; }
+    if constexpr (Lane::kFence) io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; else io.updates = nullptr;
+    if constexpr (kTipOf(Lane::kMode)) io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; else io.diag = nullptr;
     if (actions_out) {
       float *ao = actions_out + ((int64_t)t * n + i) * 3;
       if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
@@ -1082,8 +1082,8 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
         io.done = io0.done + (int64_t)t * n;
         io.success = io0.success + (int64_t)t * n;
         io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
-        if constexpr (Lane::kFence) { io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; }
-    else { io.updates = nullptr; io.diag = nullptr; }
+        if constexpr (Lane::kFence) io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; else io.updates = nullptr;
+    if constexpr (kTipOf(Lane::kMode)) io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; else io.diag = nullptr;
         const uint32_t before = L.n_done;
         L.step_tail(P, i, io, updates, lim_hit);
         if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {

@@ -15,7 +15,9 @@ namespace armenv {
 //   0  the default kernels;
 //   1  the bookkeeping build: parity-fence counters, LDL^T pivot minimum, per-step ik_updates / diag outputs
 //      (ArmEnvConfig.fence_counters);
-//   2  the bookkeeping build with the IK evaluated at ArmEnvConfig.ik_tip_offset instead of the URDF link-7 frame.
+//   2  the bookkeeping build with the IK evaluated at ArmEnvConfig.ik_tip_offset instead of the URDF link-7 frame, and with the
+//      f64 step diagnostics (StepIO::diag; ArmEnvConfig.fence_counters = 2).  Kept apart from mode 1: one more nullable output
+//      pointer in the bookkeeping build cost it 5-10 % (two scalar registers live across the IK loop, armenv_env.h step_tail).
 // Compile-time, not run-time: a branch in the trip loop cost the default path 3 %.
 constexpr bool kFenceOf(int mode) { return mode >= 1; }
 constexpr bool kTipOf(int mode) { return mode == 2; }

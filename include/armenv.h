@@ -88,11 +88,15 @@ typedef struct ArmEnvConfig {
   int32_t clamp_joint_limits; /* what stepSimulation (:258) does to a joint the IK left outside chain.limit_lo/hi (the URDF limits
                                  of envs/bmirobot_joints_info_pybullet.txt:1-7 fields 8-9; the reference never passes them to
                                  the IK: rl_reach_env.py:103-107 are dead data, :244-250).
-                                 0 = nothing (this build's kinematic stepSimulation; default);
+                                 0 = nothing (this build's kinematic stepSimulation; default) -- what real PyBullet does, by the
+                                     reference's own recorded run: its first five episodes contain 276 steps with a joint beyond
+                                     its limit and are reproduced to 4e-7 relative at 0, missed by 1e1..1e2 at 1 or 2
+                                     (tests/reference_run.py, tests/tools/fit_bullet.py);
                                  1 = project onto the limits -- the hard-limit idealisation of Bullet's joint-limit constraint;
                                  2 = move the joint back by the share limit_erp of its violation per step -- one Baumgarte-
                                      stabilised constraint solve per stepSimulation, as btMultiBodyJointLimitConstraint does.
-                                 Modes 1 and 2 are named models, not pinned against PyBullet. */
+                                 Modes 1 and 2 are named models of a hard / soft limit for callers who want one; they are NOT what the
+                                 reference's engine does. */
   double box_lo[3];        /* Cartesian clip, rl_reach_env.py:221-223 */
   double box_hi[3];
   double goal_lo[3];       /* target sampling box, rl_reach_env.py:65-70,180-182 */
@@ -114,7 +118,9 @@ typedef struct ArmEnvConfig {
                               included: the IK call ran to ik_max_iters without converging (the update oscillates), or one of
                               its damped systems was ill-conditioned (fence_pivot) -- in armenv_counters out[5] / out[6] / out[7] /
                               out[8].  Every parity claim is fenced by these four rates (bench.py reports them for its
-                              workloads).  0 (default): no bookkeeping in the step.  Needs ik_max_iters <= 254 (the per-step update
+                              workloads).  0 (default): no bookkeeping in the step.  2: the same plus the f64 step diagnostics
+                              (armenv_step / armenv_rollout diag_dev) -- a third build of the kernels, kept apart from 1 because one
+                              more output pointer costs the bookkeeping build 5-10 %.  Needs ik_max_iters <= 254 (the per-step update
                               count is reported in a u8, the wave's trip maximum folded over 8 bits). */
 
   /* push task, /root/reference/envs/rl_push_env.py (the pick task, envs/rl_pick_env.py, shares all six) */
@@ -141,10 +147,11 @@ typedef struct ArmEnvConfig {
   double ik_tip_offset[3];    /* The point of link 7, in the link-7 frame, at which calculateInverseKinematics (rl_reach_env.py:244-250)
                                  takes its position error and its linear Jacobian.  Default (0,0,0): the URDF link frame, the point
                                  p.getLinkState(body, 6)[4] reports (:237).  (0,0,0.02) is the KUKA link-7 inertial origin: Bullet's
-                                 multibody link frames sit at the centre of mass, and whether pybullet 3.0.6 runs the IK there is
-                                 the one unknown of the restatement that had no switch before ABI 4.  The
+                                 multibody link frames sit at the centre of mass, and whether pybullet 3.0.6 runs the IK there was
+                                 the one unknown of the restatement that had no switch before ABI 4; the reference's recorded run
+                                 decides it: link frame (the inertial setting misses the recorded returns by 1e3).  The
                                  target clip (:231-242), the reward and the observation always use the link frame.  A non-zero
-                                 offset selects the bookkeeping build of the kernels (as fence_counters = 1 does; it is a fitting
+                                 offset selects the MODE 2 bookkeeping build of the kernels (as fence_counters = 2 does; it is a fitting
                                  switch for tests/tools/fit_bullet.py, not a tuned path) and excludes the fused actors. */
 
   /* armenv_rollout scheduling.  0: lockstep -- the lanes of a wavefront walk through every step together (a step costs the
@@ -214,7 +221,8 @@ int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *go
  * diag_dev (nullable, f64 [N][4]) receives what _reward (:267-309) computed in the reference's number type before anything was
  * rounded to f32: [0..2] the end-effector position of getLinkState(...)[4] (:271) -- the very numbers this step's distance,
  * done and success flags come from -- and [3] the reward as a double (the reference returns a Python float).
- * ik_updates_dev and diag_dev are diagnostics: only on a handle created with fence_counters = 1 (ARMENV_ESTATE otherwise). */
+ * ik_updates_dev and diag_dev are diagnostics: only on a handle created with fence_counters >= 1 (ik_updates_dev) / = 2
+ * (diag_dev); ARMENV_ESTATE otherwise. */
 int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                 uint8_t *success_dev, float *terminal_obs_dev, uint8_t *ik_updates_dev, double *diag_dev, void *stream);
 

@@ -1,9 +1,9 @@
 """ctypes front-end of the CPU oracle (oracle/armenv_oracle.c).
 
 TEST INFRASTRUCTURE ONLY.  Importable from tests/, ``__graft_entry__.smoke()`` and the
-``cpu_baseline`` leg of ``bench.py`` -- never from the product package.  Parity against real
-PyBullet is UNPINNED (pybullet is not installable here); see the header of armenv_oracle.c for
-what does pin it.
+``cpu_baseline`` leg of ``bench.py`` -- never from the product package.  pybullet is not installable
+here; the reach path is pinned by the reference's own recorded run instead (real PyBullet, 2 068 free-running
+env steps reproduced to 4e-7 relative: tests/reference_run.py); see the header of armenv_oracle.c.
 
 The chain tables below are entered independently of the product's URDF assets so that the two
 can be cross-checked:

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Turns the raw rocprofv3 outputs of profiles/collect.sh (gpurun_out/prof/) into the summaries kept in profiles/
-(ROUND = r03 unless given as argv[1]):
+(ROUND = r04 unless given as argv[1]):
   <round>_kernel_stats_<config>.csv   --stats tables, armenv kernels only (config "driver" = `bench.py --steps 20 --warmup 5`)
+  <round>_kernel_stats_<config>_by_T.csv  the same launches from the per-dispatch kernel trace, one row per (kernel, steps per
+                                      launch): rocprofv3's --stats merges the T = 5 warm-up, the T = 20 timed launches and the
+                                      T = 100 launches of the fence leg of one symbol into one average
   <round>_bench_<config>.json         the bench.py line of the same run
   <round>_pmc_default_bench_f64.json  per-launch means of every counter for the rollout / step kernels of the default bench
   <round>_pmc_actor_f16x3.json        same for the fused f16x3 actor rollout kernel
@@ -23,7 +26,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def short(name):
@@ -72,7 +75,43 @@ def pmc(files, want):
     return out
 
 
+def by_steps(trace_csv, bench_json, dst):
+    """Per-dispatch kernel trace -> one row per (kernel symbol, steps per launch).  A rollout launch's length is not in the
+    trace; it is recovered from the duration: bench.py's line gives the time per env step of its own launches
+    (roofline.avg_launch_us / steps_per_launch), and a dispatch is assigned the candidate length (the run's warm-up remainder,
+    its steps per launch, the 100 of the fence / secondary legs) whose predicted duration is nearest on a log scale."""
+    import math
+    rows = list(csv.DictReader(open(trace_csv)))
+    try:
+        b = json.load(open(bench_json))
+    except Exception:
+        return
+    spl = float(b["config"]["steps_per_launch"])
+    us_step = b["roofline"]["avg_launch_us"] / spl
+    R = int(round(spl))
+    W = int(b["warmup"])
+    cands = sorted({R, 100, (W % R) or R})          # the warm-up's last (short) launch, the timed launches, the 100-step legs
+    groups = collections.defaultdict(list)
+    for r in rows:
+        name = r["Kernel_Name"]
+        if not any(s_ in name for s_ in ("env_", "actor_", "her_", "index_episodes")):
+            continue
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        T = ""
+        if "env_rollout" in name:
+            # per-step time differs between kernel variants (fused actors, push): scale by the variant's own median launch
+            T = min(cands, key=lambda c: abs(math.log(max(d, 1e-3) / (c * us_step)))) if ("ReachLane" in name and ", 0, 1>" in name and "double, 0>" in name) else "?"
+        groups[(name, T)].append(d)
+    with open(dst, "w") as fh:
+        fh.write("Kernel_Name,steps_per_launch,calls,avg_us,min_us,max_us,median_us\n")
+        for (name, T), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            fh.write('"%s",%s,%d,%.2f,%.2f,%.2f,%.2f\n' % (name, T, len(v), sum(v) / len(v), min(v), max(v), statistics.median(v)))
+
+
 def main():
+    for f in glob.glob(os.path.join(SRC, "*_kernel_trace.csv")):
+        cfg = os.path.basename(f)[: -len("_kernel_trace.csv")]
+        by_steps(f, os.path.join(SRC, f"{cfg}_bench.json"), os.path.join(DST, f"{ROUND}_kernel_stats_{cfg}_by_T.csv"))
     for f in glob.glob(os.path.join(SRC, "*_kernel_stats.csv")):
         cfg = os.path.basename(f)[: -len("_kernel_stats.csv")]
         rows = [l for i, l in enumerate(open(f)) if i == 0 or any(s in l for s in ("env_", "actor_", "her_", "index_episodes"))]

@@ -2,7 +2,7 @@
 # Collects a round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only,
 #                                                               `bash profiles/collect.sh pick` to redo the pick row alone)
-# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r03_*).
+# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r04_*).
 # PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
 set -u
 REPO=$(pwd)
@@ -15,6 +15,7 @@ stats() {   # name, bench args...
   local name=$1; shift
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python "$REPO/bench.py" "$@" > "$OUT/$name.log" 2>&1
   find "$OUT/$name" -name '*kernel_stats.csv' -exec cp {} "$OUT/${name}_kernel_stats.csv" \;
+  find "$OUT/$name" -name '*kernel_trace.csv' -exec cp {} "$OUT/${name}_kernel_trace.csv" \;    # per dispatch: aggregate.py splits a symbol's launches by their length
   grep -h "^{\"metric\"" "$OUT/$name.log" | tail -1 > "$OUT/${name}_bench.json"
 }
 if [ "$MODE" = "all" ]; then

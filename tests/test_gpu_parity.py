@@ -1983,7 +1983,7 @@ def test_bench_line_contract():
     # the headline as a distribution: the identical 20-step region 15 more times on fresh action rows
     assert d["regions"] == 16 and len(d["launch_us_samples"]) == 16 and d["value_min"] <= d["value_median"] <= d["value_max"]
     assert d["value_min"] <= d["value"] <= d["value_max"] and d["launch_us_samples"][0] == pytest.approx(ro["avg_launch_us"], abs=0.01)
-    assert d["launch_us_max"] < 1.25 * d["launch_us_min"], d["launch_us_samples"]
+    assert d["launch_us_max"] < 1.3 * d["launch_us_min"], d["launch_us_samples"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["threads_1"]["cores"] == 1 and cb["threads_1"]["value"] > 5e4 and cb["value"] >= 0.8 * cb["threads_1"]["value"]
     assert cb["cores"] <= cb["host"]["affinity_cpus"]

@@ -101,9 +101,9 @@ def test_vanishing_tip_offset_reproduces_the_default_kernels_bitwise(envs, task)
     a = Env(n, device=DEV, seed=4, max_steps=25, fence_counters=1)
     b = Env(n, device=DEV, seed=4, max_steps=25, ik_tip_offset=[0.0, 0.0, 1e-300])
     a.reset(); b.reset()
-    oa = a.rollout(T, acts, want_ik_updates=True, want_diag=True)
-    ob = b.rollout(T, acts, want_ik_updates=True, want_diag=True)
-    for k in ("obs", "reward", "done", "success", "ik_updates", "diag"):
+    oa = a.rollout(T, acts, want_ik_updates=True)
+    ob = b.rollout(T, acts, want_ik_updates=True)
+    for k in ("obs", "reward", "done", "success", "ik_updates"):
         assert torch.equal(oa[k], ob[k]), (task, k)
     sa, sb = a.get_state(), b.get_state()
     for k in sa:
@@ -121,7 +121,7 @@ def test_step_diag_is_the_f64_view_of_the_step(envs, O, kuka, task):
     n, T = 4096, 40
     Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv)[task]
     rng = np.random.default_rng(3)
-    e = Env(n, device=DEV, seed=5, auto_reset=False, fence_counters=1, reach_dis=0.05)
+    e = Env(n, device=DEV, seed=5, auto_reset=False, fence_counters=2, reach_dis=0.05)
     e.reset()
     goal = _np(e.get_state()["goal"]).astype(np.float64) if task == "reach" else None
     hits = 0
@@ -144,11 +144,15 @@ def test_step_diag_is_the_f64_view_of_the_step(envs, O, kuka, task):
     assert out["diag"].shape == (7, n, 4)
     assert torch.equal(out["diag"][..., :3].float(), out["obs"][..., :3]) and torch.equal(out["diag"][..., 3].float(), out["reward"])
     from armenv import ArmEnvError
-    plain = Env(64, device=DEV)
-    plain.reset()
+    for fc in (0, 1):                   # the diagnostics belong to the fence_counters = 2 build of the kernels
+        plain = Env(64, device=DEV, fence_counters=fc)
+        plain.reset()
+        with pytest.raises(ArmEnvError):
+            plain.step(torch.zeros((64, 3), device=DEV), want_diag=True)
+        plain.close()
     with pytest.raises(ArmEnvError):
-        plain.step(torch.zeros((64, 3), device=DEV), want_diag=True)
-    plain.close(); e.close()
+        Env(64, device=DEV, fence_counters=3)
+    e.close()
 
 
 def test_n1_reach_env_reward_and_flags_come_from_the_same_numbers(envs):

@@ -50,8 +50,9 @@ swap = (rows["region_swap8"]["valu"] - rows["region_io_only"]["valu"] // 3) / 8.
 trip = fk + orient + dls + rot7 + 7
 print()
 print("one IK trip (update) ~ %d vector instructions: FK %d, orientation %d, DLS (Jacobian + J J^T + LDL^T + solves + J^T y + clamp) %d, "
-      "7 x rotate_small %d (%d each), q += dtheta 7" % (trip, fk, orient, dls, rot7, (rot7 - rot1) // 6 if rot7 > rot1 else rot1))
-print("exchange: one f64 through v_permlane32_swap_b32 = 2 swaps + repacking ~ %.1f vector instructions per value" % swap)
+      "7 x rotate_small %d (%.0f each), q += dtheta 7" % (trip, fk, orient, dls, rot7, (rot7 - rot4) / 3.0))
+print("exchange: one f64 from lane i + 32 to lane i = 2 x v_permlane32_swap_b32 at best (priced so below); as the compiler packs it today "
+      "(region_swap8): %.1f vector instructions per value" % swap)
 # the split
 per_rot = (rot7 - rot4) / 3.0
 save_rot = rot7 - rot4                    # joints 4..6 on the helper
