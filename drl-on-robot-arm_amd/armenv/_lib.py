@@ -38,7 +38,7 @@ class ArmEnvConfig(C.Structure):
         ("ik_lambda", C.c_double), ("ik_residual", C.c_double), ("ik_max_dtheta", C.c_double),
         ("ik_max_iters", C.c_int32), ("ik_exit_mode", C.c_int32), ("ik_angle_f32", C.c_int32), ("fence_counters", C.c_int32),
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
-        ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
+        ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double), ("push_place_z", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
         ("fence_z", C.c_double), ("fence_pivot", C.c_double), ("limit_erp", C.c_double), ("ik_tip_offset", C.c_double * 3),
         ("rollout_ready_lanes", C.c_int32), ("rollout_waves_per_simd", C.c_int32),

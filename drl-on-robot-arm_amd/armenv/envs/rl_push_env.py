@@ -59,6 +59,9 @@ class RLPushEnv:
     def reset(self):
         self.step_counter = 0
         cube, target = draw_push_placement()
+        # the cube is spawned at z = 0.01 (the placement test above sees it there) and comes to rest on the table: what the
+        # reference's first observation shows (fitted to its recorded push run, ArmEnvConfig.push_rest_z); the target stays
+        cube = [cube[0], cube[1], float(self._eng.cfg.push_rest_z)]
         goal = torch.tensor([cube + target], dtype=torch.float64).to(torch.float32)
         obs = self._eng.reset(goal=goal)[0].cpu().numpy()
         # keep the f64 placement exactly (the engine's reset_with_goal takes f32)

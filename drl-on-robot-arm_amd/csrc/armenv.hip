@@ -145,7 +145,10 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->push_success_dis = 0.05;
   c->push_cube_half = 0.02;
   c->push_eef_radius = 0.03;
-  c->push_rest_z = 0.01;
+  c->push_place_z = 0.01;      // rl_push_env.py:199,206 (pick :194): spawn height of cube and target
+  // where Bullet lets the cube come to rest on the table: fitted to the reference's recorded push run (visdata/push/origin_TD3), whose
+  // untouched episodes return -500 - 50 sqrt(planar^2 + 0.01474^2) to 2e-3 (tests/reference_run.py); table top -0.025 + half a cube
+  c->push_rest_z = 0.01 - 0.01474;
   c->push_place_min = 0.22;
   c->push_place_max = 0.25;
   c->pick_gripper_length = 0.257;   // rl_pick_env.py:79

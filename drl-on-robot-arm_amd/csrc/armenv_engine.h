@@ -186,6 +186,7 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
     K.push_rest_z = cfg.push_rest_z;
     K.push_place_min = cfg.push_place_min;
     K.push_place_max = cfg.push_place_max;
+    K.push_place_z = cfg.push_place_z;
     K.seed = cfg.seed;
     K.env_id0 = cfg.env_id_offset;
     P.pick_gripper_length = (T)cfg.pick_gripper_length;

@@ -19,7 +19,7 @@ template <typename T> struct EnvCold {
   T trig_init[2 * NJ];  // cos(q_init)[7], sin(q_init)[7] from the device's own sincos_all
   T lim[2 * NJ + 1];    // URDF joint limits: lower[7], upper[7]; then limit_erp (ArmEnvConfig.limit_erp, read by clamp mode 2 only)
   double goal_lo[3], goal_hi[3];
-  double push_rest_z, push_place_min, push_place_max;
+  double push_rest_z, push_place_min, push_place_max, push_place_z;
   uint64_t seed, env_id0;
 };
 
@@ -504,13 +504,15 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
 };
 
 // ---- push and pick tasks (/root/reference/envs/rl_push_env.py, envs/rl_pick_env.py) -------------------------------
-// Placement of cube and target: rejection sampling, <= 1000 tries (push :195-214, pick :190-208); f64 always.
+// Placement of cube and target: rejection sampling, <= 1000 tries (push :195-214, pick :190-208); f64 always.  Both bodies are
+// SPAWNED at z = push_place_z (0.01) and the distance test sees them there; the target is a fixed body and stays, the cube is
+// dynamic and comes to rest on the table at push_rest_z (fitted to the reference's recorded push run: 14.74 mm lower).
 //   push: six draws per try (x, y, yaw, x_t, y_t, yaw_t), both bodies at the rest height, planar distance test;
 //   pick: seven draws per try (x, y, yaw, x_t, y_t, z_t, yaw_t), target anywhere in the workspace box, 3-D distance.
 template <bool PICK, typename T>
 AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&cube)[3], T (&target)[3]) {
   const EnvCold<T> &K = *P.cold;
-  double cx = 0, cy = 0, tx = 0, ty = 0, tz = K.push_rest_z;
+  double cx = 0, cy = 0, tx = 0, ty = 0, tz = K.push_place_z;    // push: the target is a fixed body at its spawn height (:206, :221-224)
   constexpr uint32_t kBlocks = PICK ? 4u : 3u;
   for (uint32_t t = 0; t < 1000u; ++t) {
     double u0, u1, u2, u3, u4, u5;
@@ -525,10 +527,10 @@ AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&
     double d;
     if constexpr (PICK) {
       tz = K.goal_lo[2] + (K.goal_hi[2] - K.goal_lo[2]) * u5;      // 7th draw (u6, the target yaw) is unused
-      const double dz = K.push_rest_z - tz;
+      const double dz = K.push_place_z - tz;                      // the test sees the cube at its spawn height (:193-207)
       d = ::sqrt(::fma(dx, dx, ::fma(dy, dy, dz * dz)));
     } else {
-      d = ::sqrt(::fma(dx, dx, dy * dy));   // both rest at the same z
+      d = ::sqrt(::fma(dx, dx, dy * dy));   // both are spawned at the same z (:199, :206)
       (void)u5;
     }
     (void)u2;

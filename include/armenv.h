@@ -127,9 +127,12 @@ typedef struct ArmEnvConfig {
   double push_success_dis; /* 0.05  :422 (pick :425) */
   double push_cube_half;   /* 0.02  models/cube_small_push.urdf */
   double push_eef_radius;  /* pusher radius of the simplified contact model (pick: radius of the gripper tip) */
-  double push_rest_z;      /* z at which the cube rests */
+  double push_rest_z;      /* z at which the cube rests on the table: -0.00474 = 14.74 mm below its spawn height, fitted to the
+                              reference's recorded push run */
   double push_place_min;   /* 0.22  :213 (pick :207) */
   double push_place_max;   /* 0.25  :213 (pick :207) */
+  double push_place_z;     /* 0.01  :199,206 (pick :194): height at which cube and (push) target are spawned; the placement test sees
+                              both there, the fixed target stays, the cube settles to push_rest_z */
 
   /* pick task, /root/reference/envs/rl_pick_env.py: gripper model (build-defined) */
   double pick_gripper_length; /* 0.257 :79 -- the gripper tip sits this far along the tool axis from the link-7 frame */

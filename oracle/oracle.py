@@ -83,7 +83,7 @@ class OrcConfig(C.Structure):
         ("ik_max_iters", C.c_int32), ("ik_exit_mode", C.c_int32), ("ik_angle_f32", C.c_int32),
         ("ik_form", C.c_int32),
         ("push_success_dis", C.c_double), ("push_cube_half", C.c_double), ("push_eef_radius", C.c_double),
-        ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double),
+        ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double), ("push_place_z", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
         ("clamp_joint_limits", C.c_int32), ("pad0", C.c_int32), ("lim_lo", C.c_double * NJ), ("lim_hi", C.c_double * NJ),
         ("fence_z", C.c_double), ("limit_erp", C.c_double), ("fence_pivot", C.c_double), ("ik_tip_offset", C.c_double * 3),
@@ -173,7 +173,8 @@ def default_config(task="reach", robot="kuka"):
     c.push_success_dis = 0.05
     c.push_cube_half = 0.02
     c.push_eef_radius = 0.03
-    c.push_rest_z = 0.01
+    c.push_place_z = 0.01              # rl_push_env.py:199,206: spawn height of cube and target
+    c.push_rest_z = 0.01 - 0.01474     # where the cube comes to rest (fitted to the reference's recorded push run)
     c.push_place_min = 0.22
     c.push_place_max = 0.25
     c.pick_gripper_length = 0.257      # rl_pick_env.py:79

@@ -26,6 +26,8 @@ reference's importable Python (config, algo.TD3) -- never reference source text.
                                EXECUTING the reference's own rejection-sampling loop (envs/rl_push_env.py:195-214,
                                envs/rl_pick_env.py:190-208; extracted from the module's AST because the module itself
                                imports pybullet) under random.seed(0)
+  G13 visdata_push_td3.json, td3_actor9_seed0.npz   the first 40 per-episode returns of visdata/push/origin_TD3/TD3.json (one
+                               train_push_with_TD3 run, main.py:449-515) and the untrained 9-input TD3 actor of torch.manual_seed(0)
   G12 visdata_reach_td3.json   the y values of visdata/reach/TD3_0.01/Reach_TD3.json: per-episode return (351), 10-episode mean
                                return (35), 25-episode success rate (14) of one train_reach_with_TD3 run (main.py:165-231) --
                                the reference's only record of how this env BEHAVES (tests/tools/learning_curve_check.py)
@@ -450,7 +452,28 @@ def g12_visdata_reach_td3():
     json.dump(out, open(os.path.join(OUT, "visdata_reach_td3.json"), "w"))
 
 
+def g13_visdata_push_td3():
+    """visdata/push/origin_TD3/TD3.json: one train_push_with_TD3 run (main.py:449-515) -- the one of the two recorded push runs whose
+    numbers fit the reward code the reference ships (an episode in which the arm never touches the cube returns 500 x -1 and a final
+    -50 * distance).  First 40 per-episode returns (episode 33 is the run's first success; until then every episode has 501 steps
+    and the `random` stream is a fixed function of the seed), and the untrained 9-input TD3 actor of torch.manual_seed(0)."""
+    d = json.load(open(os.path.join(REF, "visdata", "push", "origin_TD3", "TD3.json")))["jsons"]
+    y = [float(v) for v in d["return"]["content"]["data"][0]["y"]]
+    assert len(y) == 5000
+    json.dump({"source": "visdata/push/origin_TD3/TD3.json (visdom export; y values of the 'return' window, first 40 of 5000)",
+               "protocol": "main.py:449-515 train_push_with_TD3: one env, a = actor(s) + N(0, 0.4 * 0.98) unclipped, seed 0, 501-step episodes",
+               "return_per_episode": y[:40]}, open(os.path.join(OUT, "visdata_push_td3.json"), "w"))
+    import torch
+    sys.path.insert(0, REF)
+    from algo.TD3.TD3_mlp import TD3_MLP
+    torch.manual_seed(0)
+    agent = TD3_MLP(9, 3, 0.4, 256, 1e-3, 1e-3, 0.1, 0.005, 0.98, 0.2, 0.5, 3, torch.device("cpu"))
+    np.savez_compressed(os.path.join(OUT, "td3_actor9_seed0.npz"),
+                        **{k.replace(".", "_"): v.detach().numpy().copy() for k, v in agent.actor.state_dict().items()})
+
+
 if __name__ == "__main__":
+    g13_visdata_push_td3()
     g12_visdata_reach_td3()
     g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements(); g10_config_fields(); g11_ddpg_datd3_take_action()
     print("fixtures written to", OUT)

@@ -81,3 +81,81 @@ def replay_on_oracle(O, episodes=5, configure=None, action_f32=False):
             ret += float(r[0]); n += 1; done = bool(d[0]); succ = bool(s[0])
         out.append((ret, n, succ))
     return out, fence
+
+
+# ------------------------------------------------------------------------------ the recorded push run
+# tests/golden/visdata_push_td3.json: first 40 per-episode returns of visdata/push/origin_TD3/TD3.json (train_push_with_TD3,
+# main.py:449-515, seed 0).  Bullet's cube dynamics are not restated (the build's contact model is its own), so only what does
+# not depend on them is compared:
+#   * an episode in which the arm never touches the cube returns 500 x (-1) (rl_push_env.py:393-394,427) and a final
+#     -50 * |cube - target| (:418-420), i.e. -500 - 50 sqrt(planar^2 + dz^2): planar = the placement distance of that reset --
+#     a fixed function of random.seed(0) while every episode lasts 501 steps (6 draws per placement try :197-209, 3 per step
+#     :435-437) -- and dz = what the dynamic cube sinks below the fixed target while it settles on the table.  Episodes 4, 6, 13,
+#     24 of the recorded run fit ONE dz = 14.74 mm to 2e-3: the placement stream, the draw counts and ArmEnvConfig.push_rest_z;
+#   * WHICH of the first five episodes (before any network update) touch the cube at all: T T T - T.
+
+def push_fixture_returns():
+    return json.load(open(os.path.join(GOLDEN, "visdata_push_td3.json")))["return_per_episode"]
+
+
+def actor9_weights():
+    g = np.load(os.path.join(GOLDEN, "td3_actor9_seed0.npz"))
+    return {k: g[k.replace(".", "_")] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+
+
+def draw_push_placement():
+    """rl_push_env.py:195-214 on Python's global `random`: (cube xy, target xy, planar distance)"""
+    import math
+    x = y = xt = yt = d = 0.0
+    for _ in range(1000):
+        x = random.uniform(_LO[0], _HI[0]); y = random.uniform(_LO[1], _HI[1]); random.random()
+        xt = random.uniform(_LO[0], _HI[0]); yt = random.uniform(_LO[1], _HI[1]); random.random()
+        d = math.sqrt((x - xt) ** 2 + (y - yt) ** 2 + (0.01 - 0.01) ** 2)
+        if 0.22 <= d <= 0.25:
+            break
+    return [x, y], [xt, yt], d
+
+
+def push_untouched_returns(episodes, dz):
+    """what each of the first `episodes` episodes returns if its cube is never touched (valid while all earlier ones had 501 steps)"""
+    import math
+    random.seed(0)
+    out = []
+    for _ in range(episodes):
+        _, _, d = draw_push_placement()
+        for _ in range(501 * 3):
+            random.uniform(0.0, 1.0)
+        out.append(-500.0 - 50.0 * float(np.float32(math.sqrt(d * d + dz * dz))))
+    return out
+
+
+def replay_push_on_oracle(O, episodes=5, configure=None):
+    """The first `episodes` episodes of the recorded push run on the oracle's push env (its own contact model).
+    Returns [(return, length, steps on which the cube moved)]."""
+    import math
+    chain = O.make_chain("kuka")
+    cfg = O.default_config("push")
+    if configure:
+        configure(cfg)
+    sd = actor9_weights()
+    random.seed(0); np.random.seed(0)
+    st = O.PushState(1)
+    out = []
+    for ep in range(episodes):
+        c, t, _ = draw_push_placement()
+        cube, tgt = c + [float(cfg.push_rest_z)], t + [float(cfg.push_place_z)]
+        obs = O.push_reset_with_goal(chain, cfg, st, np.float32([cube + tgt]))[0]
+        st.aux[0, 0:3] = cube; st.aux[0, 3:6] = tgt
+        st.aux[0, 6] = math.sqrt(sum((a - b) ** 2 for a, b in zip(cube, tgt)))
+        done, ret, n, moved = False, 0.0, 0, 0
+        while not done:
+            state = np.hstack((obs[:3].astype(np.float32), st.aux[0, 0:3], st.aux[0, 3:6])).astype(np.float32)   # :308, then torch.float
+            a = O.actor_forward(sd, state[None], 0.4)[0].astype(np.float64) + np.random.normal(0, 0.4 * 0.98, size=3)   # main.py:481-484
+            c0 = st.aux[0, 0:3].copy()
+            o, r, d, s, _ = O.push_step(chain, cfg, st, a.astype(np.float32)[None])
+            for k in range(3):
+                random.uniform(_LO[k], _HI[k])                                   # :435-437
+            moved += int(np.abs(st.aux[0, 0:3] - c0).max() > 0)
+            obs = o[0]; ret += float(r[0]); n += 1; done = bool(d[0])
+        out.append((ret, n, moved))
+    return out

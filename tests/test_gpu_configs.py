@@ -232,3 +232,32 @@ def test_n1_env_reproduces_the_reference_runs_first_episodes(envs):
     diffs = [abs(r - x) for (r, _, _), x in zip(got, fx)]
     assert max(diffs) < 2e-3, diffs
     assert c["limit_steps"] > 200 and c["low_flange_steps"] > 200 and c["cap_steps"] == 0
+
+
+def test_n1_push_env_on_the_recorded_push_runs_first_episodes(envs):
+    """The first five episodes of the reference's recorded train_push_with_TD3 run (tests/golden/visdata_push_td3.json, real
+    PyBullet, seed 0; tests/reference_run.py) through the N=1 drop-in `envs.RLPushEnv` on the HIP engine: all five run to the time
+    limit, the arm touches the cube in episodes 1, 2, 3, 5 and not in 4 (the recorded run's own pattern), and episode 4 -- the
+    one that does not depend on Bullet's cube dynamics -- returns the recorded -512.0719 to 1e-4: placement stream, draw counts,
+    the cube's rest height and the reward arithmetic of rl_push_env.py:368-440 against real numbers."""
+    import reference_run as R
+    from armenv.td3 import TD3
+    fx = R.push_fixture_returns()
+    env = envs.RLPushEnv(is_render=False, is_good_view=False)                      # main.py:454
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)                        # main.py:459-461
+    agent = TD3(9, 3, 0.4, device=DEV)
+    agent.actor.load_state_dict({k: torch.from_numpy(v) for k, v in R.actor9_weights().items()})
+    got = []
+    for ep in range(5):
+        state = env.reset(); done, ret, n, moved = False, 0.0, 0, 0
+        cube0 = state[3:6].copy()
+        while not done:
+            action = agent.take_action(state) + np.random.normal(0, 0.4 * 0.98, size=3)        # main.py:481-484
+            state, reward, done, info = env.step(action)
+            moved += int(np.abs(state[3:6] - cube0).max() > 0); cube0 = state[3:6].copy()
+            ret += reward; n += 1
+        got.append((ret, n, moved))
+    env.close()
+    assert [n for _, n, _ in got] == [501] * 5
+    assert [m > 0 for _, _, m in got] == [True, True, True, False, True]
+    assert abs(got[3][0] - fx[3]) < 1e-4, (got[3][0], fx[3])

@@ -1019,12 +1019,15 @@ def test_push_full_size_properties_32768(envs):
     n = 32768
     e = envs.BatchedPushEnv(n, device=DEV, seed=1)
     obs = e.reset()
-    d = (obs[:, 3:6] - obs[:, 6:9]).double().norm(dim=1)
+    d = (obs[:, 3:5] - obs[:, 6:8]).double().norm(dim=1)           # the placement test sees both bodies at their spawn height (:199,206,213)
     assert float(d.min()) >= 0.22 - 1e-6 and float(d.max()) <= 0.25 + 1e-6
+    rest = float(e.cfg.push_rest_z)                                # the cube at rest on the table, the fixed target where it was spawned
+    assert bool((obs[:, 5] == np.float32(rest)).all()) and bool((obs[:, 8] == np.float32(0.01)).all()) and abs(rest + 0.00474) < 1e-12
     e.set_policy("random", action_bound=0.4, noise_sigma=0.4 * 0.98, noise_clip=1e9)      # main.py:457,484
     out = e.rollout(40, None)
-    eef = out["obs"][..., :3]
+    eef = out["obs"][..., :3][~out["done"]]            # (a finished env's row shows its next episode's first observation)
     assert float(eef[..., 2].max()) <= 0.1 + 2e-4 and float(eef[..., 2].min()) >= -2e-4
+    assert float(out["done"].float().mean()) < 1e-4      # a lucky sweep can deliver the cube within 40 steps; it is rare
     idle = (out["obs"][1:, :, 3:6] == out["obs"][:-1, :, 3:6]).all(-1) & ~out["done"][1:] & ~out["done"][:-1]
     assert bool((out["reward"][1:][idle] == -1.0).all()) and float(idle.float().mean()) > 0.9
     c = e.counters()
@@ -1041,8 +1044,8 @@ def test_rlpushenv_compat_surface(envs):
     assert abs(action_bound - 0.4) < 1e-7                                # main.py:457
     state = env.reset()
     assert state.shape == (9,) and state.dtype == np.float64
-    d = np.linalg.norm(state[3:6] - state[6:9])
-    assert 0.22 <= d <= 0.25 and state[5] == 0.01 and state[8] == 0.01
+    d = np.linalg.norm(state[3:5] - state[6:8])                          # planar: both bodies are spawned at z = 0.01 (:199,206)
+    assert 0.22 <= d <= 0.25 and abs(state[5] - (0.01 - 0.01474)) < 1e-12 and state[8] == 0.01       # cube at rest, target fixed
     for _ in range(5):
         action = np.zeros(3) + np.random.normal(0, action_bound * 0.98, size=3)
         state, reward, done, info = env.step(action)
@@ -1084,8 +1087,9 @@ def test_pick_reset_matches_oracle(envs, O, kuka):
     aux = _np(s["aux"])
     assert aux.shape == (n, 12) and np.array_equal(aux[:, :6], st.aux[:, :6]) and np.abs(aux[:, 6] - st.aux[:, 6]).max() < 1e-15
     assert not aux[:, 7:].any()                                          # gripper open, nothing held
-    d = np.linalg.norm(aux[:, 0:3] - aux[:, 3:6], axis=1)                # rl_pick_env.py:205-208: 3-D distance
-    assert d.min() >= 0.22 and d.max() <= 0.25 and (aux[:, 2] == 0.01).all()
+    spawn = aux[:, 0:3].copy(); spawn[:, 2] = 0.01                       # :194: the test sees the cube at its spawn height
+    d = np.linalg.norm(spawn - aux[:, 3:6], axis=1)                      # rl_pick_env.py:205-208: 3-D distance
+    assert d.min() >= 0.22 and d.max() <= 0.25 and (aux[:, 2] == cfg.push_rest_z).all()
     assert aux[:, 5].min() >= 0.0 and aux[:, 5].max() <= 0.26 and aux[:, 5].std() > 0.03   # target floats above the table
     assert np.array_equal(_np(s["q"]), st.q)
     e.close()
@@ -1219,11 +1223,11 @@ def test_pick_gripper_model_properties(envs):
         aux = e.get_state()["aux"]
         grip = aux[:, 7]
         assert bool((grip >= grip_prev).all())                          # 0 -> 1 / 2, never back
-        assert float(aux[:, 2].min()) >= 0.01 - 1e-12
+        assert float(aux[:, 2].min()) >= float(e.cfg.push_rest_z) - 1e-12
         held = (grip == 2) & (grip_prev == 2)
         if rel_prev is not None and bool(held.any()):
             fk_p, fk_q = e.fk(e.get_state()["q"])
-            lifted = held & (aux[:, 2] > 0.0101)                        # above the table: exactly tip + offset
+            lifted = held & (aux[:, 2] > float(e.cfg.push_rest_z) + 1e-4)    # above the table: exactly tip + offset
             w, x, y, z = fk_q[:, 3], fk_q[:, 0], fk_q[:, 1], fk_q[:, 2]
             axis = torch.stack([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], 1)
             tip = fk_p + 0.257 * axis
@@ -1254,10 +1258,12 @@ def test_rlpickenv_compat_surface(envs):
     assert abs(float(env.observation_space.high[2]) - (0.55 + 0.257)) < 1e-6             # rl_pick_env.py:94-97
     state = env.reset()
     assert state.shape == (9,) and state.dtype == np.float64
-    d = np.linalg.norm(state[3:6] - state[6:9])
-    assert 0.22 <= d <= 0.25 and state[5] == 0.01 and 0.0 <= state[8] <= 0.55
+    spawn = state[3:6].copy(); spawn[2] = 0.01                                            # :194
+    d = np.linalg.norm(spawn - state[6:9])
+    assert 0.22 <= d <= 0.25 and abs(state[5] - (0.01 - 0.01474)) < 1e-12 and 0.0 <= state[8] <= 0.55
     g = golden_json("py_random_pick_seed0.json")                                         # the reference's draw pattern
-    assert list(state[3:6]) == g["placements"][0]["cube"] and list(state[6:9]) == g["placements"][0]["target"]
+    # the fixture holds the SPAWN poses of the reference's loop (cube z = 0.01); the observed cube has come to rest on the table
+    assert list(state[3:5]) == g["placements"][0]["cube"][:2] and list(state[6:9]) == g["placements"][0]["target"]
     for _ in range(5):
         action = np.zeros(3) + np.random.normal(0, 0.4 * 0.98, size=3)
         state, reward, done, info = env.step(action)
@@ -1265,7 +1271,7 @@ def test_rlpickenv_compat_surface(envs):
         assert info["is_success"].dtype == np.float32 and reward == -1.0 and not done
     assert env.gripper_state == 0
     state = env.reset()
-    assert list(state[3:6]) == g["placements"][1]["cube"] and list(state[6:9]) == g["placements"][1]["target"]
+    assert list(state[3:5]) == g["placements"][1]["cube"][:2] and list(state[6:9]) == g["placements"][1]["target"]
     env.close()
 
 
