@@ -32,9 +32,10 @@ def actor_weights():
     return {k: g[k.replace(".", "_")] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
 
 
-def replay_on_oracle(O, episodes=5, configure=None, action_f32=False):
+def replay_on_oracle(O, episodes=5, configure=None, action_f32=False, record=None):
     """The first `episodes` episodes of the run on the oracle.  configure(cfg): flips switches of the OrcConfig.
-    Returns [(return, length, success)], and the number of steps on which the limit / flange fence terms fired."""
+    Returns [(return, length, success)], and the number of steps on which the limit / flange fence terms fired.
+    record (optional list): receives per episode (goal f32[3], actions f64[T][3]) -- the open-loop form of the run."""
     chain = O.make_chain("kuka")
     cfg = O.default_config()
     if configure:
@@ -56,9 +57,11 @@ def replay_on_oracle(O, episodes=5, configure=None, action_f32=False):
         obs = O.reach_reset_with_goal(chain, cfg, st, np.float32([goal]))[0]
         g64 = obs[3:].astype(np.float64)
         done, ret, n, succ = False, 0.0, 0, False
+        acts = []
         while not done:
             a = O.actor_forward(sd, obs[None].astype(np.float32), 0.7)[0].astype(np.float64)      # TD3_MLP.take_action
             a = a + np.random.normal(0, 1 * 0.98, size=3)                   # main.py:200
+            acts.append(a.copy())
             q0 = st.q.copy()
             if action_f32:
                 o, r, d, s, _ = O.reach_step(chain, cfg, st, a.astype(np.float32)[None])
@@ -80,6 +83,8 @@ def replay_on_oracle(O, episodes=5, configure=None, action_f32=False):
             obs = np.asarray(o[0], dtype=np.float32)
             ret += float(r[0]); n += 1; done = bool(d[0]); succ = bool(s[0])
         out.append((ret, n, succ))
+        if record is not None:
+            record.append((obs[3:].astype(np.float32).copy(), np.asarray(acts)))
     return out, fence
 
 

@@ -261,3 +261,36 @@ def test_n1_push_env_on_the_recorded_push_runs_first_episodes(envs):
     assert [n for _, n, _ in got] == [501] * 5
     assert [m > 0 for _, _, m in got] == [True, True, True, False, True]
     assert abs(got[3][0] - fx[3]) < 1e-4, (got[3][0], fx[3])
+
+
+@pytest.mark.parametrize("precision", [64, 32])
+def test_benchmarked_rollout_kernel_reproduces_the_reference_run(envs, O, precision):
+    """The kernel bench.py times -- env_rollout_kernel<ReachLane<KukaChain, double, 0>, double, 0, 1>: the compile-time KUKA fast
+    path, default build, external actions, one launch per episode -- against real PyBullet's numbers: the first five episodes of
+    the reference's recorded run (tests/reference_run.py) in open-loop form (goals and the 2 068 actions as the oracle's replay of
+    the run produces them), 64 lanes fed the same env.  Sum of the launch's f32 reward rows against the recorded returns: 3e-3
+    (f64 engine; measured 6e-4 + the f32 rounding of 501 rewards), success exactly at step 64 of episode 1, every lane the same
+    bits.  precision = 32: the f32 engine on the four 501-step episodes, within 1.0 of ~1 500 (its stated 1e-4-per-step class;
+    episode 1's success test at 1 cm is a threshold an f32 trajectory may cross a step early or late)."""
+    import reference_run as R
+    fx = R.fixture_returns()
+    rec = []
+    out, _ = R.replay_on_oracle(O, 5, record=rec)
+    n = 64
+    e = envs.BatchedReachEnv(n, device=DEV, auto_reset=False, precision=precision)
+    assert e.kernel_name == "reach_step<f%d,kuka>" % precision
+    for ep, ((goal, acts), (_, length, succ)) in enumerate(zip(rec, out)):
+        T = len(acts)
+        assert T == length
+        if precision == 32 and succ:
+            continue
+        e.reset(goal=torch.from_numpy(np.tile(goal, (n, 1))))
+        a = torch.from_numpy(np.tile(acts.astype(np.float32)[:, None, :], (1, n, 1))).contiguous().to(DEV)
+        o = e.rollout(T, a)
+        ret = o["reward"].double().sum(0)
+        assert bool((ret == ret[0]).all()) and bool((o["obs"] == o["obs"][:, :1]).all())          # 64 lanes, one trajectory
+        tol = 3e-3 if precision == 64 else 1.0
+        assert abs(float(ret[0]) - fx[ep]) < tol, (ep, float(ret[0]), fx[ep])
+        done = o["done"][:, 0].cpu().numpy()
+        assert done[-1] and not done[:-1].any() and bool(o["success"][-1, 0]) == succ
+    e.close()

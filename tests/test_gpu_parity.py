@@ -1032,6 +1032,7 @@ def test_push_full_size_properties_32768(envs):
     assert bool((out["reward"][1:][idle] == -1.0).all()) and float(idle.float().mean()) > 0.9
     c = e.counters()
     assert c["env_steps"] == n * 40 and c["nonfinite"] == 0
+    assert c["episodes"] == c["successes"] == int(out["done"].sum())      # nothing times out in 40 steps: every finish is a delivery
     e.close()
 
 
