@@ -18,7 +18,7 @@ _LO, _HI = (0.2, -0.3, 0), (0.7, 0.3, 0.55)
 
 def draw_pick_placement():
     """Rejection sampling of cube / target positions, rl_pick_env.py:190-208 (<= 1000 tries, last one kept): the cube
-    lies on the table (z = 0.01), the target floats anywhere in the workspace box, 0.22 <= 3-D distance <= 0.25."""
+    is spawned on the table (z = 0.01; it then settles to ArmEnvConfig.push_rest_z), the target floats anywhere in the workspace box, 0.22 <= 3-D distance <= 0.25."""
     xpos = ypos = xt = yt = zt = 0.0
     for _ in range(1000):
         xpos = random.uniform(_LO[0], _HI[0])
