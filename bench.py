@@ -82,7 +82,8 @@ F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X f64 vector (FMA = 2 flop), 1/2 of the 15
 IO_BYTES = 12 + 24 + 4 + 1 + 1                 # action in; obs, reward, done, success out
 # q, (cos q, sin q), ep_return read + written; goal read; step read + written
 STATE_BYTES = {64: 2 * (56 + 112 + 8) + 12 + 2 * 4, 32: 2 * (28 + 56 + 4) + 12 + 2 * 4}
-F64_ISSUE_CYCLES_ONE_WAVE = 6.6   # issue interval of f64 vector instructions from ONE wave (nominal pipe rate: 4): a builder probe of round 3, a constant here
+F64_ISSUE_CYCLES_ONE_WAVE = 6.6   # round 3's stand-alone probe (profiles/r03_valu_f64_rate_probe.txt); since round 4 the bench line measures it in the run (issue_probe)
+NOMINAL_GHZ = 2.4
 # algorithmic flops of the f64/f32 reach step: per IK update and per FK-only exit trip
 FLOPS_PER_UPDATE, FLOPS_PER_EXIT_FK = 1250, 510   # update trip; exit FK + residual + per-step sincos/reward
 
@@ -174,6 +175,29 @@ def traffic_lookup(kernel, policy, steps_per_launch, n):
     return traffic, key
 
 
+_ISSUE_PROBE = {}
+
+
+def issue_probe():
+    """The single-wave f64 issue interval of THIS device in THIS run (library diagnostic armenv_probe_issue_rate: sixteen
+    independent v_fma_f64 chains per wave, one / two waves on every SIMD; v_fma_f32 beside it).  Measured once per process, on a
+    device the caller has already warmed.  None if the probe fails (the bench line then carries no one_wave_per_simd)."""
+    if not _ISSUE_PROBE:
+        import ctypes as C
+        from armenv import _lib
+        lib, d = _lib.load(), torch.cuda.current_device()
+        out = {}
+        for key, prec, w in (("ns_1", 64, 1), ("ns_2", 64, 2), ("ns_f32", 32, 1)):
+            v = C.c_double(0.0)
+            if lib.armenv_probe_issue_rate(d, prec, w, C.byref(v)) != 0 or not v.value > 0:
+                _ISSUE_PROBE["failed"] = True
+                return None
+            out[key] = v.value
+        out["simds"] = 4 * torch.cuda.get_device_properties(d).multi_processor_count
+        _ISSUE_PROBE.update(out)
+    return None if _ISSUE_PROBE.get("failed") else _ISSUE_PROBE
+
+
 def rooflines(task, policy, precision, n, steps_per_launch, launch_us, updates, kernel):
     """(roofline, valu, mfma-or-None) of one launch shape: algorithmic HBM bytes against 8 TB/s (with the PMC traffic of the
     same shape when profiles/traffic.json has it), algorithmic flops against the vector peak (the bound that binds: 29 flop/B,
@@ -187,12 +211,18 @@ def rooflines(task, policy, precision, n, steps_per_launch, launch_us, updates, 
     valu = {"bound": "valu", "achieved": tf, "peak": vpeak, "unit": "TFLOP/s", "frac": tf / vpeak,
             "ik_updates_per_env_step": updates, "algo_flops_per_launch": flops}
     if precision == 64:
-        # measured, not nominal (profiles/r03_valu_f64_rate_probe.txt): one wave issues an f64 vector instruction every ~6.6 cycles,
-        # the pipe's 4-cycle rate needs several waves per SIMD; the env kernels run one wave per SIMD (two in large_batch: 5.8)
-        valu["one_wave_per_simd"] = {"cycles_per_f64_instruction": F64_ISSUE_CYCLES_ONE_WAVE, "peak": vpeak * 4.0 / F64_ISSUE_CYCLES_ONE_WAVE,
-                                     "frac": tf / (vpeak * 4.0 / F64_ISSUE_CYCLES_ONE_WAVE),
-                                     "source": "builder probe of round 3 (tests/tools/exp/valu_f64_rate_probe.hip, profiles/r03_valu_f64_rate_probe.txt), "
-                                               "NOT measured in this run; the nominal peak above is the creditable one"}
+        # measured IN THIS RUN (armenv_probe_issue_rate, ~30 ms once per process): one wave per SIMD issues independent v_fma_f64
+        # every ~6.6 cycles, the pipe's nominal 4-cycle rate needs several waves per SIMD; the env kernels run one wave per SIMD
+        # (two in large_batch).  The nominal peak above stays the creditable one.
+        pr = issue_probe()
+        if pr:
+            peak1 = 64 * 2 * pr["simds"] / pr["ns_1"] * 1e-3      # TFLOP/s of pure FMAs at the measured single-wave issue interval
+            valu["one_wave_per_simd"] = {"ns_per_f64_instruction": pr["ns_1"], "cycles_per_f64_instruction": pr["ns_1"] * NOMINAL_GHZ,
+                                         "peak": peak1, "frac": tf / peak1, "two_waves_per_simd_ns": pr["ns_2"],
+                                         "f32_ns_per_instruction": pr["ns_f32"], "simds": pr["simds"],
+                                         "source": "measured in this run: armenv_probe_issue_rate (back-to-back independent v_fma_f64, vector "
+                                                   "operands, one wave on every SIMD); cycles at the nominal %.1f GHz; round 3's stand-alone probe "
+                                                   "(profiles/r03_valu_f64_rate_probe.txt) gave %.1f" % (NOMINAL_GHZ, F64_ISSUE_CYCLES_ONE_WAVE)}
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_key": key, "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
             "binding_bound": "valu", "valu": valu}
@@ -492,7 +522,11 @@ def main():
     # one rank per GPU over RCCL; if the node has fewer GPUs than ranks (debugging on a 1-GPU box) the ranks share
     # GPUs and the logging collective falls back to gloo -- reported in config.parallelism
     backend = "nccl" if world <= ndev else "gloo"
-    init_process_group(backend, dev if backend == "nccl" else None)
+    # ARMENV_BENCH_COLLECTIVE=1: a ONE-rank job takes the multi-rank path too -- process group, barriers, the logging all-gather on
+    # the side stream, the max-over-ranks reductions -- so that a 1-GPU box executes every RCCL call an 8-GPU node would
+    # (tests/test_gpu_fence.py::test_bench_one_rank_over_rccl).  Launch under torch.distributed.run --nproc-per-node 1.
+    multi = world > 1 or os.environ.get("ARMENV_BENCH_COLLECTIVE") == "1"
+    init_process_group(backend, dev if backend == "nccl" else None, force=multi)
 
     n = args.envs_per_gpu
     Env = {"reach": envs.BatchedReachEnv, "push": envs.BatchedPushEnv, "pick": envs.BatchedPickEnv}[args.task]
@@ -518,7 +552,7 @@ def main():
                 raise SystemExit("--policy actor: the golden actor has 6 inputs (reach)")
         env.set_policy(args.policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if args.task == "reach" else 1e9,
                        actor_state_dict=sd)
-    gather = ReturnGatherer(n, dev, world)
+    gather = ReturnGatherer(n, dev, world, collective=multi)
     env.reset()
     R = max(1, min(args.rollout_steps, args.steps))
     R = min(R, S)
@@ -545,7 +579,7 @@ def main():
             for i in range(k):
                 a = next_actions(1)[0]
                 ops.append(lambda a=a: env.step(a))
-                if world > 1 and (i + 1) % args.gather_every == 0:
+                if multi and (i + 1) % args.gather_every == 0:
                     ops.append(do_gather); gathers += 1
         else:
             done_steps = 0
@@ -555,9 +589,9 @@ def main():
                 launch, _ = env.bind_rollout(r, a_in, out=bufs if r == R else None)
                 ops.append(launch)
                 done_steps += r
-                if world > 1 and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
+                if multi and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
                     ops.append(do_gather); gathers += 1
-        if world > 1 and gathers == 0:
+        if multi and gathers == 0:
             # a region shorter than --gather-every (the driver's 20 steps) still carries one all-gather, of the returns as they
             # stand AFTER its steps: episode_stats is enqueued behind the launches and the collective (side stream) waits for it
             ops.append(do_gather); gathers = 1
@@ -578,12 +612,12 @@ def main():
         evs.record(0); evs.record(1)  # first use outside the region
         torch.cuda.synchronize(dev)
         c0 = env.counters()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
         p = time.perf_counter
         cur = torch.cuda.current_stream(dev)
-        trailing = world > 1 and len(ops) > 1 and ops[-1] is do_gather     # the region's last op is a logging gather
+        trailing = multi and len(ops) > 1 and ops[-1] is do_gather     # the region's last op is a logging gather
         step_ops = ops[:-1] if trailing else ops
         t0 = p()
         evs.record(0)
@@ -604,11 +638,11 @@ def main():
         evs.stream_synchronize()
         wall_steps = p() - t0
         te = p()
-        if world > 1:
+        if multi:
             gather.result()          # orders the launch stream behind the collective ...
             torch.cuda.synchronize(dev)   # ... and the device synchronise of the bracket waits for it
         tf = p()
-        if world > 1:
+        if multi:
             dist.barrier()
         wall = p() - t0              # barrier + synchronise to synchronise + barrier: the contract's clock
         tg = p()
@@ -622,7 +656,7 @@ def main():
 
     prewarm_device(Env, n, dev, args.precision, args.prewarm_ms)
     run(args.warmup)
-    snap = {k: v.clone() for k, v in env.get_state().items()} if (world == 1 and args.repeat_regions > 0) else None
+    snap = {k: v.clone() for k, v in env.get_state().items()} if (not multi and args.repeat_regions > 0) else None
     wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps)
     host_us_main = dict(host_us)
 
@@ -640,7 +674,7 @@ def main():
 
     t = torch.tensor([wall, gpu_ms * 1e-3, wall_steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     per_rank = None
-    if world > 1:       # every rank's wall clock and kernel time of the region (stragglers show here); value uses the MAX wall
+    if multi:       # every rank's wall clock and kernel time of the region (stragglers show here); value uses the MAX wall
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = {"wall_ms": [float(x[0]) * 1e3 for x in allt], "kernel_ms": [float(x[1]) * 1e3 for x in allt],
@@ -655,7 +689,7 @@ def main():
         import hashlib
         mine = hashlib.sha256(env.get_state()["q"].cpu().numpy().tobytes()).hexdigest()
         digests = [mine]
-        if world > 1:
+        if multi:
             digests = [None] * world
             dist.all_gather_object(digests, mine)
             # one more logging all-gather, of the returns as they stand after the run: what every rank now holds
@@ -664,7 +698,7 @@ def main():
             gathered = {"sha256": hashlib.sha256(g_all.tobytes()).hexdigest(), "mean": float(g_all.astype(np.float64).mean())}
 
     step_api = None
-    if args.mode == "rollout" and world == 1 and args.policy == "external":
+    if args.mode == "rollout" and not multi and args.policy == "external":
         args.mode = "step"                      # the gym-style one-launch-per-step path, timed beside the headline
         k2 = min(args.steps, 500)
         run(10)
@@ -742,7 +776,7 @@ def main():
                                       "timed region (logging only, side stream; waited for INSIDE the clock of `value` -- host_us.gather_wait -- "
                                       "and outside the clock of `value_steps`)"
                                       % (world, "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: debug)", args.gather_every)
-                                      if world > 1 else "single GPU"},
+                                      if multi else "single GPU"},
             # `roofline.binding_bound` / `roofline.valu`: the bound that BINDS: 29 flop/B
             # puts the path right of the ridge -- the same launch against the f64 (f32) vector peak
             "roofline": roof,
@@ -768,23 +802,23 @@ def main():
                 line[name] = fn()
             except Exception as e:       # noqa: BLE001
                 line[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        if world == 1 and args.fence_steps > 0:
+        if not multi and args.fence_steps > 0:
             leg("parity_fence", lambda: parity_fence(Env, n, dev, args.precision, pool, args.fence_steps))
-        if world == 1 and args.large_batch > n and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
+        if not multi and args.large_batch > n and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
             del pool, bufs
             torch.cuda.empty_cache()
             leg("large_batch", lambda: large_batch(Env, dev, args))
         # the other single-GPU BASELINE configs, timed by the same command (each on a fresh handle, after the headline)
-        if world == 1 and args.secondary_legs and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
+        if not multi and args.secondary_legs and args.task == "reach" and args.policy == "external" and args.mode == "rollout":
             # (four timed launches behind three untimed ones: the clocks settle for ~10 ms after the switch to the MFMA-heavy kernel)
             leg("config3_actor_f32", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor", args.precision, 4, 3))
             leg("config3_actor_f16x3", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor_f16x3", args.precision, 4, 3))
             leg("config4_push", lambda: secondary_leg(envs, dev, "push", 32768, "external", args.precision, 5, 6, args.fence_steps))
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline(args.precision))
         print(json.dumps(line), flush=True)
     env.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -25,9 +25,11 @@ def shard_range(total_envs, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def init_process_group(backend=None, device=None):
+def init_process_group(backend=None, device=None, force=False):
+    """force: initialise the group for a one-rank job as well (RCCL accepts a communicator of one rank: a 1-GPU box then runs
+    the same collective calls an 8-GPU node does; needs MASTER_ADDR / MASTER_PORT as torch.distributed.run exports them)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
         kw = {}
@@ -47,8 +49,13 @@ class ReturnGatherer:
     same n_local on every rank: `shard_range` gives uneven shards when world does not divide the env count, so the
     constructor checks."""
 
-    def __init__(self, n_local, device, world=None):
+    def __init__(self, n_local, device, world=None, collective=None):
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        # collective: go through torch.distributed even when there is only one rank (a one-rank RCCL communicator: what a
+        # 1-GPU box can execute of the multi-GPU path); default: only when there is someone to exchange with
+        self.collective = (self.world > 1) if collective is None else bool(collective)
+        if self.collective and not dist.is_initialized():
+            raise RuntimeError("ReturnGatherer(collective=True) needs an initialised process group")
         self.device = torch.device(device)
         self.n_local = int(n_local)
         self.slots = [dict(stage=torch.zeros(self.n_local, dtype=torch.float32, device=self.device),
@@ -57,7 +64,7 @@ class ReturnGatherer:
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.launches = 0
         self._last = None
-        if self.world > 1 and dist.is_initialized():
+        if self.collective and dist.is_initialized():
             host = dist.get_backend() != "nccl"
             t = torch.tensor([self.n_local, -self.n_local], dtype=torch.int64, device="cpu" if host else self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -65,7 +72,7 @@ class ReturnGatherer:
                 raise ValueError("ReturnGatherer: every rank must own the same number of envs (pad the last shard)")
 
     def _host_backend(self):
-        return self.side is not None and self.world > 1 and dist.get_backend() != "nccl"
+        return self.side is not None and self.collective and dist.get_backend() != "nccl"
 
     def launch(self, local_returns):
         """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs: the side stream waits for
@@ -94,13 +101,13 @@ class ReturnGatherer:
                 slot["stage"].copy_(local_returns)
                 # the producer's tensor is read on the side stream: keep the caching allocator from recycling it early
                 local_returns.record_stream(self.side)
-                if self.world > 1:
+                if self.collective:
                     slot["work"] = dist.all_gather_into_tensor(slot["out"], slot["stage"], async_op=True)
                 else:
                     slot["out"].copy_(slot["stage"])
         else:
             slot["stage"].copy_(local_returns)
-            if self.world > 1:
+            if self.collective:
                 parts = [torch.empty_like(slot["stage"]) for _ in range(self.world)]
                 dist.all_gather(parts, slot["stage"])
                 slot["out"].copy_(torch.cat(parts))

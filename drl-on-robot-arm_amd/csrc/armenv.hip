@@ -84,6 +84,55 @@ static void fill_chain(ArmEnvChain *out, const double (*xyz)[3], const double (*
   }
 }
 
+// Issue rate of the vector pipe as the env kernels use it (armenv_probe_issue_rate): waves of 64 lanes, `per_simd` of them on
+// every SIMD of the device, back-to-back independent v_fma on sixteen chains with vector operands, nothing else in the loop.
+template <typename T>
+__global__ __launch_bounds__(256) void issue_probe_kernel(T *out, int iters, T a, T b) {
+  T x[16];
+  static_for<0, 16>([&](auto I) { constexpr int t = I; x[t] = a * (T)(t + (int)threadIdx.x); });
+  T av = a, bv = b;
+  asm volatile("" : "+v"(av), "+v"(bv));
+  // 128 instructions per trip: a taken backward branch costs a lone wave tens of cycles (a 16-instruction body measured 12 cycles
+  // per instruction instead of 6.6)
+  for (int i = 0; i < iters; ++i)
+    static_for<0, 128>([&](auto I) { constexpr int t = I % 16; x[t] = Mth<T>::fma(x[t], av, bv); asm volatile("" : "+v"(x[t])); });   // (no SLP packing into v_pk_fma_f32)
+  T s = T(0);
+  static_for<0, 16>([&](auto I) { constexpr int t = I; s += x[t]; });
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <typename T>
+static int issue_probe(int device, int waves_per_simd, double *ns_out) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  const int blocks = prop.multiProcessorCount * waves_per_simd;   // 256 threads = one wave on each of a CU's four SIMDs
+  T *out = nullptr;
+  HIP_TRY(hipMalloc(&out, sizeof(T) * 256 * (size_t)blocks));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const int iters = 512;
+  double best = 1e30;
+  // an idle MI355X needs ~30 ms of load to reach its steady clocks (tests/tools/clock_ramp.py): ~55 ms of the same kernel first
+  for (int k = 0; k < 300 / waves_per_simd; ++k) hipLaunchKernelGGL(issue_probe_kernel<T>, dim3(blocks), dim3(256), 0, 0, out, iters, T(0.999), T(1e-3));
+  for (int rep = 0; rep < 5; ++rep) {
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(issue_probe_kernel<T>, dim3(blocks), dim3(256), 0, 0, out, iters, T(0.999), T(1e-3));
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double ns = (double)ms * 1e6 / 5 / ((double)iters * 128) / waves_per_simd;
+    if (ns < best) best = ns;
+  }
+  HIP_TRY(hipGetLastError());
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  *ns_out = best;
+  return ARMENV_OK;
+}
+
 extern "C" {
 
 
@@ -374,6 +423,13 @@ int armenv_write_episodes(int32_t device, int64_t T, int64_t N, int64_t ring_bas
                      ring_base, ring_cap, done_dev, starts_at_reset, const_cast<int32_t *>(counts_dev), offsets_dev, episodes_dev);
   HIP_TRY(hipGetLastError());
   return ARMENV_OK;
+}
+
+int armenv_probe_issue_rate(int32_t device, int32_t precision, int32_t waves_per_simd, double *ns_per_instruction) {
+  DEV_ENTER(device);
+  if (!ns_per_instruction || waves_per_simd < 1 || waves_per_simd > 8 || (precision != 32 && precision != 64))
+    return fail(ARMENV_EINVAL, "armenv_probe_issue_rate: precision 32 | 64, 1..8 waves per SIMD");
+  return precision == 64 ? issue_probe<double>(device, waves_per_simd, ns_per_instruction) : issue_probe<float>(device, waves_per_simd, ns_per_instruction);
 }
 
 int armenv_her_sample(int32_t device, const ArmEnvHerArgs *a, void *stream) {

@@ -362,11 +362,13 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
   // rounding of the incremental rotations (~1e-16 each) for callers that run unbounded episodes.
   T cq[NJ], sq[NJ];
   // The link frames of the current pose.  A step's IK leaves FK(q) of the pose it ends with (the frame _reward reads);
-  // that is also the frame the NEXT step starts from, so inside a rollout launch it is carried over instead of being
-  // recomputed from the same (cos q, sin q): 120 of a step's ~3 300 instructions, the same bits.  Invalid after load and
-  // after an in-place reset.
+  // that is also the frame the NEXT step starts from, so a kernel that keeps the lane in registers across steps (CARRY: the
+  // rollout kernels without a fused actor) carries it over instead of recomputing it from the same (cos q, sin q): 120 of a
+  // step's ~3 300 instructions, the same bits.  Since round 4 the frame is made EAGERLY wherever the pose is set anew -- at the
+  // launch's start (make_frame), inside the in-place reset and the trig re-derivation (both rare, out of line) -- so that
+  // step_begin tests nothing: the lazy "if (!have_S) fk" of rounds 1-3 was a taken branch on every step.
   FKState<T> S;
-  bool have_S = false;
+  AE_DEV void make_frame(const EnvParams<T> &P) { fk<C, T>(P.chain, cq, sq, S); }
   float g[3];
   int32_t step;
   T ep_ret;
@@ -399,18 +401,19 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
   //
   // step_begin: everything ahead of the IK trips -- the frame of the start pose (carried over or recomputed) and the
   // clipped Cartesian target (:237-242).
+  // CARRY: S already is the frame of (cq, sq) (see S above); otherwise it is computed here.
+  template <bool CARRY>
   AE_DEV void step_begin(const EnvParams<T> &P, const T (&a)[3], T (&tgt)[3]) {
-    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) { derive_trig(); have_S = false; } }
-    if (!have_S) fk<C, T>(P.chain, cq, sq, S);
+    if constexpr (!CARRY) make_frame(P);
     ik_target<T, false>(S, a, P.dv, P.box_lo, P.box_hi, tgt);
     minpiv = T(1e30);
   }
   // step_tail: everything after the IK (q, cq / sq and S = FK(q) hold its result; `updates` trips applied an update; lim_hit:
   // ik_limits): step counter, distance, reward / done / success (:264-309), observation (:319), episode accounting,
   // in-place reset.  Writes row i of the caller's buffers.
+  template <bool CARRY>
   AE_DEV void step_tail(const EnvParams<T> &P, int64_t i, const StepIO &io, int updates, bool lim_hit) {
     const int64_t n = P.n;
-    have_S = true;
     n_upd += (uint32_t)updates;
     if constexpr (kFence) {
       n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; n_cap += (updates >= P.ik.max_iters) ? 1u : 0u;
@@ -423,11 +426,12 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
     step += 1;                                                                    // :264
     const T dx = S.p[0] - (T)g[0], dy = S.p[1] - (T)g[1], dz = S.p[2] - (T)g[2];
     const T dist = M::sqrt(M::fma(dx, dx, M::fma(dy, dy, dz * dz)));              // :281
-    T reward;
-    bool done, succ;
-    if (step > P.max_steps) { reward = -dist * T(10); done = true; succ = false; }          // :299-301
-    else if (dist < P.reach_dis) { reward = T(0); done = true; succ = true; }               // :303-306
-    else { reward = -dist * T(10); done = false; succ = false; }                            // :307-309
+    // :299-309 as selects (the if / else-if chain is three exec-mask regions and a branch per step; the same values):
+    //   step > max_steps -> (-10 d, done);  else d < reach_dis -> (0, done, success);  else (-10 d, not done)
+    const bool over = step > P.max_steps;
+    const bool succ = !over & (dist < P.reach_dis);
+    const bool done = over | succ;
+    const T reward = succ ? T(0) : -dist * T(10);
     ep_ret += reward;
     if constexpr (kTipOf(kMode)) {
       if (io.diag) { io.diag[4 * i] = (double)S.p[0]; io.diag[4 * i + 1] = (double)S.p[1]; io.diag[4 * i + 2] = (double)S.p[2]; io.diag[4 * i + 3] = (double)reward; }
@@ -444,31 +448,39 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
     io.reward[i] = (float)reward;
     io.done[i] = done ? 1 : 0;
     io.success[i] = succ ? 1 : 0;
-    if (io.terminal_obs) store_obs6<T>(io.terminal_obs, i, S.p, g);
+    if (__builtin_expect(io.terminal_obs != nullptr, 0)) store_obs6<T>(io.terminal_obs, i, S.p, g);
 
-    if (__builtin_expect(done, 0)) {
-      P.last_return[i] = ep_ret;
-      P.last_len[i] = step;
-      P.last_success[i] = succ ? 1 : 0;
-      n_done += 1;
-      if (succ) n_succ += 1;
-    }
-    if (__builtin_expect(done && P.auto_reset, 0)) {
-      const uint32_t ep = P.episode[i];
-      sample_goal(P, i, ep, g);
-      P.episode[i] = ep + 1u;
-      static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
-      const EnvCold<T> &K = *P.cold;
-      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
-      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = K.trig_init[j]; sq[j] = K.trig_init[NJ + j]; });
-      have_S = false;
-      step = 0;
-      ep_ret = T(0);
-      store_obs6<T>(io.obs, i, K.p_init, g);
-      cur_obs[0] = (float)K.p_init[0]; cur_obs[1] = (float)K.p_init[1]; cur_obs[2] = (float)K.p_init[2];
-    } else {
-      store_obs6<T>(io.obs, i, S.p, g);                                           // :319
-      cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    // The pair (cos q, sin q) is re-derived from q when the env's own step counter reaches a multiple of kTrigRederive (see cq
+    // above; rounds 1-3 did this at the top of the NEXT step: the same values, since nothing touches the pose in between).
+    // One rare region for "done" and "re-derive": the common path is a fall-through to the observation store.
+    const bool rederive = kTrigRederive > 0 && (step & (kTrigRederive - 1)) == 0;     // step >= 1 here
+    store_obs6<T>(io.obs, i, S.p, g);                                                // :319 (a reset overwrites it below)
+    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    if (__builtin_expect(done | rederive, 0)) {
+      if (done) {
+        P.last_return[i] = ep_ret;
+        P.last_len[i] = step;
+        P.last_success[i] = succ ? 1 : 0;
+        n_done += 1;
+        if (succ) n_succ += 1;
+      }
+      if (done && P.auto_reset) {
+        const uint32_t ep = P.episode[i];
+        sample_goal(P, i, ep, g);
+        P.episode[i] = ep + 1u;
+        static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.goal[(int64_t)k * n + i] = g[k]; });
+        const EnvCold<T> &K = *P.cold;
+        static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
+        static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = K.trig_init[j]; sq[j] = K.trig_init[NJ + j]; });
+        step = 0;
+        ep_ret = T(0);
+        store_obs6<T>(io.obs, i, K.p_init, g);      // the same lane's second store to these addresses: program order holds
+        cur_obs[0] = (float)K.p_init[0]; cur_obs[1] = (float)K.p_init[1]; cur_obs[2] = (float)K.p_init[2];
+        if constexpr (CARRY) make_frame(P);
+      } else if (rederive) {
+        derive_trig();
+        if constexpr (CARRY) make_frame(P);
+      }
     }
   }
   // The lockstep step.  Returns the number of IK updates.
@@ -476,18 +488,15 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
   // consumed here, right after the IK and BEFORE this step's stores are issued: the s_waitcnt the consumption needs
   // then covers only that old load; placed at the next step's top it would also wait for this step's stores
   // (vmcnt is in-order) -- measured 15 % of the wave's cycles.
+  template <bool CARRY = false>
   AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
                     float (*next_action)[3] = nullptr) {
     T tgt[3];
-    step_begin(P, a, tgt);
-    const T res2 = P.ik.residual * P.ik.residual;
-    const bool small_steps = P.ik.max_dtheta <= T(0.7854);
-    T diff2_prev = T(1e60);
-    int updates = 0;
-    while (!ik_trip<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :244-257
+    step_begin<CARRY>(P, a, tgt);
+    const int updates = ik_lockstep<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, minpiv);                               // :244-257
     const bool lim_hit = ik_limits<C, T, kMode>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
-    step_tail(P, i, io, updates, lim_hit);
+    step_tail<CARRY>(P, i, io, updates, lim_hit);
     return updates;
   }
 
@@ -560,7 +569,7 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
   T cq[NJ], sq[NJ];         // (cos q, sin q), carried with q in the env's state: see ReachLane::cq
   T cube[3], target[3], d_last;
   FKState<T> S;             // link frames of the current pose, carried from step to step (push only): see ReachLane::S
-  bool have_S = false;
+  AE_DEV void make_frame(const EnvParams<T> &P) { fk<C, T>(P.chain, cq, sq, S); }
   T grip = T(0);            // pick: 0 open, 1 closed, 2 closed and holding the cube
   T off[3] = {T(0), T(0), T(0)};   // pick: cube - tip while held
   int32_t step;
@@ -718,17 +727,19 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
   // float32-rounded start position :328), the IK trips, step_tail.
   T p0[3];                  // eef position at the start of the running step (the contact model's sweep origin)
   T q7s, c7s, s7s;          // pick: joint 7 and its (cos, sin) before the IK (rl_pick_env.py:343 applies joints 0..5 only)
+  // CARRY: the caller keeps the lane in registers across steps (ReachLane::S).  Pick restores joint 7 in step_tail, so its exit
+  // frame's orientation is not the next step's: only push carries the frame over.
+  template <bool CARRY>
   AE_DEV void step_begin(const EnvParams<T> &P, const T (&a)[3], T (&tgt)[3]) {
-    if constexpr (kTrigRederive > 0) { if (__builtin_expect(step != 0 && (step & (kTrigRederive - 1)) == 0, 0)) { derive_trig(); have_S = false; } }
     if constexpr (PICK) { q7s = q[NJ - 1]; c7s = cq[NJ - 1]; s7s = sq[NJ - 1]; }
-    if (!have_S) fk<C, T>(P.chain, cq, sq, S);
+    if constexpr (!(CARRY && !PICK)) make_frame(P);
     p0[0] = S.p[0]; p0[1] = S.p[1]; p0[2] = S.p[2];
     ik_target<T, PICK>(S, a, P.dv, P.box_lo, P.box_hi, tgt);
     minpiv = T(1e30);
   }
+  template <bool CARRY>
   AE_DEV void step_tail(const EnvParams<T> &P, int64_t i, const StepIO &io, int updates, bool lim_hit) {
-    // pick restores joint 7 below, so the exit frame's orientation is not the next step's: only push carries the frame over
-    have_S = !PICK;
+    constexpr bool kCarry = CARRY && !PICK;
     n_upd += (uint32_t)updates;
     if constexpr (kFence) {
       n_lim += lim_hit ? 1u : 0u; n_low += (S.p[2] < P.fence_z) ? 1u : 0u; n_cap += (updates >= P.ik.max_iters) ? 1u : 0u;
@@ -775,45 +786,48 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     io.reward[i] = (float)reward;
     io.done[i] = done ? 1 : 0;
     io.success[i] = succ ? 1 : 0;
-    if (io.terminal_obs) store_obs9<T>(io.terminal_obs, i, S.p, cube, target);
-    if (__builtin_expect(done, 0)) {
-      P.last_return[i] = ep_ret;
-      P.last_len[i] = step;
-      P.last_success[i] = succ ? 1 : 0;
-      n_done += 1;
-      if (succ) n_succ += 1;
-    }
-    if (__builtin_expect(done && P.auto_reset, 0)) {
-      const uint32_t ep = P.episode[i];
-      cube_sample<PICK, T>(P, i, ep, cube, target);
-      P.episode[i] = ep + 1u;
-      d_last = dist_ct();                                                         // :243-245
-      if constexpr (PICK) { grip = T(0); off[0] = off[1] = off[2] = T(0); }
-      const EnvCold<T> &K = *P.cold;
-      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
-      static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = K.trig_init[j]; sq[j] = K.trig_init[NJ + j]; });
-      have_S = false;
-      step = 0;
-      ep_ret = T(0);
-      store_obs9<T>(io.obs, i, K.p_init, cube, target);
-      cur_obs[0] = (float)K.p_init[0]; cur_obs[1] = (float)K.p_init[1]; cur_obs[2] = (float)K.p_init[2];
-    } else {
-      store_obs9<T>(io.obs, i, S.p, cube, target);                               // :308
-      cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    if (__builtin_expect(io.terminal_obs != nullptr, 0)) store_obs9<T>(io.terminal_obs, i, S.p, cube, target);
+    // one rare region for "done" and the trig re-derivation (see ReachLane::step_tail)
+    const bool rederive = kTrigRederive > 0 && (step & (kTrigRederive - 1)) == 0;     // step >= 1 here
+    store_obs9<T>(io.obs, i, S.p, cube, target);                                     // :308 (a reset overwrites it below)
+    cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    if (__builtin_expect(done | rederive, 0)) {
+      if (done) {
+        P.last_return[i] = ep_ret;
+        P.last_len[i] = step;
+        P.last_success[i] = succ ? 1 : 0;
+        n_done += 1;
+        if (succ) n_succ += 1;
+      }
+      if (done && P.auto_reset) {
+        const uint32_t ep = P.episode[i];
+        cube_sample<PICK, T>(P, i, ep, cube, target);
+        P.episode[i] = ep + 1u;
+        d_last = dist_ct();                                                         // :243-245
+        if constexpr (PICK) { grip = T(0); off[0] = off[1] = off[2] = T(0); }
+        const EnvCold<T> &K = *P.cold;
+        static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
+        static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = K.trig_init[j]; sq[j] = K.trig_init[NJ + j]; });
+        step = 0;
+        ep_ret = T(0);
+        store_obs9<T>(io.obs, i, K.p_init, cube, target);      // the same lane's second store to these addresses
+        cur_obs[0] = (float)K.p_init[0]; cur_obs[1] = (float)K.p_init[1]; cur_obs[2] = (float)K.p_init[2];
+        if constexpr (kCarry) make_frame(P);
+      } else if (rederive) {
+        derive_trig();
+        if constexpr (kCarry) make_frame(P);
+      }
     }
   }
+  template <bool CARRY = false>
   AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
                     float (*next_action)[3] = nullptr) {
     T tgt[3];
-    step_begin(P, a, tgt);
-    const T res2 = P.ik.residual * P.ik.residual;
-    const bool small_steps = P.ik.max_dtheta <= T(0.7854);
-    T diff2_prev = T(1e60);
-    int updates = 0;
-    while (!ik_trip<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, diff2_prev, updates, res2, small_steps, minpiv)) {}    // :339-347
+    step_begin<CARRY>(P, a, tgt);
+    const int updates = ik_lockstep<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, minpiv);                               // :339-347
     const bool lim_hit = ik_limits<C, T, kMode>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
-    step_tail(P, i, io, updates, lim_hit);
+    step_tail<CARRY>(P, i, io, updates, lim_hit);
     return updates;
   }
 };
@@ -850,7 +864,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   TL_STAMP(tl1);
-  const int updates = L.env_step(P, i, a, io);
+  const int updates = L.template env_step<false>(P, i, a, io);
   (void)updates;
   TL_STAMP(tl2);
   L.store(P, i);
@@ -930,6 +944,10 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
   }
   ActionPrefetch an_next{0.f, 0.f, 0.f};
   [[maybe_unused]] uint32_t w_trips = 0;
+  // the link frames travel from step to step in registers -- except across a fused actor, which needs the whole register file
+  // between two env steps (the lanes then recompute the frame at the top of every step)
+  constexpr bool kCarry = !kActor;
+  if constexpr (kCarry) L.make_frame(P);
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
     if constexpr (kPrefetch) {
@@ -970,19 +988,17 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     io.terminal_obs = io0.terminal_obs ? io0.terminal_obs + (int64_t)t * n * kObs : nullptr;
     if constexpr (Lane::kFence) io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; else io.updates = nullptr;
     if constexpr (kTipOf(Lane::kMode)) io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; else io.diag = nullptr;
-    if (actions_out) {
+    if (__builtin_expect(actions_out != nullptr, 0)) {
       float *ao = actions_out + ((int64_t)t * n + i) * 3;
       if constexpr (POLICY == ARMENV_POLICY_EXTERNAL) { ao[0] = (float)a[0]; ao[1] = (float)a[1]; ao[2] = (float)a[2]; }
       else { ao[0] = an[0]; ao[1] = an[1]; ao[2] = an[2]; }
     }
     const uint32_t before = L.n_done;
-    // the fused actor needs the whole register file between two env steps: the link frames are not carried across it
-    if constexpr (kActor) L.have_S = false;
     int upd;
     if constexpr (kPrefetch) {
-      upd = L.env_step(P, i, a, io, &an_next, &an);
+      upd = L.template env_step<kCarry>(P, i, a, io, &an_next, &an);
     } else {
-      upd = L.env_step(P, i, a, io);
+      upd = L.template env_step<kCarry>(P, i, a, io);
     }
     if constexpr (Lane::kFence) w_trips += wave_max8((uint32_t)upd + 1u);   // a lane's trips: its updates + the exit trip
     else (void)upd;
@@ -1054,12 +1070,13 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
       float *ao = actions_out + ((int64_t)t * n + i) * 3;
       ao[0] = af[0]; ao[1] = af[1]; ao[2] = af[2];
     }
-    L.step_begin(P, a, tgt);
+    L.template step_begin<true>(P, a, tgt);
     diff2_prev = T(1e60);
     updates = 0;
     ready = false;
   };
   load_action(0);
+  L.make_frame(P);          // carried from step to step in registers from here on (ReachLane::S; pick recomputes it per step)
   begin_step();
   [[maybe_unused]] uint32_t w_trips = 0, w_rounds = 0;
   for (;;) {
@@ -1087,7 +1104,7 @@ void env_rollout_async_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, c
         if constexpr (Lane::kFence) io.updates = io0.updates ? io0.updates + (int64_t)t * n : nullptr; else io.updates = nullptr;
     if constexpr (kTipOf(Lane::kMode)) io.diag = io0.diag ? io0.diag + (int64_t)t * n * 4 : nullptr; else io.diag = nullptr;
         const uint32_t before = L.n_done;
-        L.step_tail(P, i, io, updates, lim_hit);
+        L.template step_tail<true>(P, i, io, updates, lim_hit);
         if constexpr (POLICY != ARMENV_POLICY_EXTERNAL) {
           if (L.n_done != before && P.auto_reset) episode += 1u;
         }

@@ -630,11 +630,14 @@ AE_DEV void ik_target(const FKState<T> &S, const T (&a)[3], T dv, const T (&box_
 // minpiv (fence bookkeeping only): running minimum of the LDL^T pivots of the call's damped systems -- the damped solve
 // amplifies rounding differences by ~1 / pivot, so a call that passes through a near-singular pose (stretched elbow at the
 // edge of the arm's reach, aligned wrist) is where two implementations' trajectories start to part.
+// The trip in two pieces, for callers that steer the wave themselves (env_step's lockstep loop, armenv_env.h):
+//   ik_stop    position error e[0..2] at the IK point pe of the frame S, its square diff2, and Bullet's loop test -- true when the
+//              loop stops for this lane (nothing changes);
+//   ik_update  one DLS update of q and (cq, sq) from that error, S = FK(q) of the updated pose, the update counted in `it`.
 template <class C, typename T, int MODE = 0>
-AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
-                    T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps, T &minpiv) {
+AE_DEV bool ik_stop(const IKParams<T> &P, const T (&tgt)[3], const FKState<T> &S, T diff2_prev, int it, T res2, T (&e)[6], T (&pe)[3],
+                    T &diff2) {
   using M = Mth<T>;
-  T e[6], pe[3];
   static_for<0, 3>([&](auto RI) {
     constexpr int r = RI;
     if constexpr (kTipOf(MODE)) pe[r] = M::fma(S.W[0 + r], P.tip[0], M::fma(S.W[3 + r], P.tip[1], M::fma(S.W[6 + r], P.tip[2], S.p[r])));
@@ -643,9 +646,18 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
   e[0] = tgt[0] - pe[0];
   e[1] = tgt[1] - pe[1];
   e[2] = tgt[2] - pe[2];
-  const T diff2 = M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2]));
-  const bool stop = (it >= P.max_iters) || (P.exit_mode == 0 ? !(diff2_prev > res2) : !(diff2 > res2));
-  if (stop) return true;
+  diff2 = M::fma(e[0], e[0], M::fma(e[1], e[1], e[2] * e[2]));
+  // exit_mode is wave-uniform: written as a ternary on P.exit_mode hipcc builds a uniform BRANCH around the two compares, and
+  // lays the default mode's side out of line -- two taken branches per trip, ~25 ns each for a wave that has its SIMD to itself
+  // (tests/tools/exp/fwd_branch_probe.hip).  With the mode in a vector register the choice is two v_cndmask.
+  int em = P.exit_mode;
+  asm("" : "+v"(em));
+  const T dtest = em == 0 ? diff2_prev : diff2;
+  return (it >= P.max_iters) | !(dtest > res2);
+}
+template <class C, typename T, int MODE = 0>
+AE_DEV void ik_update(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], FKState<T> &S, T (&cq)[NJ], T (&sq)[NJ], T (&e)[6],
+                      const T (&pe)[3], T diff2, T &diff2_prev, int &it, bool small_steps, T &minpiv) {
   T qc[4], eo[3], dth[NJ];
   quat_from_frame<T>(S.W, qc);
   orientation_error<T>(P.tq, qc, P.angle_f32, eo);
@@ -655,7 +667,7 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
 #ifdef ARMENV_EXACT_ROTATE
   small_steps = false;
 #endif
-  if (small_steps) {
+  if (__builtin_expect(small_steps, 1)) {     // (the other side out of line: the loop body then ends in ONE back edge)
     static_for<0, NJ>([&](auto II) { constexpr int i = II; rotate_small<T>(cq[i], sq[i], dth[i]); });
   } else {
     sincos_all<T>(q, cq, sq);
@@ -663,8 +675,30 @@ AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], con
   diff2_prev = diff2;
   ++it;
   fk<C, T>(ch, cq, sq, S);
+}
+template <class C, typename T, int MODE = 0>
+AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
+                    T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps, T &minpiv) {
+  T e[6], pe[3], diff2;
+  if (ik_stop<C, T, MODE>(P, tgt, S, diff2_prev, it, res2, e, pe, diff2)) return true;
+  ik_update<C, T, MODE>(ch, P, q, S, cq, sq, e, pe, diff2, diff2_prev, it, small_steps, minpiv);
   return false;
 }
+// Bullet's loop for the lanes of a wave walking through it together (the lockstep kernels).  Returns the lane's number of updates.
+// (A form with the wave-level exit spelled out -- `if (__ballot(!stop) == 0) break; if (!stop) ik_update(...)` -- was tried in
+// round 4 to save the loop's entry jump and one of its two exit branches: hipcc's structuriser folds it back into the same
+// exec-mask loop, with a few more scalar instructions.)
+template <class C, typename T, int MODE = 0>
+AE_DEV int ik_lockstep(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
+                       T (&sq)[NJ], T &minpiv) {
+  const T res2 = P.residual * P.residual;     // |p - tgt| > residual on squares: no sqrt on the loop-carried critical path
+  const bool small_steps = P.max_dtheta <= T(0.7854);
+  T diff2_prev = T(1e60);
+  int it = 0;
+  while (!ik_trip<C, T, MODE>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps, minpiv)) {}
+  return it;
+}
+
 // ik_limits: URDF joint limits (/root/reference/envs/bmirobot_joints_info_pybullet.txt:1-7, fields 8-9).  The reference never
 // passes them to the IK (rl_reach_env.py:103-107 are dead data, :244-250), so q may leave them; Bullet then pushes the joint
 // back inside stepSimulation (:258) through a limit constraint this build does not model.  Returns whether the IK result
@@ -679,7 +713,7 @@ AE_DEV bool ik_limits(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], F
   using M = Mth<T>;
   constexpr bool FENCE = kFenceOf(MODE);
   bool hit = false;
-  if (P.clamp_limits || FENCE) {
+  if (FENCE || __builtin_expect(P.clamp_limits != 0, 0)) {
     T m = M::fabs(q[0]);
     static_for<1, NJ>([&](auto II) { constexpr int i = II; m = M::fmax(m, M::fabs(q[i])); });
     if (__builtin_expect(m > P.lim_min, 0)) {

@@ -356,6 +356,13 @@ typedef struct ArmEnvHerArgs {
  * reward -0.1 / 1.0 and done by the distance threshold. */
 int armenv_her_sample(int32_t device, const ArmEnvHerArgs *args, void *stream);
 
+/* Measurement aid (bench.py's roofline.valu.one_wave_per_simd; no reference counterpart): the interval at which SIMDs issue
+ * independent 64-lane v_fma_f64 (precision 64) / v_fma_f32 (32) instructions when every SIMD of `device` holds
+ * `waves_per_simd` waves that do nothing else -- the env kernels run ONE wave per SIMD, whose f64 issue interval is above the
+ * pipe's nominal four cycles.  Out: nanoseconds per wave instruction per SIMD (host double).  Blocking
+ * (about 60 ms: the device is brought to its steady clocks first; default stream). */
+int armenv_probe_issue_rate(int32_t device, int32_t precision, int32_t waves_per_simd, double *ns_per_instruction);
+
 /* Shape / capability queries. */
 int64_t armenv_num_envs(const ArmEnv *env);
 int32_t armenv_obs_dim(const ArmEnv *env);

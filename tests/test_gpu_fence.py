@@ -402,6 +402,43 @@ def test_bench_two_gpus_over_rccl():
     assert len(d["config"]["per_rank"]["kernel_ms"]) == 2
 
 
+def test_bench_one_rank_over_rccl(envs):
+    """What a 1-GPU box can execute of BASELINE configs[4]'s RCCL path: `bench.py` as ONE rank under torch.distributed.run with
+    ARMENV_BENCH_COLLECTIVE=1 -- init_process_group("nccl", device_id), the barriers of the bracket, the logging
+    all_gather_into_tensor on the side stream inside the timed region, the max-over-ranks all_gather / all_reduce on device
+    tensors, all_gather_object, destroy_process_group: every collective call of the multi-GPU run goes through RCCL (a
+    communicator of one rank).  The gathered vector is the handle's own episode returns and the trajectory is the single-handle
+    one (same digest as a plain rollout of the same pool)."""
+    import hashlib
+    n, K, W = 8192, 700, 5
+    d = _run_bench_env(["--gpus", "1", "--steps", str(K), "--warmup", str(W), "--envs-per-gpu", str(n), "--state-digest",
+                        "--prewarm-ms", "0", "--gather-every", "100", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks_seen"] == {"world_size": 1, "backend": "nccl"}
+    assert "RCCL" in d["config"]["parallelism"] and d["config"]["gathers_in_timed_region"] >= 7
+    assert d["value_steps"] >= d["value"] > 0 and len(d["config"]["per_rank"]["kernel_ms"]) == 1
+    for k in ("barrier", "gather_wait"):
+        assert k in d["config"]["host_us"], k
+    gen = torch.Generator(device=DEV); gen.manual_seed(1000)
+    pool = (torch.randn((1000, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7)
+    e = envs.BatchedReachEnv(n, device=DEV, seed=0)
+    e.reset()
+    t = 0
+    for r in [W] + [100] * (K // 100):
+        e.rollout(r, pool[t:t + r].contiguous())
+        t += r
+    q = e.get_state()["q"].cpu().numpy()
+    assert d["config"]["state_digest"] == [hashlib.sha256(q.tobytes()).hexdigest()]
+    ret = e.episode_stats()[0].detach().float().cpu().numpy()
+    assert d["config"]["gathered_returns_sha256"] == hashlib.sha256(ret.tobytes()).hexdigest()
+    assert d["config"]["gathered_returns_mean"] == pytest.approx(float(ret.astype(np.float64).mean()), rel=1e-12) and ret.min() < -1.0
+    e.close()
+
+
+def _run_bench_env(argv):
+    from test_gpu_parity import _run_bench
+    return _run_bench(argv, torchrun=True, env={"ARMENV_BENCH_COLLECTIVE": "1"})
+
+
 @pytest.mark.parametrize("task", ["reach", "push", "pick"])
 def test_half_filled_waves_equal_full_waves(envs, task):
     """ArmEnvConfig.rollout_lanes_per_wave: 32 envs per wavefront (lanes 32..63 idle; the default for push / pick rollouts of at
