@@ -331,9 +331,19 @@ AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // t
 }
 AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int IN>
-AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, uint4 *ring, int nw,
-                                   const float (&s)[IN], float (&out)[3]) {
+// FULL: all four waves of the workgroup are live (nw == 4: every workgroup but the last one of a batch that is not a multiple of
+// 256 envs).  That copy has its sixteen k-steps UNROLLED: the k-step index is then a compile-time constant -- which LDS region a
+// k-step reads, whether it refills a ring slot and which one fold away, and with them the wave-uniform BRANCHES the rolled loop
+// needs around every refill slot (`streamed`, `nw == 4`: six per k-step) and the row-tile loop's eight back edges per env tile.
+// A branch costs a wave that has its SIMD to itself ~8 ns when it falls through and 20-50 ns when it is taken
+// (tests/tools/exp/fwd_branch_probe.hip, branch_cost_probe.hip); the k-loops have 32 k-steps per env step.
+// Measured in one session: 29.3 -> 28.0 us per fused env step.  The ragged copy (FULL = false) keeps the rolled loop and its
+// run-time tests.
+// (Also tried on this form, not kept: ONE vmcnt(0) + s_barrier per PAIR of k-steps with the refills three positions ahead --
+// correct, 16 rendezvous per env step instead of 32, and no faster (28.1-28.6 against 27.9 us): the four waves are not skewed.)
+template <int IN, bool FULL>
+AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, uint4 *ring, int nw,
+                                        const float (&s)[IN], float (&out)[3]) {
   static_assert(IN + 1 <= 16, "augmented input does not fit one f16 MFMA k-step");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5;
@@ -412,7 +422,13 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     };
     auto split2b = [&](auto UI, auto CI, const half8 (&h)[2], half8 (&l)[2]) {
       constexpr int u = UI, c = CI;
-      l[u][2 * c] = (_Float16)(sx0 - (float)h[u][2 * c]); l[u][2 * c + 1] = (_Float16)(sx1 - (float)h[u][2 * c + 1]);
+      // two scalar subtractions, kept apart: hipcc's SLP pass pairs them into one v_pk_add_f32, and a packed f32 instruction in
+      // an MFMA's shadow costs ~13 cycles more than the two scalar ones it replaces (MI355X_MICROARCH.md: an anti-lever beside
+      // MFMAs); in-session 28.4 -> 27.9 us per fused env step
+      float d0 = sx0 - (float)h[u][2 * c];
+      asm("" : "+v"(d0));
+      const float d1 = sx1 - (float)h[u][2 * c + 1];
+      l[u][2 * c] = (_Float16)d0; l[u][2 * c + 1] = (_Float16)d1;
     };
     f32x16 acc[NT];   // start from the layer-2 bias: register r <-> neuron 32 nt + 8 (r / 4) + 4 half + (r % 4)
     static_for<0, NT>([&](auto NI) {
@@ -436,7 +452,7 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     //   slots 8..23   one LDS read each of k-step ks + 1's fragments into (nh, nl) and, on odd k-steps, half of the
     //                 relu + hi / lo split of a pair of layer-1 values of the next row tile.
     auto kstep = [&](auto ODD, int ks, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT],
-                     const f32x16 &a1n) {
+                     const f32x16 &a1n) __attribute__((always_inline)) {
       constexpr int u = ODD;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of the fill issued one k-step ago (k-step ks + 1)
       __builtin_amdgcn_s_barrier();
@@ -456,7 +472,7 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
         if constexpr (m < 8 && m % 2 == 1) {
           constexpr int fi = m / 2;
           if (streamed) {
-            if (nw == 4)
+            if (FULL || nw == 4)
               glds16(reinterpret_cast<const void *>(fill_src[fi] + (uint64_t)(unsigned)kf * (8u * 64u * 16u)), voff16,
                      fill_dst[fi] + (unsigned)actor_region(kf) * (16u * 64u * 16u));
             else if (m == 1) {
@@ -489,12 +505,17 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
       static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah0[nt] = slot[(2 * nt) * 64]; al0[nt] = slot[(2 * nt + 1) * 64]; });
     }
     f32x16 a1n = {};
-#pragma unroll 1
-    for (int R = 0; R < 8; ++R) {
+    auto row_tile = [&](int R) __attribute__((always_inline)) {
       kstep(std::integral_constant<int, 0>{}, 2 * R, ah0, al0, ah1, al1, a1n);
       a1n = layer1(R + 1);     // layer 1 of row tile R + 1 goes into the matrix pipe behind the 24 MFMAs
       kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n);
       bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
+    };
+    if constexpr (FULL) {
+      static_for<0, 8>([&](auto RI) { constexpr int R = RI; row_tile(R); });
+    } else {
+#pragma unroll 1
+      for (int R = 0; R < 8; ++R) row_tile(R);
     }
     // relu of layer 2 (the bias is already in the accumulators) and layer 3 over the 128 neurons this lane holds for its env
     // column (the other 128 are in lane ^ 32), on the matrix pipe (layer3_tile)
@@ -509,6 +530,12 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
     });
   }
   static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
+}
+template <int IN>
+AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, uint4 *ring, int nw,
+                                   const float (&s)[IN], float (&out)[3]) {
+  if (__builtin_expect(nw == 4, 1)) actor_forward_wg_f16x3_impl<IN, true>(A, H, w1_lds, ring, nw, s, out);
+  else actor_forward_wg_f16x3_impl<IN, false>(A, H, w1_lds, ring, nw, s, out);
 }
 
 }  // namespace armenv

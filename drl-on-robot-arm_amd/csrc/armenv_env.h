@@ -161,6 +161,9 @@ AE_DEV void prefetch_settle(ActionPrefetch &d, float (&out)[3]) {
 #define ARMENV_TRIG_REDERIVE 512
 #endif
 constexpr int kTrigRederive = ARMENV_TRIG_REDERIVE;
+#ifndef ARMENV_ROLLOUT_PEEL
+#define ARMENV_ROLLOUT_PEEL 3
+#endif
 
 struct StepIO {
   const float *action;
@@ -488,12 +491,12 @@ template <class C, typename T, int MODE = 0> struct ReachLane {
   // consumed here, right after the IK and BEFORE this step's stores are issued: the s_waitcnt the consumption needs
   // then covers only that old load; placed at the next step's top it would also wait for this step's stores
   // (vmcnt is in-order) -- measured 15 % of the wave's cycles.
-  template <bool CARRY = false>
+  template <bool CARRY = false, int PEEL = 0>
   AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
                     float (*next_action)[3] = nullptr) {
     T tgt[3];
     step_begin<CARRY>(P, a, tgt);
-    const int updates = ik_lockstep<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, minpiv);                               // :244-257
+    const int updates = ik_lockstep<C, T, kMode, PEEL>(P.chain, P.ik, q, tgt, S, cq, sq, minpiv);                               // :244-257
     const bool lim_hit = ik_limits<C, T, kMode>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail<CARRY>(P, i, io, updates, lim_hit);
@@ -819,12 +822,12 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
       }
     }
   }
-  template <bool CARRY = false>
+  template <bool CARRY = false, int PEEL = 0>
   AE_DEV int env_step(const EnvParams<T> &P, int64_t i, const T (&a)[3], const StepIO &io, ActionPrefetch *prefetched = nullptr,
                     float (*next_action)[3] = nullptr) {
     T tgt[3];
     step_begin<CARRY>(P, a, tgt);
-    const int updates = ik_lockstep<C, T, kMode>(P.chain, P.ik, q, tgt, S, cq, sq, minpiv);                               // :339-347
+    const int updates = ik_lockstep<C, T, kMode, PEEL>(P.chain, P.ik, q, tgt, S, cq, sq, minpiv);                               // :339-347
     const bool lim_hit = ik_limits<C, T, kMode>(P.chain, P.ik, q, S, cq, sq);
     if (prefetched) prefetch_settle(*prefetched, *next_action);
     step_tail<CARRY>(P, i, io, updates, lim_hit);
@@ -947,6 +950,8 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
   // the link frames travel from step to step in registers -- except across a fused actor, which needs the whole register file
   // between two env steps (the lanes then recompute the frame at the top of every step)
   constexpr bool kCarry = !kActor;
+  // straight-line IK trips ahead of the trip loop (armenv_kin.h ik_lockstep); none beside a fused actor (register pressure)
+  constexpr int kPeel = kActor ? 0 : ARMENV_ROLLOUT_PEEL;
   if constexpr (kCarry) L.make_frame(P);
   for (int32_t t = 0; t < steps; ++t) {
     T a[3];
@@ -996,9 +1001,9 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     const uint32_t before = L.n_done;
     int upd;
     if constexpr (kPrefetch) {
-      upd = L.template env_step<kCarry>(P, i, a, io, &an_next, &an);
+      upd = L.template env_step<kCarry, kPeel>(P, i, a, io, &an_next, &an);
     } else {
-      upd = L.template env_step<kCarry>(P, i, a, io);
+      upd = L.template env_step<kCarry, kPeel>(P, i, a, io);
     }
     if constexpr (Lane::kFence) w_trips += wave_max8((uint32_t)upd + 1u);   // a lane's trips: its updates + the exit trip
     else (void)upd;

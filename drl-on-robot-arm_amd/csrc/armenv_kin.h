@@ -655,7 +655,9 @@ AE_DEV bool ik_stop(const IKParams<T> &P, const T (&tgt)[3], const FKState<T> &S
   const T dtest = em == 0 ? diff2_prev : diff2;
   return (it >= P.max_iters) | !(dtest > res2);
 }
-template <class C, typename T, int MODE = 0>
+// SMALL: 1 / 0 = the caller has already branched on small_steps (a compile-time constant here: the lockstep loop tests it once per
+// step instead of once per trip), -1 = the run-time argument decides.
+template <class C, typename T, int MODE = 0, int SMALL = -1>
 AE_DEV void ik_update(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], FKState<T> &S, T (&cq)[NJ], T (&sq)[NJ], T (&e)[6],
                       const T (&pe)[3], T diff2, T &diff2_prev, int &it, bool small_steps, T &minpiv) {
   T qc[4], eo[3], dth[NJ];
@@ -664,6 +666,7 @@ AE_DEV void ik_update(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], F
   e[3] = eo[0]; e[4] = eo[1]; e[5] = eo[2];
   dls_update<C, T, MODE>(S, pe, e, P, dth, minpiv);
   static_for<0, NJ>([&](auto II) { constexpr int i = II; q[i] += dth[i]; });
+  if constexpr (SMALL >= 0) small_steps = SMALL != 0;
 #ifdef ARMENV_EXACT_ROTATE
   small_steps = false;
 #endif
@@ -676,26 +679,38 @@ AE_DEV void ik_update(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], F
   ++it;
   fk<C, T>(ch, cq, sq, S);
 }
-template <class C, typename T, int MODE = 0>
+template <class C, typename T, int MODE = 0, int SMALL = -1>
 AE_DEV bool ik_trip(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
                     T (&sq)[NJ], T &diff2_prev, int &it, T res2, bool small_steps, T &minpiv) {
   T e[6], pe[3], diff2;
   if (ik_stop<C, T, MODE>(P, tgt, S, diff2_prev, it, res2, e, pe, diff2)) return true;
-  ik_update<C, T, MODE>(ch, P, q, S, cq, sq, e, pe, diff2, diff2_prev, it, small_steps, minpiv);
+  ik_update<C, T, MODE, SMALL>(ch, P, q, S, cq, sq, e, pe, diff2, diff2_prev, it, small_steps, minpiv);
   return false;
 }
 // Bullet's loop for the lanes of a wave walking through it together (the lockstep kernels).  Returns the lane's number of updates.
-// (A form with the wave-level exit spelled out -- `if (__ballot(!stop) == 0) break; if (!stop) ik_update(...)` -- was tried in
-// round 4 to save the loop's entry jump and one of its two exit branches: hipcc's structuriser folds it back into the same
-// exec-mask loop, with a few more scalar instructions.)
-template <class C, typename T, int MODE = 0>
+// PEEL: the first PEEL trips are straight-line code, each under the mask of the lanes that have not stopped: nearly every step needs
+// them (reach: 2 updates on 8 % of the steps, 3 on 92 %), and a loop's taken back edge costs a lone wave ~47 ns
+// (tests/tools/exp/branch_cost_probe.hip) where a not-taken skip costs ~8.  The loop behind them takes
+// what is left.  The rollout kernels peel three trips (reach -2.4 %, push -1.3 % per step); the one-step kernel none: its
+// instruction fetch starts cold at every launch, and 24 KB more code cost it 2-6 %.
+// (A form with the wave-level exit spelled out -- `if (__ballot(!stop) == 0) break; if (!stop) ik_update(...)` -- was tried to save
+// the loop's entry jump and one of its two exit branches: hipcc's structuriser folds it back into the same exec-mask loop.)
+template <class C, typename T, int MODE = 0, int PEEL = 0>
 AE_DEV int ik_lockstep(const ChainDev<T> &ch, const IKParams<T> &P, T (&q)[NJ], const T (&tgt)[3], FKState<T> &S, T (&cq)[NJ],
                        T (&sq)[NJ], T &minpiv) {
   const T res2 = P.residual * P.residual;     // |p - tgt| > residual on squares: no sqrt on the loop-carried critical path
+  // every update is bounded by max_dtheta; up to pi/4 (Bullet's 45 degrees) the rotations are advanced incrementally,
+  // otherwise cos / sin are recomputed from q
   const bool small_steps = P.max_dtheta <= T(0.7854);
   T diff2_prev = T(1e60);
   int it = 0;
-  while (!ik_trip<C, T, MODE>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps, minpiv)) {}
+  // (Branching on small_steps HERE, once per step, with two compile-time copies of the trips behind it, was tried: the second copy
+  // of the loop raised the register pressure -- 124 -> 181 AGPRs of spill space in the reach rollout -- and cost 8 %.)
+  bool stopped = false;
+  static_for<0, PEEL>([&](auto) {
+    if (!stopped) stopped = ik_trip<C, T, MODE>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps, minpiv);
+  });
+  if (!stopped) while (!ik_trip<C, T, MODE>(ch, P, q, tgt, S, cq, sq, diff2_prev, it, res2, small_steps, minpiv)) {}
   return it;
 }
 
