@@ -317,6 +317,66 @@ def test_limit_pushback_model_teacher_forced(envs, O, kuka, precision):
 
 
 @pytest.mark.parametrize("task", ["reach", "push", "pick"])
+def test_trig_rederivation_at_step_512_in_every_launch_grouping(envs, task):
+    """The carried (cos q, sin q) pair is re-derived from q when an env's own step counter reaches a multiple of 512 (never inside
+    the reference's 501-step episodes; round 4 moved the re-derivation from the top of the next step to the tail of this one, into
+    the rare out-of-line region it shares with `done`).  With 1 300-step episodes: (i) right after step 512 the carried pair IS the
+    pair set_state derives from the same q, bit for bit -- and one step earlier it is not, for most envs (the incremental rotations
+    have drifted by last bits); (ii) the trajectory across steps 512 and 1 024 is the same bits as ONE rollout launch, as 100-step
+    launches (the re-derivation falls inside a launch, and -- at 1 024 -- on a launch's last step: the lane-asynchronous and the
+    lockstep kernels, full and half-filled waves) and as one-step launches around the two boundaries."""
+    n = 256 + 5
+    Env = dict(reach=envs.BatchedReachEnv, push=envs.BatchedPushEnv, pick=envs.BatchedPickEnv)[task]
+    gen = torch.Generator(device=DEV); gen.manual_seed(11)
+    sig = 0.686 if task == "reach" else 0.392
+    acts = (torch.randn((1100, n, 3), device=DEV, generator=gen) * sig).clamp_(-0.7, 0.7).contiguous()
+    kw = dict(device=DEV, seed=4, max_steps=1300, reach_dis=1e-9) if task == "reach" else dict(device=DEV, seed=4, max_steps=1300, push_success_dis=1e-9)
+
+    def derived(e):      # the pair as set_state derives it from the handle's own q
+        st = {k: v.clone() for k, v in e.get_state().items()}
+        f = Env(n, **kw); f.reset()
+        f.set_state(**{k: v for k, v in st.items() if k != "trig"})
+        t = f.get_state()["trig"].clone(); f.close()
+        return st["trig"], t
+
+    a = Env(n, **kw); a.reset()
+    a.rollout(511, acts[:511].contiguous())
+    carried, fresh = derived(a)
+    assert int((carried != fresh).any(dim=1).sum()) > n // 2          # the drift the re-derivation removes is there
+    a.rollout(1, acts[511:512].contiguous())
+    assert int(a.get_state()["step"].min()) == 512 and int(a.get_state()["step"].max()) == 512
+    carried, fresh = derived(a)
+    assert torch.equal(carried, fresh)
+    a.rollout(588, acts[512:].contiguous())
+    ref = {k: v.clone() for k, v in a.get_state().items()}
+    a.close()
+
+    def same(e, what):
+        st = e.get_state()
+        for k in ref:
+            assert torch.equal(ref[k], st[k]), (task, what, k)
+        e.close()
+
+    b = Env(n, **kw); b.reset()
+    b.rollout(1100, acts)                                               # one launch
+    same(b, "one launch")
+    for ready, lanes in ((0, 64), (62, 32), (0, 32)):                    # 100-step launches: step 512 inside one, 1 024 = a launch's last but... 1 000 + 24
+        c = Env(n, rollout_ready_lanes=ready, rollout_lanes_per_wave=lanes, **kw); c.reset()
+        for k in range(11):
+            c.rollout(100, acts[100 * k:100 * (k + 1)].contiguous())
+        same(c, ("100-step launches", ready, lanes))
+    d = Env(n, **kw); d.reset()                                          # launches that END on the re-derivation steps, step launches around them
+    d.rollout(510, acts[:510].contiguous())
+    for t in range(510, 515):
+        d.step(acts[t])
+    d.rollout(1024 - 515, acts[515:1024].contiguous())
+    for t in range(1024, 1030):
+        d.step(acts[t])
+    d.rollout(1100 - 1030, acts[1030:].contiguous())
+    same(d, "boundaries as launch ends and step launches")
+
+
+@pytest.mark.parametrize("task", ["reach", "push", "pick"])
 def test_checkpoint_restores_the_trajectory_bitwise(envs, task):
     """get_state / set_state as a checkpoint: the carried (cos q, sin q) pair travels with q, so a handle
     restored mid-episode continues the uninterrupted run bit for bit -- outputs and final state; restoring q alone
