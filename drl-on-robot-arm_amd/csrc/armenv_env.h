@@ -164,6 +164,9 @@ constexpr int kTrigRederive = ARMENV_TRIG_REDERIVE;
 #ifndef ARMENV_ROLLOUT_PEEL
 #define ARMENV_ROLLOUT_PEEL 3
 #endif
+#ifndef ARMENV_STEP_PEEL
+#define ARMENV_STEP_PEEL 0
+#endif
 
 struct StepIO {
   const float *action;
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   TL_STAMP(tl1);
-  const int updates = L.template env_step<false>(P, i, a, io);
+  const int updates = L.template env_step<false, ARMENV_STEP_PEEL>(P, i, a, io);
   (void)updates;
   TL_STAMP(tl2);
   L.store(P, i);
