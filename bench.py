@@ -629,15 +629,16 @@ def main():
         tc = p()
         if trailing:
             do_gather()              # host work under the running kernels; its device work is behind ev1 / on the side stream
-        evs.synchronize(1)           # the K steps are done when it returns
-        td = p()
-        # The K steps are done on this rank when its launch stream is idle (wall_steps).  The contract's closing bracket is a device
-        # synchronise + barrier: with several ranks that also waits for the logging all-gather on the side stream and for the
-        # slowest rank -- `value` is computed from THAT clock (as in rounds 1-2: the collective belongs to the region it is issued
-        # in), the rank-local figure is reported beside it as value_steps.
+        # The K steps are done on this rank when its launch stream is idle (wall_steps): ONE stream synchronise.  (Rounds 1-3 waited
+        # for ev1 first and synchronised the stream after it: the second call returned at once as far as the GPU was concerned and
+        # still cost ~5 us of host time inside the clock -- host_us.closing_sync of those rounds.)  The contract's closing bracket
+        # is a device synchronise + barrier: with several ranks that also waits for the logging all-gather on the side stream and
+        # for the slowest rank -- `value` is computed from THAT clock (as in rounds 1-2: the collective belongs to the region it is
+        # issued in), the rank-local figure is reported beside it as value_steps.
         evs.stream_synchronize()
-        wall_steps = p() - t0
-        te = p()
+        td = p()
+        wall_steps = td - t0
+        te = td
         if multi:
             gather.result()          # orders the launch stream behind the collective ...
             torch.cuda.synchronize(dev)   # ... and the device synchronise of the bracket waits for it
