@@ -86,12 +86,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // one env column's registers (f16x3 actor), or the two env columns of the exact-f32 actor's accumulator pair.
 template <int NT_BASE, class Relu>
 AE_DEV void layer3_tile(const float *w3p, const f32x16 &acc, f32x4 &d0, f32x4 &d1, Relu relu) {
-  float a[16];
+  float a[16], h[16];
   static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[r] = w3p[4 * (32 * NT_BASE + (r & 3) + 8 * (r >> 2))]; });
+  // The sixteen relu'd values first, each in a register of its own, then the sixteen MFMAs: left to itself hipcc funnels every value
+  // through ONE temporary (accumulator read -> v_max -> s_nop -> MFMA, 128 times in a row per env tile: ~18 cycles per neuron,
+  // 4 170 cycles per pass by the instrumented build's stamps, tests/tools/exp/run_actor_timeline.py); apart, the vector and the
+  // matrix pipe overlap.
+  static_for<0, 16>([&](auto RI) { constexpr int r = RI; h[r] = relu(acc[r]); });
+  __builtin_amdgcn_sched_barrier(0);
   static_for<0, 8>([&](auto RI) {
     constexpr int r = RI;
-    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], relu(acc[r]), d0, 0, 0, 0);
-    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r + 8], relu(acc[r + 8]), d1, 0, 0, 0);
+    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], h[r], d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r + 8], h[r + 8], d1, 0, 0, 0);
+  });
+}
+// layer3_tile over the NT tiles of one env column, with the A values (W3) of tile nt + 1 requested from LDS before tile nt's MFMAs are
+// issued: inside layer3_tile alone the sixteen reads of a tile sat between the previous tile's MFMAs and this tile's, and every tile
+// began with an exposed LDS round trip (round 4, by the instrumented build's stamps: 4 170 -> 3 490 -> see DESIGN.md cycles per pass).
+template <int NT, class Relu>
+AE_DEV void layer3_column(const float *w3p, const f32x16 (&acc)[NT], f32x4 &d0, f32x4 &d1, Relu relu) {
+  float a[2][16], h[16];
+  static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[0][r] = w3p[4 * ((r & 3) + 8 * (r >> 2))]; });
+  static_for<0, NT>([&](auto NI) {
+    constexpr int nt = NI;
+    if constexpr (nt + 1 < NT)
+      static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[(nt + 1) & 1][r] = w3p[4 * (32 * (nt + 1) + (r & 3) + 8 * (r >> 2))]; });
+    static_for<0, 16>([&](auto RI) { constexpr int r = RI; h[r] = relu(acc[nt][r]); });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 8>([&](auto RI) {
+      constexpr int r = RI;
+      d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[nt & 1][r], h[r], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[nt & 1][r + 8], h[r + 8], d1, 0, 0, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);     // (without it hipcc moves the next tile's LDS reads back behind these MFMAs: 2 760 -> 3 500 cycles)
   });
 }
 template <int NT_BASE, class Relu>
@@ -336,6 +363,28 @@ AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // t
 }
 AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Instrumented build only (make timeline): shader-clock stamps of workgroup 0's four waves at the phases of the f16x3 pass, written to
+// the buffer tests/tools/exp/run_actor_timeline.py installs (row = wave, 64 stamps each: 20 t + {0 pass start, 1 first row tile split,
+// 2..17 after k-step 0..15, 18 after layer 3}).
+#ifdef ARMENV_TIMELINE
+static __device__ unsigned long long *g_actor_tl;
+// accumulate the shader-clock time since the previous stamp into class k (scalar registers only: a store inside the k-loops would be
+// waited for by the next k-step's vmcnt(0)); ATL_FLUSH writes the classes once per pass
+#define ATL(k)                                                                \
+  do {                                                                        \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();               \
+    atl_acc[k] += t_ - atl_prev;                                              \
+    atl_prev = t_;                                                            \
+  } while (0)
+#define ATL_FLUSH(t)                                                                                                        \
+  do {                                                                                                                      \
+    if (blockIdx.x == 0 && g_actor_tl && (threadIdx.x & 63) == 0)                                                           \
+      for (int k_ = 0; k_ < 5; ++k_) g_actor_tl[(threadIdx.x >> 6) * 64 + 8 * (t) + k_] = atl_acc[k_];                      \
+  } while (0)
+#else
+#define ATL(k)
+#define ATL_FLUSH(t)
+#endif
 // FULL: all four waves of the workgroup are live (nw == 4: every workgroup but the last one of a batch that is not a multiple of
 // 256 envs).  That copy has its sixteen k-steps UNROLLED: the k-step index is then a compile-time constant -- which LDS region a
 // k-step reads, whether it refills a ring slot and which one fold away, and with them the wave-uniform BRANCHES the rolled loop
@@ -385,6 +434,9 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
     // Layer 1 on the f16 MFMA as well, three passes like layer 2: H1^T[32 R + row][env] = W1aug[32 R + row][:] . saug[:][env],
     // saug = [obs, 1, 0..].  B operand: lane l holds saug[8 (l >> 5) + j], j = 0..7, of env (l & 31) + 32 t, split hi / lo.  (As
     // f32 MFMAs, four k-pairs of 64 cycles each, layer 1 held the matrix pipe for 1.7 us of every env step; as 3 x 32 cycles 0.6 us.)
+#ifdef ARMENV_TIMELINE
+    unsigned long long atl_acc[5] = {0, 0, 0, 0, 0}, atl_prev = __builtin_amdgcn_s_memtime();   // prologue | resident k-steps | streamed even | streamed odd | layer 3
+#endif
     half8 oh, ol;
     static_for<0, 8>([&](auto JI) {
       constexpr int j = JI;
@@ -510,10 +562,13 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
       static_for<0, NT>([&](auto NI) { constexpr int nt = NI; ah0[nt] = slot[(2 * nt) * 64]; al0[nt] = slot[(2 * nt + 1) * 64]; });
     }
     f32x16 a1n = {};
+    if constexpr (FULL) ATL(0);
     auto row_tile = [&](int R) __attribute__((always_inline)) {
       kstep(std::integral_constant<int, 0>{}, 2 * R, ah0, al0, ah1, al1, a1n);
+      if constexpr (FULL) ATL(2 * R < ACTOR_KRES ? 1 : 2);
       a1n = layer1(R + 1);     // layer 1 of row tile R + 1 goes into the matrix pipe behind the 24 MFMAs
       kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n);
+      if constexpr (FULL) ATL(2 * R + 1 < ACTOR_KRES ? 1 : 3);
       bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
     };
     if constexpr (FULL) {
@@ -526,13 +581,14 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
     // column (the other 128 are in lane ^ 32), on the matrix pipe (layer3_tile)
     f32x4 d30 = {0.f, 0.f, 0.f, 0.f}, d31 = {0.f, 0.f, 0.f, 0.f};
     const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);
-    static_for<0, NT>([&](auto NI) { constexpr int nt = NI; layer3_tile<nt>(w3p, acc[nt], d30, d31, relu); });
+    layer3_column<NT>(w3p, acc, d30, d31, relu);
     const f32x4 s3 = d30 + d31;
     static_for<0, 3>([&](auto OI) {
       constexpr int o = OI;
       const float tot = s3[o] + __shfl_xor(s3[o], 32);       // lane e holds env e: tile e >> 5, column e & 31
       z[o] = (half == t) ? tot : z[o];
     });
+    if constexpr (FULL) { ATL(4); ATL_FLUSH(t); }
   }
   static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
 }

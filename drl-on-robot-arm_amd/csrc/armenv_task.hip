@@ -25,5 +25,8 @@ extern "C" {
 int armenv_dbg_set_timeline(unsigned long long *buf_dev) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf_dev, sizeof buf_dev);
 }
+int armenv_dbg_set_actor_timeline(unsigned long long *buf_dev) {     // [4 waves][64 stamps], workgroup 0 of the fused f16x3 rollout
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_actor_tl), &buf_dev, sizeof buf_dev);
+}
 #endif
 }
