@@ -471,21 +471,30 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
       l[u][2 * c] = (_Float16)(x0 - (float)h0); l[u][2 * c + 1] = (_Float16)(x1 - (float)h1);
     };
     // the same in two halves that fit the shadow of one MFMA each: (A) relu + hi, (B) lo
+    // hi as ONE packed conversion (v_cvt_pk_f16_f32) whose two halves are converted back for the lo parts: written on scalar halves
+    // hipcc converted each value to f16 on its own for the subtraction and packed the pair a second time for the operand
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    typedef float float2_t __attribute__((ext_vector_type(2)));
     float sx0 = 0.f, sx1 = 0.f;
+    half2_t shp = {(_Float16)0.f, (_Float16)0.f};
     auto split2a = [&](const f32x16 &a1, auto UI, auto CI, half8 (&h)[2]) {
       constexpr int u = UI, c = CI;
       sx0 = relu(a1[8 * u + 2 * c]); sx1 = relu(a1[8 * u + 2 * c + 1]);
-      h[u][2 * c] = (_Float16)sx0; h[u][2 * c + 1] = (_Float16)sx1;
+      const float2_t xp = {sx0, sx1};
+      shp = __builtin_convertvector(xp, half2_t);
+      h[u][2 * c] = shp[0]; h[u][2 * c + 1] = shp[1];
     };
     auto split2b = [&](auto UI, auto CI, const half8 (&h)[2], half8 (&l)[2]) {
       constexpr int u = UI, c = CI;
       // two scalar subtractions, kept apart: hipcc's SLP pass pairs them into one v_pk_add_f32, and a packed f32 instruction in
       // an MFMA's shadow costs ~13 cycles more than the two scalar ones it replaces (MI355X_MICROARCH.md: an anti-lever beside
       // MFMAs); in-session 28.4 -> 27.9 us per fused env step
-      float d0 = sx0 - (float)h[u][2 * c];
+      float d0 = sx0 - (float)shp[0];
       asm("" : "+v"(d0));
-      const float d1 = sx1 - (float)h[u][2 * c + 1];
-      l[u][2 * c] = (_Float16)d0; l[u][2 * c + 1] = (_Float16)d1;
+      const float d1 = sx1 - (float)shp[1];
+      const float2_t dp = {d0, d1};
+      const half2_t lp = __builtin_convertvector(dp, half2_t);
+      l[u][2 * c] = lp[0]; l[u][2 * c + 1] = lp[1];
     };
     f32x16 acc[NT];   // start from the layer-2 bias: register r <-> neuron 32 nt + 8 (r / 4) + 4 half + (r % 4)
     static_for<0, NT>([&](auto NI) {
@@ -509,7 +518,7 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
     //   slots 8..23   one LDS read each of k-step ks + 1's fragments into (nh, nl) and, on odd k-steps, half of the
     //                 relu + hi / lo split of a pair of layer-1 values of the next row tile.
     auto kstep = [&](auto ODD, int ks, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT],
-                     const f32x16 &a1n) __attribute__((always_inline)) {
+                     const f32x16 &a1n, auto &&inject) __attribute__((always_inline)) {
       constexpr int u = ODD;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of the fill issued one k-step ago (k-step ks + 1)
       __builtin_amdgcn_s_barrier();
@@ -523,6 +532,8 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
         constexpr int k3 = m / NT, nt = m % NT;
         __builtin_amdgcn_sched_barrier(0);
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k3 == 2 ? cl[nt] : ch[nt], k3 == 1 ? bl[u] : bh[u], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        inject(MI);      // the caller's own matrix-pipe work for this slot (even k-steps: layer 1 of the next row tile)
         __builtin_amdgcn_sched_barrier(0);
         // slots 1, 3, 5, 7: one quarter each of the refill two stream positions ahead (early, so that it has most of a
         // k-step to land before the head of the next one waits for it)
@@ -563,11 +574,24 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
     }
     f32x16 a1n = {};
     if constexpr (FULL) ATL(0);
+    half8 l1wh, l1wl;
     auto row_tile = [&](int R) __attribute__((always_inline)) {
-      kstep(std::integral_constant<int, 0>{}, 2 * R, ah0, al0, ah1, al1, a1n);
+      // layer 1 of row tile R + 1 rides inside the even k-step: its three MFMAs are a dependent chain on one accumulator tile and
+      // need their two operands from LDS; behind the k-step (rounds 2-3) that was ~190 cycles of every row tile with the matrix
+      // pipe mostly idle (instrumented build: odd k-steps 1 068 cycles against 882 for even ones); eight slots apart nothing waits
+      kstep(std::integral_constant<int, 0>{}, 2 * R, ah0, al0, ah1, al1, a1n, [&](auto MI) __attribute__((always_inline)) {
+        constexpr int m = MI;
+        if constexpr (m == 2) { const half8 *w = w1h + (R + 1 < 8 ? R + 1 : 7) * 128; l1wh = w[0]; l1wl = w[64]; }
+        if constexpr (m == 7) {
+          f32x16 z0;
+          static_for<0, 16>([&](auto RI) { constexpr int r = RI; z0[r] = 0.f; });
+          a1n = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1wh, oh, z0, 0, 0, 0);
+        }
+        if constexpr (m == 15) a1n = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1wh, ol, a1n, 0, 0, 0);
+        if constexpr (m == 23) a1n = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1wl, oh, a1n, 0, 0, 0);
+      });
       if constexpr (FULL) ATL(2 * R < ACTOR_KRES ? 1 : 2);
-      a1n = layer1(R + 1);     // layer 1 of row tile R + 1 goes into the matrix pipe behind the 24 MFMAs
-      kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n);
+      kstep(std::integral_constant<int, 1>{}, 2 * R + 1, ah1, al1, ah0, al0, a1n, [](auto) {});
       if constexpr (FULL) ATL(2 * R + 1 < ACTOR_KRES ? 1 : 3);
       bh[0] = bh_n[0]; bh[1] = bh_n[1]; bl[0] = bl_n[0]; bl[1] = bl_n[1];
     };
