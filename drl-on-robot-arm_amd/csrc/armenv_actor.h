@@ -84,25 +84,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // operand reads the next neuron's b2 -- finite, and result register 3 is never looked at.
 // Two independent accumulator chains per call (a 4x4x1 result is ready two passes after issue): d0 / d1 are the two halves of
 // one env column's registers (f16x3 actor), or the two env columns of the exact-f32 actor's accumulator pair.
-template <int NT_BASE, class Relu>
-AE_DEV void layer3_tile(const float *w3p, const f32x16 &acc, f32x4 &d0, f32x4 &d1, Relu relu) {
-  float a[16], h[16];
-  static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[r] = w3p[4 * (32 * NT_BASE + (r & 3) + 8 * (r >> 2))]; });
-  // The sixteen relu'd values first, each in a register of its own, then the sixteen MFMAs: left to itself hipcc funnels every value
-  // through ONE temporary (accumulator read -> v_max -> s_nop -> MFMA, 128 times in a row per env tile: ~18 cycles per neuron,
-  // 4 170 cycles per pass by the instrumented build's stamps, tests/tools/exp/run_actor_timeline.py); apart, the vector and the
-  // matrix pipe overlap.
-  static_for<0, 16>([&](auto RI) { constexpr int r = RI; h[r] = relu(acc[r]); });
-  __builtin_amdgcn_sched_barrier(0);
-  static_for<0, 8>([&](auto RI) {
-    constexpr int r = RI;
-    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], h[r], d0, 0, 0, 0);
-    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r + 8], h[r + 8], d1, 0, 0, 0);
-  });
-}
-// layer3_tile over the NT tiles of one env column, with the A values (W3) of tile nt + 1 requested from LDS before tile nt's MFMAs are
-// issued: inside layer3_tile alone the sixteen reads of a tile sat between the previous tile's MFMAs and this tile's, and every tile
-// began with an exposed LDS round trip (round 4, by the instrumented build's stamps: 4 170 -> 3 490 -> see DESIGN.md cycles per pass).
+// Layer 3 over the NT tiles of one env column, with the A values (W3) of tile nt + 1 requested from LDS before tile nt's MFMAs are
+// issued: tile by tile the sixteen reads sat between the previous tile's MFMAs and this tile's, and every tile began with an
+// exposed LDS round trip (round 4, by the instrumented build's stamps: 4 170 -> 3 490 -> see DESIGN.md cycles per pass).
 template <int NT, class Relu>
 AE_DEV void layer3_column(const float *w3p, const f32x16 (&acc)[NT], f32x4 &d0, f32x4 &d1, Relu relu) {
   float a[2][16], h[16];
@@ -121,17 +105,6 @@ AE_DEV void layer3_column(const float *w3p, const f32x16 (&acc)[NT], f32x4 &d0, 
     __builtin_amdgcn_sched_barrier(0);     // (without it hipcc moves the next tile's LDS reads back behind these MFMAs: 2 760 -> 3 500 cycles)
   });
 }
-template <int NT_BASE, class Relu>
-AE_DEV void layer3_tile_pair(const float *w3p, const f32x16 &accA, const f32x16 &accB, f32x4 &dA, f32x4 &dB, Relu relu) {
-  float a[16];
-  static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[r] = w3p[4 * (32 * NT_BASE + (r & 3) + 8 * (r >> 2))]; });
-  static_for<0, 16>([&](auto RI) {
-    constexpr int r = RI;
-    dA = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], relu(accA[r]), dA, 0, 0, 0);
-    dB = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], relu(accB[r]), dB, 0, 0, 0);
-  });
-}
-
 // Exact-f32 actor for the 64 envs of one wave.  s: this lane's env observation (IN floats); all 64 lanes must be active;
 // w1_lds: the tables of actor_stage_w1.
 //   Layer 1 runs on the f32 MFMA as W1aug . [obs, 1] per 32-neuron row tile and env column tile.  In the accumulator
@@ -193,7 +166,7 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
   const float4 *w2 = A.W2P + l32;
   const float4 *b2w3 = w1_lds + ACTOR_W1A_FLOATS / 4;     // staged beside the layer-1 table
   const float4 *b2tab = b2w3 + ACTOR_HID;                 // b2 alone, four consecutive neurons per float4
-  const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);   // layer3_tile
+  const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);   // layer 3's A values
   f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};   // layer-3 sums of the env in tile 0 / tile 1
   constexpr int AD = 4;
 #pragma unroll 1
@@ -243,12 +216,27 @@ AE_DEV void actor_forward_wave(const ActorParams &A, const float4 *w1_lds, const
       a1A = nA; a1B = nB;
     }
     // relu of layer 2 (the bias is already in the accumulators) and layer 3 over the 64 neurons this lane holds per env tile in
-    // this pass, on the matrix pipe (layer3_tile)
+    // this pass, on the matrix pipe (layer3_column)
+    // as in layer3_column: relu'd values in registers of their own ahead of the MFMAs, the next tile's W3 values requested from
+    // LDS before this tile's MFMAs (hipcc's own order funnels every value through one temporary register)
     const float *w3part = w3p + 4 * 128 * part;
-    static_for<0, 4>([&](auto NI) {
-      constexpr int nt = NI;
-      layer3_tile_pair<nt>(w3part, acc[nt][0], acc[nt][1], dA, dB, relu);
-    });
+    {
+      float a[2][16], hA[16], hB[16];
+      static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[0][r] = w3part[4 * ((r & 3) + 8 * (r >> 2))]; });
+      static_for<0, 4>([&](auto NI) {
+        constexpr int nt = NI;
+        if constexpr (nt + 1 < 4)
+          static_for<0, 16>([&](auto RI) { constexpr int r = RI; a[(nt + 1) & 1][r] = w3part[4 * (32 * (nt + 1) + (r & 3) + 8 * (r >> 2))]; });
+        static_for<0, 16>([&](auto RI) { constexpr int r = RI; hA[r] = relu(acc[nt][0][r]); hB[r] = relu(acc[nt][1][r]); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 16>([&](auto RI) {
+          constexpr int r = RI;
+          dA = __builtin_amdgcn_mfma_f32_4x4x1f32(a[nt & 1][r], hA[r], dA, 0, 0, 0);
+          dB = __builtin_amdgcn_mfma_f32_4x4x1f32(a[nt & 1][r], hB[r], dB, 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
   }
   const f32x4 sA = dA, sB = dB;
   static_for<0, 3>([&](auto OI) {
@@ -602,7 +590,7 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
       for (int R = 0; R < 8; ++R) row_tile(R);
     }
     // relu of layer 2 (the bias is already in the accumulators) and layer 3 over the 128 neurons this lane holds for its env
-    // column (the other 128 are in lane ^ 32), on the matrix pipe (layer3_tile)
+    // column (the other 128 are in lane ^ 32), on the matrix pipe (layer3_column)
     f32x4 d30 = {0.f, 0.f, 0.f, 0.f}, d31 = {0.f, 0.f, 0.f, 0.f};
     const float *w3p = reinterpret_cast<const float *>(b2w3) + 16 * half + 1 + (lane & 3);
     layer3_column<NT>(w3p, acc, d30, d31, relu);
