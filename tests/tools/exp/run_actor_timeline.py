@@ -7,7 +7,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "..", "..", "..", "drl-on-robot-arm_amd"))
 from armenv import _lib as L
-L.LIB_PATH = os.path.join(ROOT, "libarmenv_tl.so")
+L.LIB_PATH = os.environ.get("ARMENV_TL_LIB", os.path.join(ROOT, "libarmenv_tl.so"))
 from armenv import envs
 n = 65536
 e = envs.BatchedReachEnv(n, device="cuda:0")
