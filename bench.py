@@ -150,6 +150,39 @@ class HipEvents:
             self.h = None
 
 
+class ClockProbes:
+    """armenv_probe_clock samples around the timed regions: one wavefront runs a fixed dependent chain of 4 096 v_fma_f32 between two
+    readings of the device's 100 MHz counter, so a sample's duration is inversely proportional to the shader clock at that moment.
+    Enqueued OUTSIDE every clock and every pair of HIP events (before the opening synchronise, after the closing one); read back
+    once at the end of the run."""
+
+    def __init__(self, dev, cap=256):
+        import ctypes as C
+        from armenv import _lib
+        self.C, self.lib, self.dev = C, _lib.load(), dev
+        self.buf = torch.zeros((cap, 4), dtype=torch.int64, device=dev)
+        self.tags = []
+
+    def mark(self, tag):
+        if tag is None or len(self.tags) >= self.buf.shape[0]:
+            return
+        C = self.C
+        ptr = C.c_void_p(self.buf[len(self.tags)].data_ptr())
+        if self.lib.armenv_probe_clock(self.dev.index or 0, ptr, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)) == 0:
+            self.tags.append(tag)
+
+    def read(self):
+        """{tag: ns per chained instruction}, {tag: device time of the sample in us since the first sample}"""
+        if not self.tags:
+            return {}, {}
+        b = self.buf[:len(self.tags)].cpu().numpy()
+        t0 = int(b[0, 2])
+        ns = {t: float(b[i, 0]) * 10.0 / max(1.0, float(b[i, 3])) for i, t in enumerate(self.tags)}
+        at = {t: (int(b[i, 2]) - t0) * 0.01 for i, t in enumerate(self.tags)}
+        self.memtime_per_tick = float(np.median(b[:, 1] / np.maximum(b[:, 0], 1)))     # s_memtime ticks per 10 ns tick
+        return ns, at
+
+
 def algo_bytes_per_launch(task, policy, precision, n, steps_per_launch):
     """Algorithmic bytes one launch moves: caller I/O per env-step + the state read and written once."""
     io_b, st_b = IO_BYTES, STATE_BYTES[precision]
@@ -471,6 +504,46 @@ def prewarm_device(Env, n, dev, precision, ms):
     del bufs
 
 
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher around it (how the round driver types it): start the N ranks here, one
+    per GPU, as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+    bench.py <same argv>` in a process group of their own, relay their stdout (rank 0's ONE JSON line) and stderr, and return
+    their exit code.  The group is killed if it outlives ARMENV_BENCH_LAUNCH_TIMEOUT seconds (default 1800) or if this
+    process is interrupted.  The torch.distributed.run form keeps working: it sets WORLD_SIZE and never gets here."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver supports dmabuf IPC only (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    limit = float(os.environ.get("ARMENV_BENCH_LAUNCH_TIMEOUT", "1800"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)          # stdout / stderr inherited: the line passes through
+
+    def kill_group(*_):
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+    old = {s: signal.signal(s, lambda *_: (kill_group(), sys.exit(130))) for s in (signal.SIGINT, signal.SIGTERM)}
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        kill_group()
+        proc.wait()
+        print("bench.py: the %d-rank job did not finish within %.0f s and was killed" % (n_ranks, limit), file=sys.stderr)
+        return 124
+    finally:
+        if proc.poll() is None:      # no rank outlives the launcher
+            kill_group()
+        for s, h in old.items():
+            signal.signal(s, h)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,6 +559,10 @@ def main():
     ap.add_argument("--repeat-regions", type=int, default=15,
                     help="single-GPU runs: after the contract's timed region, the identical region this many more times on fresh "
                          "action rows -> value_median / value_min / value_max / launch_us_samples (0 = skip)")
+    ap.add_argument("--ab-regions", type=int, default=8,
+                    help="single-GPU runs with --repeat-regions > 0: the region this many more times under each of two other regimes "
+                         "(state restored on the device without a host round trip; the same behind 5 ms of other work) with clock "
+                         "probes around every region -> line.ab_device_restore / ab_busy_ahead, clock_probe_ns_samples (0 = skip)")
     ap.add_argument("--state-digest", action="store_true",
                     help="add config.state_digest: per rank, the sha256 of the joint angles of its envs right after the timed "
                          "region (tests: rank shards reproduce the single-handle trajectory)")
@@ -513,9 +590,12 @@ def main():
     from armenv.dist import ReturnGatherer, env_rank_world, init_process_group
 
     rank, local_rank, world = env_rank_world()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and relays rank 0's line
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or with plain "
+                         "`python bench.py --gpus %d` (no WORLD_SIZE in the environment)" % (args.gpus, world, args.gpus, args.gpus))
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % max(1, ndev))
     torch.cuda.set_device(dev)
@@ -606,12 +686,18 @@ def main():
 
     host_us = {}
 
-    def timed(k):
+    probes = ClockProbes(dev)
+
+    def timed(k, tag=None, count=True):
+        """tag: name of the region for the clock probes (one sample enqueued ahead of the opening synchronise, one after the
+        closing one; both outside the clock and the events).  count=False: no armenv_counters round trips around the region."""
         ops, launches, gathers = plan(k)
         evs = HipEvents(dev)
         evs.record(0); evs.record(1)  # first use outside the region
-        torch.cuda.synchronize(dev)
-        c0 = env.counters()
+        if count:
+            torch.cuda.synchronize(dev)
+        c0 = env.counters() if count else None
+        probes.mark(tag and tag + ":before")
         if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -650,15 +736,16 @@ def main():
         host_us.update(event0_record=(ta - t0) * 1e6, enqueue=(tb - ta) * 1e6, event1_record=(tc - tb) * 1e6,
                        wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, gather_wait=(tf - te) * 1e6,
                        barrier=(tg - tf) * 1e6)
-        c1 = env.counters()
+        probes.mark(tag and tag + ":after")
+        c1 = env.counters() if count else None
         gpu_ms = evs.elapsed_ms()
         evs.close()
-        return wall, gpu_ms, launches, gathers, {k_: c1[k_] - c0[k_] for k_ in c1}, wall_steps
+        return wall, gpu_ms, launches, gathers, ({k_: c1[k_] - c0[k_] for k_ in c1} if count else None), wall_steps
 
     prewarm_device(Env, n, dev, args.precision, args.prewarm_ms)
     run(args.warmup)
     snap = {k: v.clone() for k, v in env.get_state().items()} if (not multi and args.repeat_regions > 0) else None
-    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps)
+    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0")
     host_us_main = dict(host_us)
 
     # The headline is ONE sample of a short region (the driver's 20 steps are one 132 us launch): the same region again, 15
@@ -667,11 +754,34 @@ def main():
     # same handle, same launch shape, same bracket -- for the spread.  `value` stays the first region, the contract's; the
     # repeats are reported beside it.  The trajectory then continues from the last repeat's end.
     repeats = []
+    ab = {}
     if snap is not None:
-        for _ in range(args.repeat_regions):
+        for j in range(args.repeat_regions):
             env.set_state(**snap)
-            w_, g_, l_, _, _, _ = timed(args.steps)
+            w_, g_, l_, _, _, _ = timed(args.steps, tag="r%d" % (j + 1))
             repeats.append((w_, g_ * 1e3 / l_))
+        # Why do those samples spread (117 us on the driver's first region, 130-133 us on its last eight)?
+        # The same region again under two other regimes, eight times each, with the same clock probes:
+        #   device_restore: the state is restored by ONE device-to-device kernel enqueued on the launch stream and no counters are
+        #                   read -- no host round trip (D2H copy, synchronise) between a region and the next;
+        #   busy_ahead:     the same, with ~5 ms of rollout work on a scratch handle enqueued ahead of every region.
+        if args.ab_regions > 0:
+            scratch = Env(n, device=dev, seed=987654321, precision=args.precision)
+            scratch.set_policy("random", action_bound=0.7, noise_sigma=0.686, noise_clip=0.7)
+            scratch.reset()
+            sb = {}
+            for mode in ("device_restore", "busy_ahead"):
+                res = []
+                for j in range(args.ab_regions):
+                    if mode == "busy_ahead":
+                        for _ in range(7):
+                            scratch.rollout(100, None, out=sb)
+                    env.set_state(**snap, sync=False)
+                    w_, g_, l_, _, _, _ = timed(args.steps, tag="%s%d" % (mode, j), count=False)
+                    res.append((w_, g_ * 1e3 / l_))
+                ab[mode] = res
+            scratch.close()
+            del sb
 
     t = torch.tensor([wall, gpu_ms * 1e-3, wall_steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     per_rank = None
@@ -793,6 +903,27 @@ def main():
                          "regions": 1 + len(repeats),
                          "launch_us_samples": [round(u_, 2) for u_ in us],
                          "launch_us_median": sorted(us)[len(us) // 2], "launch_us_min": min(us), "launch_us_max": max(us)})
+            pns, pat = probes.read()
+            if pns:
+                # ns per chained v_fma_f32 of the probe wave right before / right after each region: ratio of two samples = inverse
+                # ratio of the shader clocks they ran at.  launch_us_at_fastest_clock rescales each launch to the run's fastest
+                # probe: if the spread of the launches is the clocks', it collapses here.
+                bef = [pns.get("r%d:before" % j) for j in range(len(us))]
+                aft = [pns.get("r%d:after" % j) for j in range(len(us))]
+                fastest = min(pns.values())
+                line.update({"clock_probe_ns_samples": [round(x, 4) for x in aft], "clock_probe_ns_before": [round(x, 4) for x in bef],
+                             "clock_probe_ns_fastest": fastest, "clock_probe_chain": 4096,
+                             "clock_probe_memtime_ticks_per_10ns": probes.memtime_per_tick,
+                             "clock_probe_device_time_us": [round(pat.get("r%d:before" % j, 0.0), 1) for j in range(len(us))],
+                             "launch_us_at_fastest_clock": [round(u_ * fastest / a_, 2) for u_, a_ in zip(us, aft)]})
+                for mode, res in ab.items():
+                    mu = [u_ for _, u_ in res]
+                    ma = [pns.get("%s%d:after" % (mode, j)) for j in range(len(res))]
+                    line["ab_" + mode] = {"launch_us_samples": [round(u_, 2) for u_ in mu], "launch_us_median": sorted(mu)[len(mu) // 2],
+                                          "launch_us_min": min(mu), "launch_us_max": max(mu),
+                                          "value_median": sorted(total_envs * args.steps / w_ for w_, _ in res)[len(res) // 2],
+                                          "clock_probe_ns_samples": [round(x, 4) for x in ma],
+                                          "launch_us_at_fastest_clock": [round(u_ * fastest / a_, 2) for u_, a_ in zip(mu, ma)]}
         if step_api:
             line["step_api"] = step_api
         if in_kernel:
@@ -817,6 +948,35 @@ def main():
             leg("config4_push", lambda: secondary_leg(envs, dev, "push", 32768, "external", args.precision, 5, 6, args.fence_steps))
         if not multi and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline(args.precision))
+        # the scalars a record that keeps only flat `config` values would otherwise lose
+        cfg = line["config"]
+        cfg["rccl_world_size"] = cfg["rccl_ranks_seen"]["world_size"]
+        cfg["rccl_backend"] = cfg["rccl_ranks_seen"]["backend"]
+        for k_ in ("value_median", "value_min", "value_max", "launch_us_median", "launch_us_min", "launch_us_max"):
+            if k_ in line:
+                cfg[k_] = line[k_]
+        for k_, leg_ in (("actor_f32", "config3_actor_f32"), ("actor_f16x3", "config3_actor_f16x3"), ("push", "config4_push")):
+            if isinstance(line.get(leg_), dict) and "us_per_step" in line[leg_]:
+                cfg[k_ + "_us_per_step"] = line[leg_]["us_per_step"]
+                cfg[k_ + "_env_steps_per_s"] = line[leg_]["value_kernel"]
+        for mode in ("device_restore", "busy_ahead"):
+            if "ab_" + mode in line:
+                for k_ in ("launch_us_median", "launch_us_min", "launch_us_max"):
+                    cfg["ab_%s_%s" % (mode, k_)] = line["ab_" + mode][k_]
+        if line.get("clock_probe_ns_samples"):
+            cfg["clock_probe_ns_min"] = min(line["clock_probe_ns_samples"])
+            cfg["clock_probe_ns_max"] = max(line["clock_probe_ns_samples"])
+            lf = line["launch_us_at_fastest_clock"]
+            cfg["launch_us_at_fastest_clock_min"], cfg["launch_us_at_fastest_clock_max"] = min(lf), max(lf)
+        if step_api:
+            cfg["step_api_us"] = step_api["avg_launch_us"]
+        if in_kernel:
+            cfg["in_kernel_policy_us_per_step"] = in_kernel["us_per_step"]
+        if isinstance(line.get("large_batch"), dict) and "us_per_step" in line["large_batch"]:
+            cfg["large_batch_env_steps_per_s"] = line["large_batch"]["value"]
+        if isinstance(line.get("cpu_baseline"), dict) and "value" in line["cpu_baseline"]:
+            cfg["cpu_env_steps_per_s"] = line["cpu_baseline"]["value"]
+            cfg["cpu_cores"] = line["cpu_baseline"]["cores"]
         print(json.dumps(line), flush=True)
     env.close()
     if multi:

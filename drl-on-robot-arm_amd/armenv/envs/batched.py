@@ -5,6 +5,7 @@
 and outputs are PyTorch-ROCm tensors on the env's device; PyTorch is used only for device memory and
 streams -- every number is produced by the HIP kernels behind the C ABI (include/armenv.h).
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -64,7 +65,8 @@ class BatchedArmEnv:
         self._terminal = None
         self._ik_updates = None
         self._diag = None
-        self._fixed_stream = None     # set by PipelinedEnv: this handle always launches on its own stream
+        self._fixed_stream = None     # set by PipelinedEnv: this handle always launches on its own stream ...
+        self._fixed_torch_stream = None   # ... and the same stream as a torch object (ordering against the caller's stream)
         self.action_space = Box(low=[-0.4, -0.4, -0.6], high=[0.4, 0.4, 0.3])       # rl_reach_env.py:87-90
         self.max_steps_one_episode = int(cfg.max_steps)
 
@@ -73,6 +75,21 @@ class BatchedArmEnv:
         if self._fixed_stream is not None:
             return self._fixed_stream
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @contextlib.contextmanager
+    def _ordered(self):
+        """For the calls that allocate their tensors here (get_state, episode_stats, fk, ik, set_state): with a fixed launch
+        stream the tensors belong to the CALLER's current stream, so the fixed stream first waits for everything the caller has
+        enqueued (a recycled block's last reader, the producer of the inputs) and the caller's stream then waits for the kernel
+        launched in between.  Without a fixed stream the launch stream IS the current stream and nothing is needed."""
+        fs = self._fixed_torch_stream
+        if fs is None:
+            yield
+            return
+        cur = torch.cuda.current_stream(self.device)
+        fs.wait_stream(cur)
+        yield
+        cur.wait_stream(fs)
 
     @property
     def kernel_name(self):
@@ -136,8 +153,10 @@ class BatchedArmEnv:
 
     def bind_step(self, action, stream=None):
         """Everything `step` does except the launch (argument checks, pointer and stream resolution): returns `launch()`, one
-        ctypes call into armenv_step on the stream current at bind time (or `stream`); outputs go to the tensors `step` returns."""
-        self._check_action(action)
+        ctypes call into armenv_step on the stream current at bind time (or `stream`); outputs go to the tensors `step` returns.
+        action None: the fused policy installed with set_policy() acts (as in `step`)."""
+        if action is not None:
+            self._check_action(action)
         fn, args = self._lib.armenv_step, (self._h, _ptr(action), _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
                                            _ptr(self._success), None, None, None, stream if stream is not None else self._stream())
 
@@ -171,8 +190,9 @@ class BatchedArmEnv:
             keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
             w = [actor_state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in keys]
             hidden = int(w[0].shape[0])
-        L.check(self._lib.armenv_set_policy(self._h, code, *[_ptr(t) for t in w], hidden, float(action_bound),
-                                            float(noise_sigma), float(noise_clip), self._stream()))
+        with self._ordered():
+            L.check(self._lib.armenv_set_policy(self._h, code, *[_ptr(t) for t in w], hidden, float(action_bound),
+                                                float(noise_sigma), float(noise_clip), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
         self._policy = kind
 
@@ -180,7 +200,8 @@ class BatchedArmEnv:
         """TD3_MLP.take_action without noise (algo/TD3/TD3_mlp.py:82-97) for states f32 [n, obs_dim]."""
         st = states.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, self.obs_dim)
         out = torch.empty((st.shape[0], 3), dtype=torch.float32, device=self.device)
-        L.check(self._lib.armenv_actor_forward(self._h, st.shape[0], _ptr(st), _ptr(out), self._stream()))
+        with self._ordered():
+            L.check(self._lib.armenv_actor_forward(self._h, st.shape[0], _ptr(st), _ptr(out), self._stream()))
         return out
 
     def rollout(self, steps, actions=None, out=None, want_actions=False, want_terminal_obs=False, want_ik_updates=False,
@@ -240,7 +261,8 @@ class BatchedArmEnv:
         n = q.shape[0]
         pos = torch.empty((n, 3), dtype=torch.float64, device=self.device)
         quat = torch.empty((n, 4), dtype=torch.float64, device=self.device)
-        L.check(self._lib.armenv_fk(self._h, n, _ptr(q), _ptr(pos), _ptr(quat), self._stream()))
+        with self._ordered():
+            L.check(self._lib.armenv_fk(self._h, n, _ptr(q), _ptr(pos), _ptr(quat), self._stream()))
         return pos, quat
 
     def ik(self, q, target_pos):
@@ -250,7 +272,8 @@ class BatchedArmEnv:
         n = q.shape[0]
         out = torch.empty_like(q)
         iters = torch.empty(n, dtype=torch.int32, device=self.device)
-        L.check(self._lib.armenv_ik(self._h, n, _ptr(q), _ptr(t), _ptr(out), _ptr(iters), self._stream()))
+        with self._ordered():
+            L.check(self._lib.armenv_ik(self._h, n, _ptr(q), _ptr(t), _ptr(out), _ptr(iters), self._stream()))
         return out, iters
 
     # ------------------------------------------------------------------ state exchange / stats
@@ -269,14 +292,17 @@ class BatchedArmEnv:
             st["aux"] = torch.empty((n, self.aux_dim), dtype=torch.float64, device=dev)
         else:
             st["goal"] = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        L.check(self._lib.armenv_get_state(self._h, _ptr(st["q"]), _ptr(st.get("goal")), _ptr(st["step"]),
-                                           _ptr(st["episode"]), _ptr(st["ep_return"]), _ptr(st.get("aux")), _ptr(st["trig"]),
-                                           self._stream()))
+        with self._ordered():
+            L.check(self._lib.armenv_get_state(self._h, _ptr(st["q"]), _ptr(st.get("goal")), _ptr(st["step"]),
+                                               _ptr(st["episode"]), _ptr(st["ep_return"]), _ptr(st.get("aux")), _ptr(st["trig"]),
+                                               self._stream()))
         return st
 
-    def set_state(self, q=None, goal=None, step=None, episode=None, ep_return=None, aux=None, trig=None):
+    def set_state(self, q=None, goal=None, step=None, episode=None, ep_return=None, aux=None, trig=None, sync=True):
         """Any subset of the fields of get_state().  q without trig: resetJointState semantics, the carried (cos q, sin q)
-        are re-derived from the new angles."""
+        are re-derived from the new angles.  sync=False: enqueue only (one device-to-device kernel on the launch stream, no host
+        round trip) -- for tensors that already have get_state()'s device, dtypes and layout and that the caller keeps alive
+        until the copy has run (a snapshot restored many times); anything that would need a temporary is refused."""
         dev = self.device
 
         def prep(x, dt, shape):
@@ -290,9 +316,16 @@ class BatchedArmEnv:
                                   prep(step, torch.int32, (n,)), prep(episode, torch.int32, (n,)),
                                   prep(ep_return, torch.float64, (n,)), prep(aux, torch.float64, (n, self.aux_dim)))
         t_ = prep(trig, torch.float64, (n, 14))
-        L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), _ptr(a_), _ptr(t_),
-                                           self._stream()))
-        torch.cuda.current_stream(dev).synchronize()   # temporaries above must outlive the copy
+        if not sync:
+            for given, used in ((q, q_), (goal, g_), (step, s_), (episode, e_), (ep_return, r_), (aux, a_), (trig, t_)):
+                if given is not None and (not torch.is_tensor(given) or given.data_ptr() != used.data_ptr()):
+                    raise ValueError("set_state(sync=False): every field must already be a contiguous tensor of get_state()'s dtype on the env's device")
+        with self._ordered():
+            L.check(self._lib.armenv_set_state(self._h, _ptr(q_), _ptr(g_), _ptr(s_), _ptr(e_), _ptr(r_), _ptr(a_), _ptr(t_),
+                                               self._stream()))
+        if sync:
+            # temporaries above must outlive the copy: the current stream (which, with a fixed launch stream, now waits for it)
+            torch.cuda.current_stream(dev).synchronize()
 
     def episode_stats(self):
         """(return, length, success) of each env's most recently finished episode."""
@@ -300,14 +333,16 @@ class BatchedArmEnv:
         ret = torch.empty(n, dtype=torch.float64, device=dev)
         ln = torch.empty(n, dtype=torch.int32, device=dev)
         su = torch.empty(n, dtype=torch.uint8, device=dev)
-        L.check(self._lib.armenv_episode_stats(self._h, _ptr(ret), _ptr(ln), _ptr(su), self._stream()))
+        with self._ordered():
+            L.check(self._lib.armenv_episode_stats(self._h, _ptr(ret), _ptr(ln), _ptr(su), self._stream()))
         return ret, ln, su
 
     def summary(self):
         """Device-side logging summary, no host sync: dict of 0-dim tensors (mean / max distance to goal, mean return,
         length and success rate of the envs' last finished episodes)."""
         out = torch.empty(8, dtype=torch.float64, device=self.device)
-        L.check(self._lib.armenv_summary(self._h, _ptr(out), self._stream()))
+        with self._ordered():
+            L.check(self._lib.armenv_summary(self._h, _ptr(out), self._stream()))
         n = out[5]
         return dict(mean_distance=out[0] / n, max_distance=out[1], mean_last_return=out[2] / n, mean_last_len=out[3] / n,
                     last_success_rate=out[4] / n, raw=out)

@@ -45,6 +45,7 @@ class PipelinedEnv:
         for e, (lo, hi), s in zip(self.envs, self.bounds, self.streams):
             e._obs, e._reward, e._done, e._success = self._obs[lo:hi], self._reward[lo:hi], self._done[lo:hi], self._success[lo:hi]
             e._fixed_stream = C.c_void_p(s.cuda_stream)           # BatchedArmEnv._stream(): this part always launches here
+            e._fixed_torch_stream = s                             # BatchedArmEnv._ordered(): allocating calls order against the caller
         self._fork = torch.cuda.Event()
         self._join = [torch.cuda.Event() for _ in range(self.parts)]
 
@@ -88,8 +89,9 @@ class PipelinedEnv:
 
     def bind_steps(self, actions):
         """actions f32 [K, N, 3], complete before the first call: returns a list of K closures, closure t = step t of every part
-        (`parts` bare C calls, no stream or event traffic).  Outputs of the last executed step are in the [N, ...] tensors after
-        join().  For open-loop drivers and for capturing into a hipGraph."""
+        (`parts` bare C calls on the parts' own streams, no stream or event traffic).  Outputs of the last executed step are in the
+        [N, ...] tensors after join().  For open-loop drivers.  (Not for hipGraph capture: the closures launch on `parts` streams the
+        capturing stream knows nothing about; capture a single handle's `bind_step` closures instead, as bench.py's step_api leg does.)"""
         fns = []
         for t in range(actions.shape[0]):
             calls = []
@@ -122,9 +124,8 @@ class PipelinedEnv:
 
     # ------------------------------------------------------------------ state / stats over all parts
     def get_state(self):
-        self.join()
+        # every part's get_state orders its own stream against the caller's on both sides (BatchedArmEnv._ordered)
         sts = [e.get_state() for e in self.envs]
-        self.join()
         return {k: torch.cat([s[k] for s in sts], dim=0) for k in sts[0]}
 
     def counters(self):
@@ -135,9 +136,7 @@ class PipelinedEnv:
         return tot
 
     def episode_stats(self):
-        self.join()
         parts = [e.episode_stats() for e in self.envs]
-        self.join()
         return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
     def close(self):

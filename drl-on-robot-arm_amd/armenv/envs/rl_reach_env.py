@@ -88,9 +88,11 @@ class RLReachEnv:
 
     def step(self, action):
         """:219-319 -> (np.float32[6], float reward, bool done, bool is_success).  One armenv_step launch.  The reward buffer of the C
-        ABI is f32, the reference returns a Python float computed in f64: position, distance and reward are taken from the step's
-        own f64 diagnostics (armenv_step diag_dev) -- the very numbers the kernel derived done / success from, so
-        `self.distance < reach_dis` and `is_success` can never disagree."""
+        ABI is f32, the reference returns a Python float computed in f64: position and reward are taken from the step's own f64
+        diagnostics (armenv_step diag_dev) -- reward, done and is_success all come from the kernel's one f64 distance.
+        `self.distance` (an attribute the reference sets at :281, read by nobody) is recomputed here from that position as the
+        reference's plain sum of squares; the kernel's distance is FMA-contracted, so the two can differ in the last place and
+        `self.distance < reach_dis` may disagree with is_success for a distance within one ulp of the threshold."""
         self._sync_opt()
         a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 3), dtype=torch.float32).to(self._eng.device)
         obs, reward, done, success = self._eng.step(a, want_diag=True)

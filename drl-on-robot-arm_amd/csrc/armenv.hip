@@ -133,8 +133,34 @@ static int issue_probe(int device, int waves_per_simd, double *ns_out) {
   return ARMENV_OK;
 }
 
+// armenv_probe_clock: ONE wave runs a fixed dependent chain of CLOCK_PROBE_CHAIN v_fma_f32 (its duration in shader cycles does not
+// depend on anything but the chain) between two readings of the constant-rate counter (s_memrealtime, 100 MHz) and of s_memtime.
+// out[0] = chain duration in 10 ns ticks (inversely proportional to the shader clock at that moment), out[1] = the same in
+// s_memtime ticks, out[2] = the 100 MHz counter at the start (places the sample on the device's own time line), out[3] = chain length.
+constexpr int CLOCK_PROBE_CHAIN = 4096;
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, float a, float b) {
+  float x = a * (float)threadIdx.x;
+  asm volatile("" : "+v"(x), "+v"(a), "+v"(b));
+  const unsigned long long w0 = wall_clock64(), c0 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int i = 0; i < CLOCK_PROBE_CHAIN / 128; ++i)
+    static_for<0, 128>([&](auto) { x = __builtin_fmaf(x, a, b); asm volatile("" : "+v"(x)); });
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) { out[0] = w1 - w0; out[1] = c1 - c0; out[2] = w0; out[3] = (unsigned long long)CLOCK_PROBE_CHAIN + (x == 12345.f); }
+}
+
 extern "C" {
 
+int armenv_probe_clock(int32_t device, uint64_t *out_dev, void *stream) {
+  DeviceGuard guard_(device);
+  if (!guard_.ok) return fail(ARMENV_ENODEV, "armenv_probe_clock: hipSetDevice(%d) failed", (int)device);
+  if (!out_dev) return fail(ARMENV_EINVAL, "armenv_probe_clock: out_dev is NULL");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<unsigned long long *>(out_dev), 0.999f, 1e-3f);
+  HIP_TRY(hipGetLastError());
+  return ARMENV_OK;
+}
 
 int32_t armenv_abi_version(void) { return ARMENV_ABI_VERSION; }
 const char *armenv_last_error(void) { return g_err.c_str(); }

@@ -1993,6 +1993,19 @@ def test_bench_line_contract():
     assert d["regions"] == 16 and len(d["launch_us_samples"]) == 16 and d["value_min"] <= d["value_median"] <= d["value_max"]
     assert d["value_min"] <= d["value"] <= d["value_max"] and d["launch_us_samples"][0] == pytest.approx(ro["avg_launch_us"], abs=0.01)
     assert d["launch_us_max"] < 1.6 * d["launch_us_min"], d["launch_us_samples"]      # sanity, not a performance claim
+    # clock probes around every region (ns per chained v_fma_f32 of one probe wave: 4-8 cycles at 1.4-2.5 GHz), and the same region
+    # under the two other regimes (state restored on the device / behind 5 ms of other work)
+    assert len(d["clock_probe_ns_samples"]) == 16 and all(1.0 < x < 8.0 for x in d["clock_probe_ns_samples"] + d["clock_probe_ns_before"])
+    assert len(d["launch_us_at_fastest_clock"]) == 16 and d["clock_probe_ns_fastest"] <= min(d["clock_probe_ns_samples"])
+    for mode in ("ab_device_restore", "ab_busy_ahead"):
+        assert len(d[mode]["launch_us_samples"]) == 8 and len(d[mode]["clock_probe_ns_samples"]) == 8
+        assert d[mode]["launch_us_max"] < 1.6 * d["launch_us_min"] and d[mode]["launch_us_min"] > 0.7 * d["launch_us_min"], d[mode]
+    cf = d["config"]      # the flat copies
+    assert cf["rccl_world_size"] == 1 and cf["value_median"] == d["value_median"] and cf["launch_us_median"] == d["launch_us_median"]
+    assert cf["actor_f32_us_per_step"] == d["config3_actor_f32"]["us_per_step"] and cf["actor_f16x3_us_per_step"] == d["config3_actor_f16x3"]["us_per_step"]
+    assert cf["push_us_per_step"] == d["config4_push"]["us_per_step"] and cf["step_api_us"] == d["step_api"]["avg_launch_us"]
+    assert all(not isinstance(cf[k], (dict, list)) for k in ("rccl_backend", "ab_device_restore_launch_us_median", "ab_busy_ahead_launch_us_median",
+                                                             "clock_probe_ns_min", "cpu_env_steps_per_s", "large_batch_env_steps_per_s"))
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["threads_1"]["cores"] == 1 and cb["threads_1"]["value"] > 5e4 and cb["value"] >= 0.8 * cb["threads_1"]["value"]
     assert cb["cores"] <= cb["host"]["affinity_cpus"]
@@ -2068,6 +2081,36 @@ def test_bench_driver_shape_with_gathers_every_region():
     assert d["value_steps"] >= d["value"] and len(d["config"]["per_rank"]["wall_steps_ms"]) == 2
     assert max(d["config"]["per_rank"]["wall_steps_ms"]) <= max(d["config"]["per_rank"]["wall_ms"])
     assert d["config"]["rccl_ranks_seen"] == {"world_size": 2, "backend": "gloo"}
+
+
+def test_bench_plain_python_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with NO launcher around it and no RANK / WORLD_SIZE in the environment -- the way the round
+    driver types the command: bench.py starts the two ranks itself (torch.distributed.run, a free port on
+    127.0.0.1), relays rank 0's ONE line and the job's exit code.  The scalars of the multi-rank record sit in `config` as flat
+    keys (a record that keeps only flat values loses nothing)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--envs-per-gpu", "8192"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["rccl_world_size"] == 2 and d["config"]["total_envs"] == 16384 and d["config"]["gathers_in_timed_region"] == 1
+    assert d["config"]["rccl_backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert abs(d["value"] - 16384 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+    # a failing job's exit code comes through as well (an unknown flag makes every rank exit with 2)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")]
+    # and WORLD_SIZE that contradicts --gpus is refused instead of silently running another job
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
 def test_bench_eight_ranks_on_one_gpu_config5_control_flow(envs):

@@ -261,3 +261,25 @@ def test_ddpg_and_datd3_take_action_match_reference_golden():
     assert clear.sum() >= 250 and 100 < g["picked_actor"][clear].sum() < 156
     assert np.abs(a.numpy() - g["actions"])[clear].max() < 1e-6
     assert np.array_equal((q1 < q2).numpy()[clear], g["picked_actor"][clear].astype(bool))
+
+
+def test_bench_launcher_relays_exit_code_and_refuses_contradictions():
+    """`python bench.py --gpus 2` without WORLD_SIZE starts its own two ranks (torch.distributed.run on a free 127.0.0.1 port) and
+    relays their exit code -- here, without a GPU, both ranks fail, and the launcher must come back non-zero without a JSON line
+    and without leaving a rank behind; WORLD_SIZE that contradicts --gpus is refused by name.  (The successful two-rank run is a
+    `-m gpu` test: test_bench_plain_python_launches_its_own_ranks.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "--gpus 2" in r.stderr
+    import torch
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs-per-gpu", "64"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode not in (0, 124), r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr      # the ranks were really started
