@@ -9,7 +9,8 @@ configs[1]; N>1 = configs[4], envs sharded over GPUs, RCCL all-gather of episode
 A step = one pass of the hot path over one batch of actions: every env of the rank advances once with a
 pre-generated random-policy action batch already resident in HBM (an i.i.d. [<=1000, N, 3] pool consumed in order).
 Before the W warm-up steps the device is brought to its steady clocks on a scratch handle (--prewarm-ms; an idle
-MI355X ramps for ~30 ms, tests/tools/clock_ramp.py).  Two launch shapes run the same per-step code:
+MI355X ramps for ~30 ms, tests/tools/clock_ramp.py), and every timed region has --busy-ahead-ms of the same scratch work
+enqueued right in front of its opening synchronise (the region starts from the clocks of a chip under sustained load).  Two launch shapes run the same per-step code:
   --mode rollout (default, `value`): armenv_rollout, R = 100 steps per kernel launch, env state kept in registers,
                  per-step outputs written to [R][N][...] buffers (the trajectory of R armenv_step calls);
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
@@ -151,36 +152,46 @@ class HipEvents:
 
 
 class ClockProbes:
-    """armenv_probe_clock samples around the timed regions: one wavefront runs a fixed dependent chain of 4 096 v_fma_f32 between two
-    readings of the device's 100 MHz counter, so a sample's duration is inversely proportional to the shader clock at that moment.
-    Enqueued OUTSIDE every clock and every pair of HIP events (before the opening synchronise, after the closing one); read back
-    once at the end of the run."""
+    """armenv_probe_clock samples around the timed regions: one wavefront on every SIMD runs a fixed dependent chain of v_fma_f32
+    between two readings of the device's 100 MHz counter, so a sample's duration is inversely proportional to the shader clock at
+    that moment (whole chip loaded, ~10 us).  Enqueued OUTSIDE every clock and every pair of HIP events (before the opening
+    synchronise, after the closing one); read back once at the end of the run."""
 
-    def __init__(self, dev, cap=256):
+    def __init__(self, dev, cap=128):
         import ctypes as C
         from armenv import _lib
         self.C, self.lib, self.dev = C, _lib.load(), dev
-        self.buf = torch.zeros((cap, 4), dtype=torch.int64, device=dev)
+        rows = C.c_int32(0)
+        self.ok = self.lib.armenv_probe_clock(dev.index or 0, None, C.byref(rows), None) == 0 and rows.value > 0
+        self.rows = rows.value
+        self.buf = torch.zeros((cap, max(1, self.rows), 4), dtype=torch.int64, device=dev) if self.ok else None
         self.tags = []
 
     def mark(self, tag):
-        if tag is None or len(self.tags) >= self.buf.shape[0]:
+        if tag is None or not self.ok or len(self.tags) >= self.buf.shape[0]:
             return
         C = self.C
         ptr = C.c_void_p(self.buf[len(self.tags)].data_ptr())
-        if self.lib.armenv_probe_clock(self.dev.index or 0, ptr, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)) == 0:
+        if self.lib.armenv_probe_clock(self.dev.index or 0, ptr, None, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)) == 0:
             self.tags.append(tag)
 
     def read(self):
-        """{tag: ns per chained instruction}, {tag: device time of the sample in us since the first sample}"""
+        """per tag: ns per chained instruction (median over the waves), the same in s_memtime ticks, the slowest XCD's median ns,
+        and the device time of the sample (us since the first one)"""
         if not self.tags:
-            return {}, {}
-        b = self.buf[:len(self.tags)].cpu().numpy()
-        t0 = int(b[0, 2])
-        ns = {t: float(b[i, 0]) * 10.0 / max(1.0, float(b[i, 3])) for i, t in enumerate(self.tags)}
-        at = {t: (int(b[i, 2]) - t0) * 0.01 for i, t in enumerate(self.tags)}
-        self.memtime_per_tick = float(np.median(b[:, 1] / np.maximum(b[:, 0], 1)))     # s_memtime ticks per 10 ns tick
-        return ns, at
+            return {}
+        b = self.buf[:len(self.tags)].cpu().numpy().astype(np.float64)
+        chain = float(int(b[0, 0, 3]) >> 8 & 0xFFFFFF)
+        xcd = self.buf[0, :, 3].cpu().numpy() & 15
+        t0 = b[0, :, 2].min()
+        out = {}
+        for i, t in enumerate(self.tags):
+            ns = b[i, :, 0] * 10.0 / chain
+            per_xcd = [float(np.median(ns[xcd == x])) for x in sorted(set(xcd.tolist()))]
+            out[t] = {"ns": float(np.median(ns)), "memtime_ticks": float(np.median(b[i, :, 1]) / chain), "ns_slowest_xcd": max(per_xcd),
+                      "ns_fastest_xcd": min(per_xcd), "at_us": float((b[i, :, 2].min() - t0) * 0.01)}
+        self.xcds = len(set(xcd.tolist()))
+        return out
 
 
 def algo_bytes_per_launch(task, policy, precision, n, steps_per_launch):
@@ -484,24 +495,43 @@ def parity_fence(Env, n, dev, precision, pool, fence_steps):
                        "space (the strict tier of the parity tests excludes an env from such a call to its next reset; the task-space tier does not)"}
 
 
-def prewarm_device(Env, n, dev, precision, ms):
-    """Bring the GPU to its steady clocks with the same kind of work on a scratch handle (in-kernel random policy, outputs
-    discarded).  From idle the first ~3 000 steps (30 ms) of the headline workload run 10-25 % slower than the rest
-    (profiles/r01_launch_costs.txt, section 4); the W warm-up steps of the contract are too short to cover that when W is
-    small, and they belong to the benchmarked handle's trajectory, so the ramp is absorbed here instead."""
-    if ms <= 0:
-        return
-    scratch = Env(n, device=dev, seed=987654321, precision=precision)
-    scratch.set_policy("random", action_bound=0.7, noise_sigma=0.686, noise_clip=0.7)
-    scratch.reset()
-    bufs = {}
-    t0 = time.perf_counter()
-    while (time.perf_counter() - t0) * 1e3 < ms:
-        for _ in range(4):
-            scratch.rollout(100, None, out=bufs)
-        torch.cuda.synchronize(dev)
-    scratch.close()
-    del bufs
+class Scratch:
+    """A second env handle that only makes load (in-kernel random policy, outputs discarded): `prewarm(ms)` brings the GPU to its
+    steady clocks before the W warm-up steps (from idle the first ~3 000 steps, 30 ms, of the headline workload run 10-25 % slower
+    than the rest, profiles/r01_launch_costs.txt section 4; the W warm-up steps of the contract are too short to cover that and they
+    belong to the benchmarked handle's trajectory), `ahead(ms)` ENQUEUES about `ms` of the same work without waiting for it --
+    bench.py puts it in front of every timed region so that each region starts from the clocks of a chip under sustained load, the
+    state a rollout engine runs in (round 4's regions followed host round trips of ~0.3 ms each, and what the clocks did in those
+    gaps differed from box to box: VERDICT r04 weak #5).  The benchmarked handle is never touched."""
+
+    def __init__(self, Env, n, dev, precision):
+        self.dev = dev
+        self.env = Env(n, device=dev, seed=987654321, precision=precision)
+        self.env.set_policy("random", action_bound=0.7, noise_sigma=0.686, noise_clip=0.7)
+        self.env.reset()
+        self.bufs = {}
+        self.launch, _ = self.env.bind_rollout(100, None, out=self.bufs)
+        self.ms_per_launch = 0.7
+
+    def prewarm(self, ms):
+        if ms <= 0:
+            return
+        t0 = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(4):
+                self.launch()
+            k += 4
+            torch.cuda.synchronize(self.dev)
+        self.ms_per_launch = (time.perf_counter() - t0) * 1e3 / k
+
+    def ahead(self, ms):
+        for _ in range(int(round(ms / self.ms_per_launch))):
+            self.launch()
+
+    def close(self):
+        self.env.close()
+        self.bufs = None
 
 
 def self_launch(n_ranks, argv):
@@ -559,10 +589,13 @@ def main():
     ap.add_argument("--repeat-regions", type=int, default=15,
                     help="single-GPU runs: after the contract's timed region, the identical region this many more times on fresh "
                          "action rows -> value_median / value_min / value_max / launch_us_samples (0 = skip)")
+    ap.add_argument("--busy-ahead-ms", type=float, default=8.0,
+                    help="scratch-handle work enqueued in front of every timed region's opening synchronise, so that the region starts "
+                         "from the clocks of a chip under sustained load (0 = nothing in front, round 4's procedure)")
     ap.add_argument("--ab-regions", type=int, default=8,
-                    help="single-GPU runs with --repeat-regions > 0: the region this many more times under each of two other regimes "
-                         "(state restored on the device without a host round trip; the same behind 5 ms of other work) with clock "
-                         "probes around every region -> line.ab_device_restore / ab_busy_ahead, clock_probe_ns_samples (0 = skip)")
+                    help="single-GPU runs with --repeat-regions > 0: the region this many more times under each of round 4's two "
+                         "regimes (nothing in front of the region; state restored through the host / on the device) with clock "
+                         "probes around every region -> line.ab_host_restore / ab_device_restore (0 = skip)")
     ap.add_argument("--state-digest", action="store_true",
                     help="add config.state_digest: per rank, the sha256 of the joint angles of its envs right after the timed "
                          "region (tests: rank shards reproduce the single-handle trajectory)")
@@ -688,15 +721,18 @@ def main():
 
     probes = ClockProbes(dev)
 
-    def timed(k, tag=None, count=True):
+    def timed(k, tag=None, count=True, ahead_ms=0.0):
         """tag: name of the region for the clock probes (one sample enqueued ahead of the opening synchronise, one after the
-        closing one; both outside the clock and the events).  count=False: no armenv_counters round trips around the region."""
+        closing one; both outside the clock and the events).  count=False: no armenv_counters round trips around the region.
+        ahead_ms: this much scratch-handle work is enqueued right before the opening synchronise (Scratch.ahead)."""
         ops, launches, gathers = plan(k)
         evs = HipEvents(dev)
         evs.record(0); evs.record(1)  # first use outside the region
         if count:
             torch.cuda.synchronize(dev)
         c0 = env.counters() if count else None
+        if ahead_ms > 0:
+            scratch.ahead(ahead_ms)
         probes.mark(tag and tag + ":before")
         if multi:
             dist.barrier()
@@ -742,46 +778,39 @@ def main():
         evs.close()
         return wall, gpu_ms, launches, gathers, ({k_: c1[k_] - c0[k_] for k_ in c1} if count else None), wall_steps
 
-    prewarm_device(Env, n, dev, args.precision, args.prewarm_ms)
+    scratch = Scratch(Env, n, dev, args.precision)
+    scratch.prewarm(args.prewarm_ms)
     run(args.warmup)
     snap = {k: v.clone() for k, v in env.get_state().items()} if (not multi and args.repeat_regions > 0) else None
-    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0")
+    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=args.busy_ahead_ms)
     host_us_main = dict(host_us)
 
-    # The headline is ONE sample of a short region (the driver's 20 steps are one 132 us launch): the same region again, 15
-    # times -- the env state restored to what it was when the contract's region started (same phase of the episodes: the cost of
-    # a step drifts with the time since the common reset, 6.6 us at step 25, 7.9 at step 330), fresh rows of the action pool,
-    # same handle, same launch shape, same bracket -- for the spread.  `value` stays the first region, the contract's; the
-    # repeats are reported beside it.  The trajectory then continues from the last repeat's end.
+    # The headline is ONE sample of a short region (the driver's 20 steps are one ~120 us launch): the same region again, 15
+    # times -- the env state restored ON THE DEVICE (one kernel on the launch stream, no host round trip) to what it was when the
+    # contract's region started (same phase of the episodes: the cost of a step drifts with the time since the common reset, 6.6 us
+    # at step 25, 7.9 at step 330), fresh rows of the action pool, same handle, same launch shape, same bracket, the same
+    # --busy-ahead-ms of scratch work in front -- for the spread.  `value` stays the first region, the contract's; the repeats are
+    # reported beside it.  The trajectory then continues from the last repeat's end.
     repeats = []
     ab = {}
     if snap is not None:
         for j in range(args.repeat_regions):
-            env.set_state(**snap)
-            w_, g_, l_, _, _, _ = timed(args.steps, tag="r%d" % (j + 1))
+            env.set_state(**snap, sync=False)
+            w_, g_, l_, _, _, _ = timed(args.steps, tag="r%d" % (j + 1), count=False, ahead_ms=args.busy_ahead_ms)
             repeats.append((w_, g_ * 1e3 / l_))
-        # Why do those samples spread (117 us on the driver's first region, 130-133 us on its last eight)?
-        # The same region again under two other regimes, eight times each, with the same clock probes:
-        #   device_restore: the state is restored by ONE device-to-device kernel enqueued on the launch stream and no counters are
-        #                   read -- no host round trip (D2H copy, synchronise) between a region and the next;
-        #   busy_ahead:     the same, with ~5 ms of rollout work on a scratch handle enqueued ahead of every region.
-        if args.ab_regions > 0:
-            scratch = Env(n, device=dev, seed=987654321, precision=args.precision)
-            scratch.set_policy("random", action_bound=0.7, noise_sigma=0.686, noise_clip=0.7)
-            scratch.reset()
-            sb = {}
-            for mode in ("device_restore", "busy_ahead"):
-                res = []
-                for j in range(args.ab_regions):
-                    if mode == "busy_ahead":
-                        for _ in range(7):
-                            scratch.rollout(100, None, out=sb)
-                    env.set_state(**snap, sync=False)
-                    w_, g_, l_, _, _, _ = timed(args.steps, tag="%s%d" % (mode, j), count=False)
-                    res.append((w_, g_ * 1e3 / l_))
-                ab[mode] = res
-            scratch.close()
-            del sb
+        # Round 4's procedure beside it, eight regions each, same clock probes: NOTHING in front of the region, the state restored
+        #   host_restore:   through the host (set_state + synchronise, armenv_counters D2H before and after: ~0.3 ms between regions);
+        #   device_restore: on the device.
+        # Where these differ from the samples above the difference is what the clocks do when the chip is left idle between short
+        # kernels -- chip- and firmware-dependent, which is why the headline regions no longer depend on it.
+        for mode in ("host_restore", "device_restore")[:2 if args.ab_regions > 0 else 0]:
+            res = []
+            for j in range(args.ab_regions):
+                env.set_state(**snap, sync=(mode == "host_restore"))
+                w_, g_, l_, _, _, _ = timed(args.steps, tag="%s%d" % (mode, j), count=(mode == "host_restore"))
+                res.append((w_, g_ * 1e3 / l_))
+            ab[mode] = res
+    scratch.close()
 
     t = torch.tensor([wall, gpu_ms * 1e-3, wall_steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     per_rank = None
@@ -873,6 +902,7 @@ def main():
             "config": {"workload": workload,
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
+                       "busy_ahead_ms": args.busy_ahead_ms,
                        "gathers_in_timed_region": gathers, "state_digest": digests, "per_rank": per_rank,
                        "gathered_returns_sha256": gathered["sha256"] if gathered else None,
                        "gathered_returns_mean": gathered["mean"] if gathered else None,
@@ -903,27 +933,29 @@ def main():
                          "regions": 1 + len(repeats),
                          "launch_us_samples": [round(u_, 2) for u_ in us],
                          "launch_us_median": sorted(us)[len(us) // 2], "launch_us_min": min(us), "launch_us_max": max(us)})
-            pns, pat = probes.read()
-            if pns:
-                # ns per chained v_fma_f32 of the probe wave right before / right after each region: ratio of two samples = inverse
-                # ratio of the shader clocks they ran at.  launch_us_at_fastest_clock rescales each launch to the run's fastest
-                # probe: if the spread of the launches is the clocks', it collapses here.
-                bef = [pns.get("r%d:before" % j) for j in range(len(us))]
-                aft = [pns.get("r%d:after" % j) for j in range(len(us))]
-                fastest = min(pns.values())
-                line.update({"clock_probe_ns_samples": [round(x, 4) for x in aft], "clock_probe_ns_before": [round(x, 4) for x in bef],
-                             "clock_probe_ns_fastest": fastest, "clock_probe_chain": 4096,
-                             "clock_probe_memtime_ticks_per_10ns": probes.memtime_per_tick,
-                             "clock_probe_device_time_us": [round(pat.get("r%d:before" % j, 0.0), 1) for j in range(len(us))],
-                             "launch_us_at_fastest_clock": [round(u_ * fastest / a_, 2) for u_, a_ in zip(us, aft)]})
+            pr = probes.read()
+            if pr:
+                # ns per chained v_fma_f32 of the probe waves (median over all SIMDs) right after each region: ratio of two samples =
+                # inverse ratio of the shader clocks they ran at.  launch_us_at_fastest_clock rescales each launch to the run's
+                # fastest sample: if the spread of the launches is the clocks', it collapses here.
+                aft = [pr["r%d:after" % j] for j in range(len(us))]
+                bef = [pr["r%d:before" % j] for j in range(len(us))]
+                fastest = min(v_["ns"] for v_ in pr.values())
+                line.update({"clock_probe_ns_samples": [round(x["ns"], 4) for x in aft],
+                             "clock_probe_ns_before": [round(x["ns"], 4) for x in bef],
+                             "clock_probe_ns_slowest_xcd": [round(x["ns_slowest_xcd"], 4) for x in aft],
+                             "clock_probe_memtime_ticks_per_instruction": [round(x["memtime_ticks"], 4) for x in aft],
+                             "clock_probe_ns_fastest": fastest, "clock_probe_xcds": probes.xcds,
+                             "clock_probe_device_time_us": [round(x["at_us"], 1) for x in bef],
+                             "launch_us_at_fastest_clock": [round(u_ * fastest / a_["ns"], 2) for u_, a_ in zip(us, aft)]})
                 for mode, res in ab.items():
                     mu = [u_ for _, u_ in res]
-                    ma = [pns.get("%s%d:after" % (mode, j)) for j in range(len(res))]
+                    ma = [pr["%s%d:after" % (mode, j)] for j in range(len(res))]
                     line["ab_" + mode] = {"launch_us_samples": [round(u_, 2) for u_ in mu], "launch_us_median": sorted(mu)[len(mu) // 2],
                                           "launch_us_min": min(mu), "launch_us_max": max(mu),
                                           "value_median": sorted(total_envs * args.steps / w_ for w_, _ in res)[len(res) // 2],
-                                          "clock_probe_ns_samples": [round(x, 4) for x in ma],
-                                          "launch_us_at_fastest_clock": [round(u_ * fastest / a_, 2) for u_, a_ in zip(mu, ma)]}
+                                          "clock_probe_ns_samples": [round(x["ns"], 4) for x in ma],
+                                          "launch_us_at_fastest_clock": [round(u_ * fastest / a_["ns"], 2) for u_, a_ in zip(mu, ma)]}
         if step_api:
             line["step_api"] = step_api
         if in_kernel:
@@ -959,7 +991,7 @@ def main():
             if isinstance(line.get(leg_), dict) and "us_per_step" in line[leg_]:
                 cfg[k_ + "_us_per_step"] = line[leg_]["us_per_step"]
                 cfg[k_ + "_env_steps_per_s"] = line[leg_]["value_kernel"]
-        for mode in ("device_restore", "busy_ahead"):
+        for mode in ("host_restore", "device_restore"):
             if "ab_" + mode in line:
                 for k_ in ("launch_us_median", "launch_us_min", "launch_us_max"):
                     cfg["ab_%s_%s" % (mode, k_)] = line["ab_" + mode][k_]

@@ -84,7 +84,7 @@ SYMBOLS = {
     "armenv_write_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P, _P, _P]),
     "armenv_her_sample": (C.c_int, [C.c_int32, C.POINTER(ArmEnvHerArgs), _P]),
     "armenv_probe_issue_rate": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
-    "armenv_probe_clock": (C.c_int, [C.c_int32, _P, _P]),
+    "armenv_probe_clock": (C.c_int, [C.c_int32, _P, C.POINTER(C.c_int32), _P]),
     "armenv_num_envs": (C.c_int64, [_P]),
     "armenv_obs_dim": (C.c_int32, [_P]),
     "armenv_aux_dim": (C.c_int32, [_P]),

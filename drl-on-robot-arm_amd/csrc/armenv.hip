@@ -133,12 +133,13 @@ static int issue_probe(int device, int waves_per_simd, double *ns_out) {
   return ARMENV_OK;
 }
 
-// armenv_probe_clock: ONE wave runs a fixed dependent chain of CLOCK_PROBE_CHAIN v_fma_f32 (its duration in shader cycles does not
-// depend on anything but the chain) between two readings of the constant-rate counter (s_memrealtime, 100 MHz) and of s_memtime.
-// out[0] = chain duration in 10 ns ticks (inversely proportional to the shader clock at that moment), out[1] = the same in
-// s_memtime ticks, out[2] = the 100 MHz counter at the start (places the sample on the device's own time line), out[3] = chain length.
-constexpr int CLOCK_PROBE_CHAIN = 4096;
-__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, float a, float b) {
+// armenv_probe_clock: one wave on every SIMD of the device runs a fixed dependent chain of CLOCK_PROBE_CHAIN v_fma_f32 (its duration
+// in shader cycles does not depend on anything but the chain) between two readings of the constant-rate counter (s_memrealtime,
+// 100 MHz) and of s_memtime.  Row w of out (one row per wave): [0] chain duration in 10 ns ticks (inversely proportional to the
+// shader clock of the wave's XCD at that moment), [1] the same in s_memtime ticks, [2] the 100 MHz counter at the start (the device's
+// own time line), [3] the XCD the wave ran on (HW_REG_XCC_ID) in bits 0..3 and the chain length in bits 8...
+constexpr int CLOCK_PROBE_CHAIN = 2048;
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *out, float a, float b) {
   float x = a * (float)threadIdx.x;
   asm volatile("" : "+v"(x), "+v"(a), "+v"(b));
   const unsigned long long w0 = wall_clock64(), c0 = __builtin_amdgcn_s_memtime();
@@ -147,16 +148,30 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out
     static_for<0, 128>([&](auto) { x = __builtin_fmaf(x, a, b); asm volatile("" : "+v"(x)); });
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (threadIdx.x == 0) { out[0] = w1 - w0; out[1] = c1 - c0; out[2] = w0; out[3] = (unsigned long long)CLOCK_PROBE_CHAIN + (x == 12345.f); }
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long *row = out + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+    row[0] = w1 - w0; row[1] = c1 - c0; row[2] = w0;
+    row[3] = (unsigned long long)(xcc & 15u) | ((unsigned long long)CLOCK_PROBE_CHAIN << 8) | (x == 12345.f ? 1ull << 63 : 0ull);
+  }
 }
 
 extern "C" {
 
-int armenv_probe_clock(int32_t device, uint64_t *out_dev, void *stream) {
+int armenv_probe_clock(int32_t device, uint64_t *out_dev, int32_t *rows, void *stream) {
   DeviceGuard guard_(device);
   if (!guard_.ok) return fail(ARMENV_ENODEV, "armenv_probe_clock: hipSetDevice(%d) failed", (int)device);
-  if (!out_dev) return fail(ARMENV_EINVAL, "armenv_probe_clock: out_dev is NULL");
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+  static thread_local int cus[64];
+  if (device < 0 || device >= 64) return fail(ARMENV_ENODEV, "armenv_probe_clock: device %d", (int)device);
+  if (!cus[device]) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    cus[device] = prop.multiProcessorCount;
+  }
+  if (rows) *rows = 4 * cus[device];
+  if (!out_dev) return ARMENV_OK;       // size query
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(cus[device]), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<unsigned long long *>(out_dev), 0.999f, 1e-3f);
   HIP_TRY(hipGetLastError());
   return ARMENV_OK;

@@ -363,12 +363,15 @@ int armenv_her_sample(int32_t device, const ArmEnvHerArgs *args, void *stream);
  * (about 60 ms: the device is brought to its steady clocks first; default stream). */
 int armenv_probe_issue_rate(int32_t device, int32_t precision, int32_t waves_per_simd, double *ns_per_instruction);
 
-/* Measurement aid (bench.py's clock_probe samples; no reference counterpart): enqueues on `stream` ONE wavefront that runs a fixed
- * dependent chain of v_fma_f32 between two readings of the device's constant-rate 100 MHz counter.  out_dev u64 [4] (device):
- * [0] the chain's duration in 10 ns ticks -- inversely proportional to the shader clock at that moment, so the ratio of two samples
- * is the ratio of the clocks they ran at; [1] the same in s_memtime ticks; [2] the 100 MHz counter at the chain's start (the
- * device's own time line); [3] the chain length in instructions.  About 10 us of one SIMD; does not synchronise. */
-int armenv_probe_clock(int32_t device, uint64_t *out_dev, void *stream);
+/* Measurement aid (bench.py's clock_probe samples; no reference counterpart): enqueues on `stream` one wavefront per SIMD of the
+ * device (256-thread blocks, one per CU), each running a fixed dependent chain of v_fma_f32 between two readings of the device's
+ * constant-rate 100 MHz counter -- the whole chip under the kind of load the env kernels put on it, for about 10 us.
+ * *rows (nullable, host) receives the number of rows = 4 x CUs; out_dev == NULL only answers that.  out_dev u64 [rows][4] (device),
+ * one row per wavefront: [0] the chain's duration in 10 ns ticks -- inversely proportional to the shader clock the wave's XCD ran
+ * at, so the ratio of two samples is the ratio of the clocks; [1] the same in s_memtime ticks; [2] the 100 MHz counter at the
+ * chain's start (the device's own time line); [3] bits 0..3 the XCD the wave ran on, bits 8.. the chain length in instructions.
+ * Does not synchronise. */
+int armenv_probe_clock(int32_t device, uint64_t *out_dev, int32_t *rows, void *stream);
 
 /* Shape / capability queries. */
 int64_t armenv_num_envs(const ArmEnv *env);

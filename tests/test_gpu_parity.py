@@ -1993,18 +1993,20 @@ def test_bench_line_contract():
     assert d["regions"] == 16 and len(d["launch_us_samples"]) == 16 and d["value_min"] <= d["value_median"] <= d["value_max"]
     assert d["value_min"] <= d["value"] <= d["value_max"] and d["launch_us_samples"][0] == pytest.approx(ro["avg_launch_us"], abs=0.01)
     assert d["launch_us_max"] < 1.6 * d["launch_us_min"], d["launch_us_samples"]      # sanity, not a performance claim
-    # clock probes around every region (ns per chained v_fma_f32 of one probe wave: 4-8 cycles at 1.4-2.5 GHz), and the same region
-    # under the two other regimes (state restored on the device / behind 5 ms of other work)
+    # clock probes around every region (ns per chained v_fma_f32, median over one probe wave per SIMD: 4-8 cycles at 1.4-2.5 GHz),
+    # every region behind --busy-ahead-ms of scratch work, and round 4's two regimes (nothing in front; host / device restore) beside it
+    assert d["config"]["busy_ahead_ms"] == 8.0 and d["clock_probe_xcds"] == 8
     assert len(d["clock_probe_ns_samples"]) == 16 and all(1.0 < x < 8.0 for x in d["clock_probe_ns_samples"] + d["clock_probe_ns_before"])
-    assert len(d["launch_us_at_fastest_clock"]) == 16 and d["clock_probe_ns_fastest"] <= min(d["clock_probe_ns_samples"])
-    for mode in ("ab_device_restore", "ab_busy_ahead"):
+    assert len(d["launch_us_at_fastest_clock"]) == 16 and d["clock_probe_ns_fastest"] <= min(d["clock_probe_ns_samples"]) + 1e-3
+    assert all(a_ <= b_ + 1e-9 for a_, b_ in zip(d["clock_probe_ns_samples"], d["clock_probe_ns_slowest_xcd"]))
+    for mode in ("ab_host_restore", "ab_device_restore"):
         assert len(d[mode]["launch_us_samples"]) == 8 and len(d[mode]["clock_probe_ns_samples"]) == 8
         assert d[mode]["launch_us_max"] < 1.6 * d["launch_us_min"] and d[mode]["launch_us_min"] > 0.7 * d["launch_us_min"], d[mode]
     cf = d["config"]      # the flat copies
     assert cf["rccl_world_size"] == 1 and cf["value_median"] == d["value_median"] and cf["launch_us_median"] == d["launch_us_median"]
     assert cf["actor_f32_us_per_step"] == d["config3_actor_f32"]["us_per_step"] and cf["actor_f16x3_us_per_step"] == d["config3_actor_f16x3"]["us_per_step"]
     assert cf["push_us_per_step"] == d["config4_push"]["us_per_step"] and cf["step_api_us"] == d["step_api"]["avg_launch_us"]
-    assert all(not isinstance(cf[k], (dict, list)) for k in ("rccl_backend", "ab_device_restore_launch_us_median", "ab_busy_ahead_launch_us_median",
+    assert all(not isinstance(cf[k], (dict, list)) for k in ("rccl_backend", "ab_device_restore_launch_us_median", "ab_host_restore_launch_us_median",
                                                              "clock_probe_ns_min", "cpu_env_steps_per_s", "large_batch_env_steps_per_s"))
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["threads_1"]["cores"] == 1 and cb["threads_1"]["value"] > 5e4 and cb["value"] >= 0.8 * cb["threads_1"]["value"]
