@@ -299,8 +299,21 @@ AE_DEV void actor_stage_w1h(const float *W1P, float4 *w1_lds, int in_dim) {
 }
 // LDS region (in k-step units) that holds k-step ks
 AE_DEV int actor_region(int ks) { return ks < ACTOR_KRES ? ks : ACTOR_KRES + (ks & (ACTOR_RING_SLOTS - 1)); }
-// the streamed k-step two stream positions after ks (ks >= KRES): 4 -> 6, ..., 13 -> 15, 14 -> 4, 15 -> 5
-AE_DEV int actor_next2(int ks) { const int t = ks - ACTOR_KRES + 2; return ACTOR_KRES + (t >= 16 - ACTOR_KRES ? t - (16 - ACTOR_KRES) : t); }
+// How far ahead of its use a streamed k-step is requested: the refill issued during k-step ks fetches the streamed k-step
+// ACTOR_FILL_AHEAD stream positions after ks.
+//   2 (rounds 2-4): the data of k-step ks + 2, read from LDS during k-step ks + 1, has from the refill slots of k-step ks to the head
+//      of k-step ks + 1 to land: ~20 MFMA slots, ~650 cycles -- about what an LDS DMA from L2 takes with every CU streaming, so the
+//      head's vmcnt(0) could catch its tail;
+//   3: one k-step more (its ring slot was last read during k-step ks - 2 and every wave has passed the barrier of k-step ks - 1
+//      since); the head then waits for the refill issued TWO k-steps ago only -- vmcnt(4): the four DMA instructions of the last
+//      k-step stay in flight (full workgroups; the ragged copy issues a varying number and keeps vmcnt(0)).
+#ifndef ARMENV_ACTOR_FILL_AHEAD
+#define ARMENV_ACTOR_FILL_AHEAD 2
+#endif
+constexpr int ACTOR_FILL_AHEAD = ARMENV_ACTOR_FILL_AHEAD;
+static_assert(ACTOR_FILL_AHEAD == 2 || ACTOR_FILL_AHEAD == 3, "ring protocol: 2 or 3 stream positions ahead");
+// the streamed k-step ACTOR_FILL_AHEAD stream positions after ks (ks >= KRES); ahead 2: 4 -> 6, ..., 13 -> 15, 14 -> 4, 15 -> 5
+AE_DEV int actor_next2(int ks) { const int t = ks - ACTOR_KRES + ACTOR_FILL_AHEAD; return ACTOR_KRES + (t >= 16 - ACTOR_KRES ? t - (16 - ACTOR_KRES) : t); }
 
 // one 1 KB direct-to-LDS copy: lane l moves 16 bytes from src_base + voff (voff = 16 l) to LDS byte lds_dst + 16 l.
 // src_base and lds_dst are wave-uniform (SGPRs): a fill costs scalar adds only, no VALU.
@@ -346,14 +359,15 @@ AE_DEV void actor_ring_fill(const ActorParamsH &H, uint4 *ring, int ks, int nw) 
     for (int f = wave; f < 16; f += nw) actor_ring_fill_one(H, ring, ks, f);
   }
 }
-AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // the resident k-steps and the first two streamed
-  static_for<0, ACTOR_KRES + 2>([&](auto KI) { constexpr int k = KI; actor_ring_fill(H, ring, k, nw); });
+AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // the resident k-steps and the first ACTOR_FILL_AHEAD streamed
+  static_for<0, ACTOR_KRES + ACTOR_FILL_AHEAD>([&](auto KI) { constexpr int k = KI; actor_ring_fill(H, ring, k, nw); });
 }
 AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Instrumented build only (make timeline): shader-clock stamps of workgroup 0's four waves at the phases of the f16x3 pass, written to
-// the buffer tests/tools/exp/run_actor_timeline.py installs (row = wave, 64 stamps each: 20 t + {0 pass start, 1 first row tile split,
-// 2..17 after k-step 0..15, 18 after layer 3}).
+// Instrumented build only (make timeline): shader-clock time of workgroup 0's four waves by phase of the f16x3 pass, accumulated in
+// scalar registers and written once per pass to the buffer tests/tools/exp/run_actor_timeline.py installs (row = wave, 64 slots each:
+// 8 t + class; classes: 0 prologue, 1 bodies of the resident k-steps, 2 / 3 of the streamed even / odd k-steps, 4 layer 3 + epilogue,
+// 5 the sixteen heads' s_waitcnt vmcnt, 6 their s_barrier).
 #ifdef ARMENV_TIMELINE
 static __device__ unsigned long long *g_actor_tl;
 // accumulate the shader-clock time since the previous stamp into class k (scalar registers only: a store inside the k-loops would be
@@ -367,7 +381,7 @@ static __device__ unsigned long long *g_actor_tl;
 #define ATL_FLUSH(t)                                                                                                        \
   do {                                                                                                                      \
     if (blockIdx.x == 0 && g_actor_tl && (threadIdx.x & 63) == 0)                                                           \
-      for (int k_ = 0; k_ < 5; ++k_) g_actor_tl[(threadIdx.x >> 6) * 64 + 8 * (t) + k_] = atl_acc[k_];                      \
+      for (int k_ = 0; k_ < 7; ++k_) g_actor_tl[(threadIdx.x >> 6) * 64 + 8 * (t) + k_] = atl_acc[k_];                      \
   } while (0)
 #else
 #define ATL(k)
@@ -423,7 +437,8 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
     // saug = [obs, 1, 0..].  B operand: lane l holds saug[8 (l >> 5) + j], j = 0..7, of env (l & 31) + 32 t, split hi / lo.  (As
     // f32 MFMAs, four k-pairs of 64 cycles each, layer 1 held the matrix pipe for 1.7 us of every env step; as 3 x 32 cycles 0.6 us.)
 #ifdef ARMENV_TIMELINE
-    unsigned long long atl_acc[5] = {0, 0, 0, 0, 0}, atl_prev = __builtin_amdgcn_s_memtime();   // prologue | resident k-steps | streamed even | streamed odd | layer 3
+    // prologue | resident k-steps' bodies | streamed even | streamed odd | layer 3 | the sixteen heads' vmcnt waits | their barriers
+    unsigned long long atl_acc[7] = {0, 0, 0, 0, 0, 0, 0}, atl_prev = __builtin_amdgcn_s_memtime();
 #endif
     half8 oh, ol;
     static_for<0, 8>([&](auto JI) {
@@ -508,9 +523,14 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
     auto kstep = [&](auto ODD, int ks, const half8 (&ch)[NT], const half8 (&cl)[NT], half8 (&nh)[NT], half8 (&nl)[NT],
                      const f32x16 &a1n, auto &&inject) __attribute__((always_inline)) {
       constexpr int u = ODD;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of the fill issued one k-step ago (k-step ks + 1)
+      // own share of the fill of k-step ks + 1 has landed: issued one k-step ago (ahead 2) / two k-steps ago, with the last k-step's
+      // four DMA instructions still in flight behind it (ahead 3, full workgroups: loads return in order)
+      if constexpr (FULL && ACTOR_FILL_AHEAD == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ATL(5);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      ATL(6);
       const half8 *slot = reinterpret_cast<const half8 *>(ring) + actor_region((ks + 1) & 15) * 16 * 64 + lane;
       const bool streamed = ks >= ACTOR_KRES;            // resident k-steps consume no ring slot: nothing to refill
       const int kf = actor_next2(streamed ? ks : ACTOR_KRES);

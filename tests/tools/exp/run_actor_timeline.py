@@ -24,10 +24,16 @@ for _ in range(8):
     e.rollout(100, None, out=b)
 torch.cuda.synchronize()
 t = tl.cpu().numpy().astype(np.int64)
-names = ("prologue (obs operands, layer 1 + split of row tile 0)", "4 resident k-steps", "6 streamed even k-steps", "6 streamed odd k-steps", "layer 3 + pass epilogue")
+names = ("prologue (obs operands, layer 1 + split of row tile 0)", "4 resident k-step bodies", "6 streamed even k-step bodies", "6 streamed odd k-step bodies",
+         "layer 3 + pass epilogue", "16 heads: s_waitcnt vmcnt", "16 heads: s_barrier")
 for w in range(4):
     for p in range(2):
-        a = t[w, 8 * p:8 * p + 5]
+        a = t[w, 8 * p:8 * p + 7]
         print("wave %d env tile %d: %s | total %d cycles" % (w, p, "  ".join("%s %d" % (nm.split(" (")[0], x) for nm, x in zip(names, a)), a.sum()))
-a = np.array([t[w, 8 * p:8 * p + 5] for w in range(4) for p in range(2)], dtype=np.float64).mean(0)
-print("mean per pass: prologue %.0f | per resident k-step %.0f | per streamed even k-step %.0f | odd %.0f | layer 3 + epilogue %.0f | pass %.0f cycles (24 MFMAs of a k-step: 768)" % (a[0], a[1] / 4, a[2] / 6, a[3] / 6, a[4], a.sum()))
+a = np.array([t[w, 8 * p:8 * p + 7] for w in range(4) for p in range(2)], dtype=np.float64).mean(0)
+tot = a.sum()
+print("mean per pass (cycles, share of the pass): prologue %.0f (%.1f %%) | resident k-step body %.0f each | streamed even body %.0f | odd %.0f | layer 3 + epilogue %.0f (%.1f %%) | "
+      "head vmcnt wait %.0f per k-step (%.1f %% of the pass) | head barrier %.0f per k-step (%.1f %%) | pass %.0f cycles; the 24 MFMAs of a k-step hold the pipe 768 cycles "
+      "(bodies: %.1f %% of the pass, of which matrix pipe 16 x 768 = %.1f %% of the pass)"
+      % (a[0], 100 * a[0] / tot, a[1] / 4, a[2] / 6, a[3] / 6, a[4], 100 * a[4] / tot, a[5] / 16, 100 * a[5] / tot, a[6] / 16, 100 * a[6] / tot, tot,
+         100 * (a[1] + a[2] + a[3]) / tot, 100 * 16 * 768 / tot))
