@@ -726,6 +726,11 @@ def main():
         closing one; both outside the clock and the events).  count=False: no armenv_counters round trips around the region.
         ahead_ms: this much scratch-handle work is enqueued right before the opening synchronise (Scratch.ahead)."""
         ops, launches, gathers = plan(k)
+        # the launches' output buffers may be fresh allocations (the first region of a run: plan() has just made them): written
+        # once here so that the region does not pay their first touch (cold TLB entries: the contract's region measured 3-6 us
+        # slower than its 15 repeats into the same buffers, gpurun_out/r05/bench_driver_c.json)
+        for v_ in bufs.values():
+            v_.zero_()
         evs = HipEvents(dev)
         evs.record(0); evs.record(1)  # first use outside the region
         if count:
