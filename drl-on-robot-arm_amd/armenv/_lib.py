@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 NJ = 7
-ABI_VERSION = 4
+ABI_VERSION = 5
 TASK_REACH, TASK_PUSH, TASK_PICK = 0, 1, 2
 ROBOT_KUKA, ROBOT_DIANA = 0, 1
 FK_AUTO, FK_GENERIC = 0, 1
@@ -41,6 +41,9 @@ class ArmEnvConfig(C.Structure):
         ("push_rest_z", C.c_double), ("push_place_min", C.c_double), ("push_place_max", C.c_double), ("push_place_z", C.c_double),
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
         ("fence_z", C.c_double), ("fence_pivot", C.c_double), ("limit_erp", C.c_double), ("ik_tip_offset", C.c_double * 3),
+        ("push_tool_radius", C.c_double), ("push_tool_below", C.c_double), ("push_contact_erp", C.c_double),
+        ("push_contact_split", C.c_double), ("push_friction", C.c_double), ("push_gravity", C.c_double), ("push_dt", C.c_double),
+        ("push_drop_contact", C.c_double), ("push_drop_relax", C.c_double), ("push_contact_model", C.c_int32), ("reserved0", C.c_int32),
         ("rollout_ready_lanes", C.c_int32), ("rollout_waves_per_simd", C.c_int32),
         ("rollout_lanes_per_wave", C.c_int32), ("rollout_straggler_trips", C.c_int32),
         ("chain", ArmEnvChain),

@@ -278,7 +278,7 @@ class BatchedArmEnv:
 
     # ------------------------------------------------------------------ state exchange / stats
     def get_state(self):
-        """Reach: q, goal, step, episode, ep_return, trig.  Push: aux [N,8] (cube xyz, target xyz, d_last, 0) replaces goal;
+        """Reach: q, goal, step, episode, ep_return, trig.  Push: aux [N,10] (cube xyz, target xyz, d_last, cube velocity xy, 0) replaces goal;
         pick: aux [N,12] (cube xyz, target xyz, d_last, gripper 0/1/2, hold offset xyz, 0).  trig [N,14] = (cos q, sin q) as
         the engine carries them: ``set_state(**get_state())`` restores a checkpoint bit for bit."""
         n, dev = self.num_envs, self.device
@@ -380,12 +380,13 @@ def diana_cam_reach_kinematics():
 
 
 class BatchedPushEnv(BatchedArmEnv):
-    """N x RLPushEnv (/root/reference/envs/rl_push_env.py): arm pipeline exact (dv 0.08, z in [0, 0.1]); the cube
-    follows a simplified sphere-vs-box push-out model instead of Bullet's rigid-body step (DESIGN.md section 4);
-    reward / done / success follow rl_push_env.py:368-445.  obs f32 [N, 9] = [eef, cube, target]."""
+    """N x RLPushEnv (/root/reference/envs/rl_push_env.py): arm pipeline exact (dv 0.08, z in [0, 0.1]); the cube falls from its
+    spawn height as Bullet lets it (pinned by the reference's recorded runs) and is pushed in the plane by a velocity-level contact
+    model with Bullet's step order instead of Bullet's rigid-body step over the KUKA meshes (ArmEnvConfig.push_contact_model,
+    DESIGN.md section 2); reward / done / success follow rl_push_env.py:368-445.  obs f32 [N, 9] = [eef, cube, target]."""
     task = L.TASK_PUSH
     obs_dim = 9
-    aux_dim = 8
+    aux_dim = 10
 
     def __init__(self, num_envs, **kw):
         super().__init__(num_envs, **kw)

@@ -241,6 +241,18 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->push_rest_z = 0.01 - 0.01474;
   c->push_place_min = 0.22;
   c->push_place_max = 0.25;
+  // the cube under stepSimulation (include/armenv.h, push_contact_model): fall constants from the reference's scene, contact
+  // constants fitted to its recorded push runs (tests/tools/fit_bullet.py part C)
+  c->push_contact_model = 1;
+  c->push_tool_radius = 0.035;
+  c->push_tool_below = 0.03;
+  c->push_contact_erp = 0.02;
+  c->push_contact_split = 0.04;
+  c->push_friction = 0.03;
+  c->push_gravity = 10.0;           // rl_push_env.py:155
+  c->push_dt = 1.0 / 240.0;
+  c->push_drop_contact = 0.015;
+  c->push_drop_relax = 0.1;
   c->pick_gripper_length = 0.257;   // rl_pick_env.py:79
   c->pick_trigger_dis = 0.006;      // rl_pick_env.py:412
   c->pick_jaw_half = 0.02;
@@ -276,6 +288,11 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
   if (cfg->rollout_straggler_trips < 0 || cfg->rollout_straggler_trips > 64)
     return fail(ARMENV_EINVAL, "armenv_create: rollout_straggler_trips must be in 0..64");
   if (cfg->rollout_waves_per_simd < 0 || cfg->rollout_waves_per_simd > 2) return fail(ARMENV_EINVAL, "armenv_create: rollout_waves_per_simd must be 0, 1 or 2");
+  if (cfg->push_contact_model < 0 || cfg->push_contact_model > 1 || cfg->reserved0 != 0) return fail(ARMENV_EINVAL, "armenv_create: push_contact_model must be 0 or 1 (reserved0 0)");
+  if (cfg->task == ARMENV_TASK_PUSH && cfg->push_contact_model == 1 &&
+      !(cfg->push_dt > 0.0 && cfg->push_gravity > 0.0 && cfg->push_drop_contact > 0.0 && cfg->push_drop_contact < 1.0 && cfg->push_drop_relax > 0.0 &&
+        cfg->push_drop_relax <= 1.0 && cfg->push_contact_erp >= 0.0 && cfg->push_friction >= 0.0 && cfg->push_tool_radius > 0.0))
+    return fail(ARMENV_EINVAL, "armenv_create: push_contact_model 1 needs push_dt, push_gravity, push_tool_radius > 0, push_drop_contact in (0, 1), push_drop_relax in (0, 1], push_contact_erp, push_friction >= 0");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(ARMENV_ENODEV, "armenv_create: no HIP device is visible (this library has no CPU fallback)");
@@ -504,7 +521,7 @@ int64_t armenv_num_envs(const ArmEnv *env) { return env ? env->cfg.num_envs : 0;
 int32_t armenv_obs_dim(const ArmEnv *env) { return env ? (env->cfg.task == ARMENV_TASK_REACH ? 6 : 9) : 0; }
 int32_t armenv_aux_dim(const ArmEnv *env) {
   if (!env) return 0;
-  return env->cfg.task == ARMENV_TASK_PUSH ? 8 : (env->cfg.task == ARMENV_TASK_PICK ? 12 : 0);
+  return env->cfg.task == ARMENV_TASK_PUSH ? 10 : (env->cfg.task == ARMENV_TASK_PICK ? 12 : 0);
 }
 int32_t armenv_action_dim(const ArmEnv *) { return 3; }
 const char *armenv_kernel_name(const ArmEnv *env) { return env ? env->eng->name() : ""; }

@@ -187,6 +187,22 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
     K.push_place_min = cfg.push_place_min;
     K.push_place_max = cfg.push_place_max;
     K.push_place_z = cfg.push_place_z;
+    {   // the cube under stepSimulation (CubeLane::cube_fall / contact_dyn): constants folded on the host in f64
+      K.push_model = cfg.task == ARMENV_TASK_PUSH ? cfg.push_contact_model : 0;
+      const double c = 0.5 * cfg.push_gravity * cfg.push_dt * cfg.push_dt;
+      int kl = 1;
+      while (kl < 100000 && c * (double)kl * (double)(kl + 1) < cfg.push_drop_contact) ++kl;
+      K.fall_land = kl;
+      K.fall_c = (T)c;
+      K.fall_keep = (T)(1.0 - cfg.push_drop_relax);
+      K.place_z = (T)cfg.push_place_z;
+      K.tool_radius = (T)cfg.push_tool_radius;
+      K.tool_below = (T)cfg.push_tool_below;
+      K.erp = (T)cfg.push_contact_erp;
+      K.split = (T)cfg.push_contact_split;
+      K.fric_dv = (T)(cfg.push_friction * cfg.push_gravity * cfg.push_dt);
+      K.dt = (T)cfg.push_dt;
+    }
     K.seed = cfg.seed;
     K.env_id0 = cfg.env_id_offset;
     P.pick_gripper_length = (T)cfg.pick_gripper_length;

@@ -21,6 +21,14 @@ template <typename T> struct EnvCold {
   double goal_lo[3], goal_hi[3];
   double push_rest_z, push_place_min, push_place_max, push_place_z;
   uint64_t seed, env_id0;
+  // push task, ArmEnvConfig.push_contact_model = 1: the cube under stepSimulation (CubeLane::cube_fall, contact_dyn).  Read once per
+  // step, behind the IK loop.
+  int32_t push_model;       // 0: rounds 1-4 (tool sphere, full push-out; always 0 for the pick task), 1: fall + velocity-level contact
+  int32_t fall_land;        // the stepSimulation call (counted from the spawn) in which the falling cube reaches the table
+  T fall_c;                 // g dt^2 / 2: the cube is fall_c k (k + 1) below its spawn height after k free steps
+  T fall_keep;              // 1 - push_drop_relax
+  T place_z;                // spawn height
+  T tool_radius, tool_below, erp, split, fric_dv, dt;
 };
 
 template <typename T> struct EnvParams {
@@ -34,7 +42,7 @@ template <typename T> struct EnvParams {
   int32_t *last_len;
   uint8_t *last_success;
   unsigned long long *counters;   // [ceil(N / 32)][16]: one row per wave (half-filled waves carry 32 envs), summed by counters_sum_kernel on read
-  T *aux;  // push: [7][N] = cube xyz, target xyz, d_last;  pick: [11][N] = the same + gripper state + hold offset xyz
+  T *aux;  // push: [9][N] = cube xyz, target xyz, d_last, cube velocity xy;  pick: [11][N] = cube xyz, target xyz, d_last, gripper state, hold offset xyz
   T *trig; // [14][N] = cos q[7], sin q[7]: the pair every FK starts from, carried with q (see ReachLane::trig)
   int64_t n;
   // task constants
@@ -551,7 +559,9 @@ AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&
     (void)u2;
     if (d >= K.push_place_min && d <= K.push_place_max) break;
   }
-  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = (T)K.push_rest_z;
+  // push_contact_model 1: spawned at push_place_z, the cube has begun to fall in reset()'s own stepSimulation (:241); otherwise it
+  // is already at rest on the table
+  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = K.push_model == 1 ? K.place_z - K.fall_c * T(1) * T(2) : (T)K.push_rest_z;
   target[0] = (T)tx; target[1] = (T)ty; target[2] = (T)tz;
 }
 
@@ -569,11 +579,12 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
   using Chain = C;
   static constexpr int kTask = PICK ? ARMENV_TASK_PICK : ARMENV_TASK_PUSH;
   static constexpr int kObs = 9;
-  static constexpr int kAuxRows = PICK ? 11 : 7, kAuxDim = PICK ? 12 : 8;
+  static constexpr int kAuxRows = PICK ? 11 : 9, kAuxDim = PICK ? 12 : 10;
   static constexpr const char *kName = PICK ? "pick" : "push";
   T q[NJ];
   T cq[NJ], sq[NJ];         // (cos q, sin q), carried with q in the env's state: see ReachLane::cq
   T cube[3], target[3], d_last;
+  T vel[2] = {T(0), T(0)};  // push: the cube's planar velocity (push_contact_model 1)
   FKState<T> S;             // link frames of the current pose, carried from step to step (push only): see ReachLane::S
   AE_DEV void make_frame(const EnvParams<T> &P) { fk<C, T>(P.chain, cq, sq, S); }
   T grip = T(0);            // pick: 0 open, 1 closed, 2 closed and holding the cube
@@ -612,6 +623,8 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     P.episode[i] = ep + 1u;
     if (goal_in) {
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = (T)goal_in[6 * i + k]; target[k] = (T)goal_in[6 * i + 3 + k]; });
+      // the caller places the cube in the plane; its height is the engine's (one step into its fall, as in cube_sample)
+      if (P.cold->push_model == 1) cube[2] = P.cold->place_z - P.cold->fall_c * T(1) * T(2);
     } else {
       cube_sample<PICK, T>(P, i, ep, cube, target);
     }
@@ -621,6 +634,7 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     const T x = cube[0] - target[0], y = cube[1] - target[1], z = cube[2] - target[2];
     P.aux[(int64_t)6 * n + i] = M::sqrt(M::fma(x, x, M::fma(y, y, z * z)));
     if constexpr (PICK) static_for<7, 11>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = T(0); });   // gripper open (:235-238)
+    else static_for<7, 9>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)k * n + i] = T(0); });                    // cube at rest in the plane
     P.step[i] = 0;
     P.ep_return[i] = T(0);
     if (obs) store_obs9<T>(obs, i, P.cold->p_init, cube, target);
@@ -634,6 +648,8 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     if constexpr (PICK) {
       grip = P.aux[(int64_t)7 * n + i];
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; off[k] = P.aux[(int64_t)(8 + k) * n + i]; });
+    } else {
+      vel[0] = P.aux[(int64_t)7 * n + i]; vel[1] = P.aux[(int64_t)8 * n + i];
     }
     step = P.step[i];
     ep_ret = P.ep_return[i];
@@ -650,6 +666,8 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     if constexpr (PICK) {
       P.aux[(int64_t)7 * n + i] = grip;
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; P.aux[(int64_t)(8 + k) * n + i] = off[k]; });
+    } else {
+      P.aux[(int64_t)7 * n + i] = vel[0]; P.aux[(int64_t)8 * n + i] = vel[1];
     }
     P.step[i] = step;
     P.ep_return[i] = ep_ret;
@@ -680,6 +698,54 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
       const T s = (r + h) - M::fma(cube[0] - p[0], mx, (cube[1] - p[1]) * my);
       if (s > T(0)) { cube[0] = M::fma(s, mx, cube[0]); cube[1] = M::fma(s, my, cube[1]); }
     }
+  }
+
+  // stepSimulation (:349), push_contact_model 1 (include/armenv.h).
+  // k = number of stepSimulation calls since the cube was spawned, this one included (reset() made the first, :241).
+  // The cube's height: free fall through the step in which it reaches the table, then the overshoot decays towards the rest height.
+  AE_DEV void cube_fall(const EnvCold<T> &K, int k) {
+    if (k <= K.fall_land) cube[2] = K.place_z - K.fall_c * (T)k * (T)(k + 1);
+    else cube[2] = (T)K.push_rest_z + (cube[2] - (T)K.push_rest_z) * K.fall_keep;
+  }
+  // The cube in the plane: collision detection at the positions the step starts from (tool = vertical cylinder about the link-7
+  // frame's xy, reaching tool_below under it), velocity-level contact along the horizontal normal unless the tool sits less deep in the
+  // cube from above than from the side (then it presses the cube onto the table), Coulomb friction once the cube has landed, integration.
+  AE_DEV void contact_dyn(const EnvParams<T> &P, const EnvCold<T> &K, const T (&p)[3], int k) {
+    const T h = P.push_cube_half, r = K.tool_radius, dt = K.dt;
+    const T lo = p[2] - K.tool_below;
+    if (lo < cube[2] + h) {
+      const T lx = cube[0] - h, hx = cube[0] + h, ly = cube[1] - h, hy = cube[1] + h;
+      const T qx = p[0] < lx ? lx : (p[0] > hx ? hx : p[0]);
+      const T qy = p[1] < ly ? ly : (p[1] > hy ? hy : p[1]);
+      const T gx = qx - p[0], gy = qy - p[1];
+      const T gap = M::sqrt(gx * gx + gy * gy);
+      if (gap < r) {
+        T pen, nx, ny;
+        if (gap > T(1e-9)) { pen = r - gap; nx = gx / gap; ny = gy / gap; }
+        else {   // tool axis inside the footprint: out through the nearest face (-x, +x, -y, +y in this order on ties)
+          const T e0 = hx - p[0], e1 = p[0] - lx, e2 = hy - p[1], e3 = p[1] - ly;
+          T eb = e0; nx = T(-1); ny = T(0);
+          if (e1 < eb) { eb = e1; nx = T(1); ny = T(0); }
+          if (e2 < eb) { eb = e2; nx = T(0); ny = T(-1); }
+          if (e3 < eb) { eb = e3; nx = T(0); ny = T(1); }
+          pen = eb + r;
+        }
+        const T pen_v = (cube[2] + h) - lo;
+        if (!(pen_v < pen)) {
+          const T vn = vel[0] * nx + vel[1] * ny;
+          const T tgt = pen < K.split ? K.erp * pen / dt : T(0);
+          if (vn < tgt) { vel[0] += (tgt - vn) * nx; vel[1] += (tgt - vn) * ny; }
+        }
+      }
+    }
+    if (k >= K.fall_land) {
+      const T sp = M::sqrt(vel[0] * vel[0] + vel[1] * vel[1]);
+      if (sp > T(0)) {
+        const T f = sp > K.fric_dv ? (sp - K.fric_dv) / sp : T(0);
+        vel[0] *= f; vel[1] *= f;
+      }
+    }
+    cube[0] += vel[0] * dt; cube[1] += vel[1] * dt;
   }
 
   // Pick: gripper and cube after the arm's teleport (rl_pick_env.py:349 stepSimulation, :412-417 getClosestPoints ->
@@ -760,7 +826,9 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
       cq[NJ - 1] = c7s; sq[NJ - 1] = s7s;
       grip_step(P, p0, S);          // :349, :412-417
     } else {
-      contact(P, p0, S.p);          // :349
+      const EnvCold<T> &K = *P.cold;
+      if (K.push_model == 1) { cube_fall(K, step + 2); contact_dyn(P, K, S.p, step + 2); }      // :349
+      else contact(P, p0, S.p);                                                                // :349, rounds 1-4
     }
     step += 1;                                                                    // :355
     const T d_cur = dist_ct();                                                    // :388
@@ -811,6 +879,7 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
         P.episode[i] = ep + 1u;
         d_last = dist_ct();                                                         // :243-245
         if constexpr (PICK) { grip = T(0); off[0] = off[1] = off[2] = T(0); }
+        else { vel[0] = vel[1] = T(0); }
         const EnvCold<T> &K = *P.cold;
         static_for<0, NJ>([&](auto JI) { constexpr int j = JI; q[j] = K.q_init[j]; });
         static_for<0, NJ>([&](auto JI) { constexpr int j = JI; cq[j] = K.trig_init[j]; sq[j] = K.trig_init[NJ + j]; });

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define ARMENV_NJ 7
-#define ARMENV_ABI_VERSION 4
+#define ARMENV_ABI_VERSION 5
 
 enum {
   ARMENV_OK = 0,
@@ -157,6 +157,36 @@ typedef struct ArmEnvConfig {
                                  offset selects the MODE 2 bookkeeping build of the kernels (as fence_counters = 2 does; it is a fitting
                                  switch for tests/tools/fit_bullet.py, not a tuned path) and excludes the fused actors. */
 
+  /* push task: the cube under stepSimulation (/root/reference/envs/rl_push_env.py:349; models/cube_small_push.urdf: 4 cm box, 1 kg,
+   * lateral friction 5, pushed by link meshes that resetJointState teleports with zero velocity, :339-347).  Bullet's rigid-body step
+   * over the KUKA meshes is not restated; push_contact_model names what stands in for it:
+   *   1 (default, ABI 5): the cube as a planar point mass under Bullet's step order -- collision detection at the positions the
+   *     step starts from, velocity-level contact (the cube's velocity along the contact normal is raised to push_contact_erp x
+   *     penetration / push_dt; penetrations beyond push_contact_split get no positional correction), Coulomb friction against the
+   *     table (push_friction x push_gravity), integration -- against a vertical tool cylinder (push_tool_radius about the link-7
+   *     frame, reaching push_tool_below under it); a tool that is less deep in the cube from above than from the side presses it onto
+   *     the table and moves nothing.  The cube's HEIGHT follows Bullet exactly as far as the reference's recorded runs can tell: spawned
+   *     at push_place_z it is in free fall (semi-implicit Euler, push_gravity, push_dt) from reset()'s own stepSimulation (:241)
+   *     through the step in which its drop passes push_drop_contact, then recovers the overshoot towards push_rest_z by the share
+   *     push_drop_relax per step.  The fall has no fitted number but the rest height and reproduces the untouched episodes of both
+   *     recorded runs (visdata/push/origin_TD3 and updata_TD3: tests/reference_run.py) to 3e-4; push_tool_radius, push_tool_below,
+   *     push_contact_erp and push_friction are fitted to the touched ones (tests/tools/fit_bullet.py part C, DESIGN.md section 2:
+   *     final distances within 2 cm = returns of the first run within 1.0; the count of steps on which the cube moves -- the second
+   *     run's returns -- within 0..34 of 84..192).
+   *   0: rounds 1-4 -- tool sphere of push_eef_radius at the link-7 frame, the whole penetration removed in one step, the cube
+   *     already at rest at push_rest_z after reset() (what the pick task's gripper tip still uses). */
+  double push_tool_radius;    /* 0.035 */
+  double push_tool_below;     /* 0.03 (the KUKA flange face is 0.045 below the link-7 frame) */
+  double push_contact_erp;    /* 0.02 (Bullet's contact ERP, 0.2, is the share against an immovable body; link 7 weighs 0.3 kg) */
+  double push_contact_split;  /* 0.04: Bullet's m_splitImpulsePenetrationThreshold */
+  double push_friction;       /* 0.03 */
+  double push_gravity;        /* 10: p.setGravity(0, 0, -10), :155 */
+  double push_dt;             /* 1 / 240: Bullet's default fixed time step */
+  double push_drop_contact;   /* 0.015 = spawn height 0.01 - cube half 0.02 - table top -0.025 (pybullet_data table.urdf based at z = -0.65, :189) */
+  double push_drop_relax;     /* 0.1; the recorded run bounds it to (0, 0.14): no recovery step moves the cube-target distance by 1e-5 */
+  int32_t push_contact_model; /* 1 */
+  int32_t reserved0;          /* must be 0 */
+
   /* armenv_rollout scheduling.  0: lockstep -- the lanes of a wavefront walk through every step together (a step costs the
    * wave its slowest lane's IK trips).  k in 1..64: lane-asynchronous -- a lane whose IK has stopped waits until k lanes of
    * its wave are waiting (or nobody iterates), then they finish their step and start the next one while the others carry on;
@@ -208,7 +238,8 @@ int armenv_reset(ArmEnv *env, const uint8_t *mask_dev, float *obs_dev, void *str
 
 /* Same, with caller-supplied goals f32 [N][3] (reach) -- the N=1 compatibility class uses this to
  * keep the reference's Python `random` stream (rl_reach_env.py:180-183). Push / pick: goal_dev is
- * f32 [N][6] = [cube xyz, target xyz]. */
+ * f32 [N][6] = [cube xyz, target xyz]; push with push_contact_model = 1 takes the cube's xy from it and lets the cube fall from
+ * push_place_z itself (its height is a function of the step count). */
 int armenv_reset_with_goal(ArmEnv *env, const uint8_t *mask_dev, const float *goal_dev, float *obs_dev,
                            void *stream);
 
@@ -260,7 +291,7 @@ int armenv_ik(ArmEnv *env, int64_t n, const double *q_dev, const double *target_
 /* State exchange for teacher-forced parity tests and checkpointing (the reference keeps this state
  * inside the PyBullet client: joint angles via resetJointState rl_reach_env.py:252-257, target via
  * loadURDF :186-189, step_counter :264).  Any pointer may be NULL to skip that field. Push and pick keep their
- * cube state in aux f64 [N][armenv_aux_dim()]: push [N][8] = [cube xyz, target xyz, d_last, pad]; pick [N][12] =
+ * cube state in aux f64 [N][armenv_aux_dim()]: push [N][10] = [cube xyz, target xyz, d_last, cube velocity xy, pad]; pick [N][12] =
  * [cube xyz, target xyz, d_last, gripper (0 open, 1 closed, 2 closed and holding the cube), cube - tip offset xyz
  * while held, pad].
  * trig f64 [N][14] = (cos q[7], sin q[7]) is the pair the engine carries with q and advances incrementally (DESIGN.md
@@ -376,7 +407,7 @@ int armenv_probe_clock(int32_t device, uint64_t *out_dev, int32_t *rows, void *s
 /* Shape / capability queries. */
 int64_t armenv_num_envs(const ArmEnv *env);
 int32_t armenv_obs_dim(const ArmEnv *env);
-int32_t armenv_aux_dim(const ArmEnv *env);   /* row length of get/set_state's aux: 0 reach, 8 push, 12 pick */
+int32_t armenv_aux_dim(const ArmEnv *env);   /* row length of get/set_state's aux: 0 reach, 10 push, 12 pick */
 int32_t armenv_action_dim(const ArmEnv *env);
 /* name of the step kernel variant in use, e.g. "reach_step<f64,kuka>" (for profiles) */
 const char *armenv_kernel_name(const ArmEnv *env);

@@ -87,6 +87,9 @@ class OrcConfig(C.Structure):
         ("pick_gripper_length", C.c_double), ("pick_trigger_dis", C.c_double), ("pick_jaw_half", C.c_double),
         ("clamp_joint_limits", C.c_int32), ("pad0", C.c_int32), ("lim_lo", C.c_double * NJ), ("lim_hi", C.c_double * NJ),
         ("fence_z", C.c_double), ("limit_erp", C.c_double), ("fence_pivot", C.c_double), ("ik_tip_offset", C.c_double * 3),
+        ("push_tool_radius", C.c_double), ("push_tool_below", C.c_double), ("push_contact_erp", C.c_double),
+        ("push_contact_split", C.c_double), ("push_friction", C.c_double), ("push_gravity", C.c_double), ("push_dt", C.c_double),
+        ("push_drop_contact", C.c_double), ("push_drop_relax", C.c_double), ("push_contact_model", C.c_int32), ("pad1", C.c_int32),
     ]
 
 
@@ -177,6 +180,17 @@ def default_config(task="reach", robot="kuka"):
     c.push_rest_z = 0.01 - 0.01474     # where the cube comes to rest (fitted to the reference's recorded push run)
     c.push_place_min = 0.22
     c.push_place_max = 0.25
+    # the cube under stepSimulation (armenv_oracle.c push_contact_dyn / push_cube_z); fitted values: tests/tools/fit_bullet.py part (C)
+    c.push_contact_model = 1
+    c.push_tool_radius = 0.035
+    c.push_tool_below = 0.03
+    c.push_contact_erp = 0.02
+    c.push_contact_split = 0.04        # Bullet: m_splitImpulsePenetrationThreshold = -0.04
+    c.push_friction = 0.03
+    c.push_gravity = 10.0              # rl_push_env.py:155
+    c.push_dt = 1.0 / 240.0            # Bullet's default time step
+    c.push_drop_contact = 0.015        # spawn 0.01 - half 0.02 - table top -0.025
+    c.push_drop_relax = 0.1
     c.pick_gripper_length = 0.257      # rl_pick_env.py:79
     c.pick_trigger_dis = 0.006         # rl_pick_env.py:412
     c.pick_jaw_half = 0.02
@@ -433,12 +447,15 @@ def reach_rollout(chain, cfg, st, steps, actions=None, seed=0, env_id0=0, sigma=
 
 # ------------------------------------------------------------------ push env
 
+PUSH_AUX = 10
+
+
 class PushState(ReachState):
-    """adds aux [N,8] = cube xyz, target xyz, d_last, pad"""
+    """adds aux [N,10] = cube xyz, target xyz, d_last, cube velocity xy, pad"""
 
     def __init__(self, n):
         super().__init__(n)
-        self.aux = np.zeros((n, 8))
+        self.aux = np.zeros((n, PUSH_AUX))
 
 
 def push_reset(chain, cfg, st, seed=0, env_id0=0, mask=None):

@@ -453,16 +453,22 @@ def g12_visdata_reach_td3():
 
 
 def g13_visdata_push_td3():
-    """visdata/push/origin_TD3/TD3.json: one train_push_with_TD3 run (main.py:449-515) -- the one of the two recorded push runs whose
-    numbers fit the reward code the reference ships (an episode in which the arm never touches the cube returns 500 x -1 and a final
-    -50 * distance).  First 40 per-episode returns (episode 33 is the run's first success; until then every episode has 501 steps
-    and the `random` stream is a fixed function of the seed), and the untrained 9-input TD3 actor of torch.manual_seed(0)."""
-    d = json.load(open(os.path.join(REF, "visdata", "push", "origin_TD3", "TD3.json")))["jsons"]
-    y = [float(v) for v in d["return"]["content"]["data"][0]["y"]]
-    assert len(y) == 5000
-    json.dump({"source": "visdata/push/origin_TD3/TD3.json (visdom export; y values of the 'return' window, first 40 of 5000)",
+    """The two recorded train_push_with_TD3 runs (main.py:449-515, seed 0), first 40 per-episode returns each:
+    visdata/push/updata_TD3/TD3.json fits the reward code the reference ships (an untouched episode returns -504.12: eight of the
+    cube's falling steps change its distance to the target by >= 1e-5 and cost -100 x the change instead of -1, rl_push_env.py:388-397,427);
+    visdata/push/origin_TD3/TD3.json was recorded with the earlier `reward = -1` (:426): -500 - 50 * final distance.  Same seeds: the
+    first five episodes (no network update before five are stored) are the same trajectories under two rewards -- tests/reference_run.py.
+    Episode 33 of the origin run is its first success; until then every episode has 501 steps and the `random` stream is a fixed function
+    of the seed.  And the untrained 9-input TD3 actor of torch.manual_seed(0)."""
+    ys = {}
+    for run in ("origin_TD3", "updata_TD3"):
+        d = json.load(open(os.path.join(REF, "visdata", "push", run, "TD3.json")))["jsons"]
+        ys[run] = [float(v) for v in d["return"]["content"]["data"][0]["y"]]
+        assert len(ys[run]) == 5000
+    json.dump({"source": "visdata/push/origin_TD3/TD3.json and visdata/push/updata_TD3/TD3.json (visdom exports; y values of the 'return' windows, first 40 of 5000)",
                "protocol": "main.py:449-515 train_push_with_TD3: one env, a = actor(s) + N(0, 0.4 * 0.98) unclipped, seed 0, 501-step episodes",
-               "return_per_episode": y[:40]}, open(os.path.join(OUT, "visdata_push_td3.json"), "w"))
+               "return_per_episode": ys["origin_TD3"][:40], "return_per_episode_updata": ys["updata_TD3"][:40]},
+              open(os.path.join(OUT, "visdata_push_td3.json"), "w"))
     import torch
     sys.path.insert(0, REF)
     from algo.TD3.TD3_mlp import TD3_MLP

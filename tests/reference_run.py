@@ -88,19 +88,42 @@ def replay_on_oracle(O, episodes=5, configure=None, action_f32=False, record=Non
     return out, fence
 
 
-# ------------------------------------------------------------------------------ the recorded push run
-# tests/golden/visdata_push_td3.json: first 40 per-episode returns of visdata/push/origin_TD3/TD3.json (train_push_with_TD3,
-# main.py:449-515, seed 0).  Bullet's cube dynamics are not restated (the build's contact model is its own), so only what does
-# not depend on them is compared:
-#   * an episode in which the arm never touches the cube returns 500 x (-1) (rl_push_env.py:393-394,427) and a final
-#     -50 * |cube - target| (:418-420), i.e. -500 - 50 sqrt(planar^2 + dz^2): planar = the placement distance of that reset --
-#     a fixed function of random.seed(0) while every episode lasts 501 steps (6 draws per placement try :197-209, 3 per step
-#     :435-437) -- and dz = what the dynamic cube sinks below the fixed target while it settles on the table.  Episodes 4, 6, 13,
-#     24 of the recorded run fit ONE dz = 14.74 mm to 2e-3: the placement stream, the draw counts and ArmEnvConfig.push_rest_z;
-#   * WHICH of the first five episodes (before any network update) touch the cube at all: T T T - T.
+# ------------------------------------------------------------------------------ the recorded push runs
+# tests/golden/visdata_push_td3.json: the first 40 per-episode returns of BOTH recorded train_push_with_TD3 runs (main.py:449-515, seed 0):
+#   "origin"  visdata/push/origin_TD3/TD3.json -- recorded with an EARLIER reward: every step that is neither the last nor a success
+#             costs -1 (the line `# reward = -1` the shipped _reward still carries, rl_push_env.py:426), so an episode returns
+#             -500 - 50 |cube - target|_final (:418-420);
+#   "updata"  visdata/push/updata_TD3/TD3.json -- recorded with the reward the reference SHIPS (:388-397,427): -1 on a step whose
+#             cube-target distance changes by less than 1e-5, -100 x the change otherwise.
+# Same seeds, and no network update before five episodes are stored (main.py:497): episodes 1-5 are the SAME trajectories in both runs,
+# seen through two rewards.  Per episode the pair of returns therefore yields two observables of Bullet's cube:
+#   d_f = (-500 - R_origin) / 50                      the final cube-target distance,
+#   M   = R_updata - R_origin + 100 (d_f - d_0)       the number of steps on which the distance changed by >= 1e-5 (d_0 = distance after
+#                                                     reset(); the sub-threshold changes of the other steps sum to < 1e-3) --
+# M comes out integer to 1e-2 for every one of the first six episodes, which is the check that the two runs do share them.
+#   * untouched episodes (4 and 6): M = 8 -- the cube is in free fall from its spawn height for reset()'s stepSimulation and the first
+#     twelve env steps, eight of which change the distance by >= 1e-5 -- and d_f = sqrt(planar^2 + dz^2) with the placement distance of
+#     that reset (a fixed function of random.seed(0): 6 draws per placement try :197-209, 3 per step :435-437) and dz = 14.74 mm
+#     (ArmEnvConfig.push_rest_z).  The engine's free-fall model has no other fitted number and reproduces both returns to 3e-4.
+#   * touched episodes (1, 2, 3, 5): M = 149, 192, 84, 32 and d_f - d_0 = +32.9, +1.7, +53.4, +7.4 mm: what the contact model is fitted
+#     on (tests/tools/fit_bullet.py part C).
 
-def push_fixture_returns():
-    return json.load(open(os.path.join(GOLDEN, "visdata_push_td3.json")))["return_per_episode"]
+def push_fixture_returns(run="origin"):
+    return json.load(open(os.path.join(GOLDEN, "visdata_push_td3.json")))["return_per_episode" if run == "origin" else "return_per_episode_updata"]
+
+
+def push_recorded_observables(episodes=5):
+    """[(d_f, M, planar)] of the first `episodes` episodes from the two recorded runs' returns (see above)"""
+    org, upd = push_fixture_returns("origin"), push_fixture_returns("updata")
+    random.seed(0)
+    out = []
+    for e in range(episodes):
+        _, _, planar = draw_push_placement()
+        for _ in range(501 * 3):
+            random.uniform(0.0, 1.0)
+        d_f = (-500.0 - org[e]) / 50.0
+        out.append((d_f, upd[e] - org[e] + 100.0 * (d_f - planar), planar))
+    return out
 
 
 def actor9_weights():
@@ -135,8 +158,10 @@ def push_untouched_returns(episodes, dz):
 
 
 def replay_push_on_oracle(O, episodes=5, configure=None):
-    """The first `episodes` episodes of the recorded push run on the oracle's push env (its own contact model).
-    Returns [(return, length, steps on which the cube moved)]."""
+    """The first `episodes` episodes of the recorded push runs on the oracle's push env (its own contact model).
+    Returns per episode a dict: ret (the shipped reward = the "updata" run's), ret_origin (the earlier reward: -1 per step, same
+    trajectory), n (steps), M (steps whose cube-target distance changed by >= 1e-5), d_f (final distance, float32 states as :400),
+    planar (placement distance), moved (steps on which the cube's xy moved at all)."""
     import math
     chain = O.make_chain("kuka")
     cfg = O.default_config("push")
@@ -147,20 +172,23 @@ def replay_push_on_oracle(O, episodes=5, configure=None):
     st = O.PushState(1)
     out = []
     for ep in range(episodes):
-        c, t, _ = draw_push_placement()
-        cube, tgt = c + [float(cfg.push_rest_z)], t + [float(cfg.push_place_z)]
+        c, t, planar = draw_push_placement()
+        cube, tgt = c + [float(cfg.push_place_z)], t + [float(cfg.push_place_z)]          # both spawned at z = 0.01 (:199,206)
         obs = O.push_reset_with_goal(chain, cfg, st, np.float32([cube + tgt]))[0]
-        st.aux[0, 0:3] = cube; st.aux[0, 3:6] = tgt
-        st.aux[0, 6] = math.sqrt(sum((a - b) ** 2 for a, b in zip(cube, tgt)))
-        done, ret, n, moved = False, 0.0, 0, 0
+        st.aux[0, 0:2] = c; st.aux[0, 3:6] = tgt      # the f64 placement (reset_with_goal takes f32); the cube's z is the engine's: it has
+        st.aux[0, 6] = math.sqrt(sum((a - b) ** 2 for a, b in zip(st.aux[0, 0:3], tgt)))      # begun to fall in reset()'s stepSimulation
+        done, ret, ret_o, n, moved, M = False, 0.0, 0.0, 0, 0, 0
         while not done:
             state = np.hstack((obs[:3].astype(np.float32), st.aux[0, 0:3], st.aux[0, 3:6])).astype(np.float32)   # :308, then torch.float
             a = O.actor_forward(sd, state[None], 0.4)[0].astype(np.float64) + np.random.normal(0, 0.4 * 0.98, size=3)   # main.py:481-484
-            c0 = st.aux[0, 0:3].copy()
+            c0, dl = st.aux[0, 0:3].copy(), float(st.aux[0, 6])
             o, r, d, s, _ = O.push_step(chain, cfg, st, a.astype(np.float32)[None])
             for k in range(3):
                 random.uniform(_LO[k], _HI[k])                                   # :435-437
-            moved += int(np.abs(st.aux[0, 0:3] - c0).max() > 0)
+            moved += int(np.abs(st.aux[0, 0:2] - c0[0:2]).max() > 0)
+            M += int(abs(float(st.aux[0, 6]) - dl) >= 1e-5)
             obs = o[0]; ret += float(r[0]); n += 1; done = bool(d[0])
-        out.append((ret, n, moved))
+            ret_o += float(r[0]) if (done or float(r[0]) == 100.0) else -1.0
+        d32 = float(np.linalg.norm(st.aux[0, 0:3].astype(np.float32) - st.aux[0, 3:6].astype(np.float32)))
+        out.append(dict(ret=ret, ret_origin=ret_o, n=n, M=M, d_f=d32, planar=planar, moved=moved))
     return out
