@@ -199,9 +199,9 @@ def algo_bytes_per_launch(task, policy, precision, n, steps_per_launch):
     io_b, st_b = IO_BYTES, STATE_BYTES[precision]
     if policy != "external":
         io_b -= 12                      # no action read
-    if task != "reach":  # obs 36 B instead of 24; state: cube/target/d_last (7 reals; pick 11) r+w instead of goal
+    if task != "reach":  # obs 36 B instead of 24; state: cube / target / d_last / cube velocity (9 reals; pick 11) r+w instead of goal
         io_b += 12
-        st_b += 2 * (7 if task == "push" else 11) * (precision // 8) - 12
+        st_b += 2 * (9 if task == "push" else 11) * (precision // 8) - 12
     return (io_b * steps_per_launch + st_b) * n
 
 

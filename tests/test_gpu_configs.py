@@ -114,8 +114,12 @@ def test_n1_cube_envs_return_the_f64_reward(envs, O, kuka, kind):
     st = (O.PushState if kind == "push" else O.PickState)(1)
     reset_g, stepf = (O.push_reset_with_goal, O.push_step) if kind == "push" else (O.pick_reset_with_goal, O.pick_step)
     reset_g(kuka, cfg, st, state[3:9].reshape(1, 6))
-    st.aux[0, :6] = state[3:9]                                   # the f64 placement (reset_with_goal takes f32)
-    st.aux[0, 6] = np.linalg.norm(state[3:6] - state[6:9])
+    if kind == "push":       # the cube's height is the engine's on both sides (one step into its fall); the f64 placement in the plane
+        assert abs(st.aux[0, 2] - state[5]) < 1e-15 and abs(state[5] - (0.01 - 10.0 / 240.0 ** 2)) < 1e-15
+        st.aux[0, 0:2] = state[3:5]; st.aux[0, 3:6] = state[6:9]
+    else:
+        st.aux[0, :6] = state[3:9]                               # the f64 placement (reset_with_goal takes f32)
+    st.aux[0, 6] = np.linalg.norm(st.aux[0, 0:3] - st.aux[0, 3:6])
     worst = 0.0
     moved = 0
     d_last = float(np.linalg.norm(state[3:6] - state[6:9], axis=-1))     # np.linalg.norm(..., axis=-1) as the reference calls it (:388)
@@ -123,7 +127,7 @@ def test_n1_cube_envs_return_the_f64_reward(envs, O, kuka, kind):
         # steer the tool through the cube at table height so that the shaped reward is not just the idle -1
         eef, cube = state[:3].astype(np.float64), state[3:6]
         tip = eef - np.array([0.0, 0.0, 0.257 if kind == "pick" else 0.0])
-        want = cube + np.array([0.0, 0.0, 0.012]) + 0.05 * np.sign(cube - tip) * np.array([1, 1, 0])
+        want = np.array([cube[0], cube[1], 0.0]) + np.array([0.0, 0.0, 0.02]) + 0.05 * np.sign(cube - tip) * np.array([1, 1, 0])
         action = np.clip((want - tip) / 0.08, -0.5, 0.5)
         state, reward, done, info = env.step(action)
         o_r, r_r, d_r, s_r, _ = stepf(kuka, cfg, st, action.astype(np.float32).reshape(1, 3))
@@ -235,32 +239,42 @@ def test_n1_env_reproduces_the_reference_runs_first_episodes(envs):
 
 
 def test_n1_push_env_on_the_recorded_push_runs_first_episodes(envs):
-    """The first five episodes of the reference's recorded train_push_with_TD3 run (tests/golden/visdata_push_td3.json, real
-    PyBullet, seed 0; tests/reference_run.py) through the N=1 drop-in `envs.RLPushEnv` on the HIP engine: all five run to the time
-    limit, the arm touches the cube in episodes 1, 2, 3, 5 and not in 4 (the recorded run's own pattern), and episode 4 -- the
-    one that does not depend on Bullet's cube dynamics -- returns the recorded -512.0719 to 1e-4: placement stream, draw counts,
-    the cube's rest height and the reward arithmetic of rl_push_env.py:368-440 against real numbers."""
+    """The first five episodes of the reference's two recorded train_push_with_TD3 runs (tests/golden/visdata_push_td3.json, real
+    PyBullet, seed 0, the same trajectories under two rewards: tests/reference_run.py) through the N=1 drop-in `envs.RLPushEnv` on
+    the HIP engine.  All five run to the time limit; the arm touches the cube in episodes 1, 2, 3, 5 and not in 4 (the recorded runs'
+    own pattern); episode 4 -- which depends on nothing but the cube's free fall, the placement stream, the draw counts and the
+    reward arithmetic of rl_push_env.py:368-440 -- returns the SHIPPED reward's recorded -504.1221 to 3e-4 (eight falling steps above
+    the 1e-5 threshold) and, re-scored with the earlier reward, the other run's -512.0719 to 1e-4; the touched episodes end with the
+    cube within 2.1 cm of where Bullet left it and move it on 149 / 172 / 118 / 43 steps against Bullet's 149 / 192 / 84 / 32."""
     import reference_run as R
     from armenv.td3 import TD3
-    fx = R.push_fixture_returns()
+    org, upd = R.push_fixture_returns("origin"), R.push_fixture_returns("updata")
+    rec = R.push_recorded_observables(5)
     env = envs.RLPushEnv(is_render=False, is_good_view=False)                      # main.py:454
     random.seed(0); np.random.seed(0); torch.manual_seed(0)                        # main.py:459-461
     agent = TD3(9, 3, 0.4, device=DEV)
     agent.actor.load_state_dict({k: torch.from_numpy(v) for k, v in R.actor9_weights().items()})
     got = []
     for ep in range(5):
-        state = env.reset(); done, ret, n, moved = False, 0.0, 0, 0
+        state = env.reset(); done, ret, ret_o, n, moved, M = False, 0.0, 0.0, 0, 0, 0
         cube0 = state[3:6].copy()
+        d_last = float(np.linalg.norm(state[3:6] - state[6:9]))
         while not done:
             action = agent.take_action(state) + np.random.normal(0, 0.4 * 0.98, size=3)        # main.py:481-484
             state, reward, done, info = env.step(action)
-            moved += int(np.abs(state[3:6] - cube0).max() > 0); cube0 = state[3:6].copy()
+            moved += int(np.abs(state[3:5] - cube0[0:2]).max() > 0); cube0 = state[3:6].copy()
+            d_cur = float(np.linalg.norm(state[3:6] - state[6:9]))
+            M += int(abs(d_cur - d_last) >= 1e-5); d_last = d_cur
             ret += reward; n += 1
-        got.append((ret, n, moved))
+            ret_o += reward if (done or reward == 100) else -1.0
+        d_f = float(np.linalg.norm(state[3:6].astype(np.float32) - state[6:9].astype(np.float32)))
+        got.append(dict(ret=ret, ret_origin=ret_o, n=n, moved=moved, M=M, d_f=d_f))
     env.close()
-    assert [n for _, n, _ in got] == [501] * 5
-    assert [m > 0 for _, _, m in got] == [True, True, True, False, True]
-    assert abs(got[3][0] - fx[3]) < 1e-4, (got[3][0], fx[3])
+    assert [g["n"] for g in got] == [501] * 5
+    assert [g["moved"] > 0 for g in got] == [True, True, True, False, True] and [g["M"] > 8 for g in got] == [True, True, True, False, True]
+    assert abs(got[3]["ret"] - upd[3]) < 3e-4 and abs(got[3]["ret_origin"] - org[3]) < 1e-4 and got[3]["M"] == 8, got[3]
+    for k in (0, 1, 2, 4):
+        assert abs(got[k]["d_f"] - rec[k][0]) < 0.021 and abs(got[k]["ret_origin"] - org[k]) < 1.05 and abs(got[k]["M"] - rec[k][1]) <= 35, (k, got[k], rec[k])
 
 
 @pytest.mark.parametrize("precision", [64, 32])
