@@ -271,9 +271,11 @@ def rooflines(task, policy, precision, n, steps_per_launch, launch_us, updates, 
             "traffic": traffic, "traffic_key": key, "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
             "binding_bound": "valu", "valu": valu}
     mfma = None
-    if policy.startswith("actor"):
+    if policy.startswith("actor") or policy == "datd3":
         # 2 * (6*256 + 256*256 + 256*3) flop per env-step; both layers on the MFMA
         af = 2 * (6 * 256 + 256 * 256 + 256 * 3) * n * steps_per_launch
+        if policy == "datd3":     # two actors + two critics (9 -> 256 -> 256 -> 1): DATD3_mlp.py:88-109
+            af = 2 * (2 * (6 * 256 + 256 * 256 + 256 * 3) + 2 * (9 * 256 + 256 * 256 + 256)) * n * steps_per_launch
         if policy == "actor":
             peak, dt, mult = 157.3, "f32 (v_mfma_f32_32x32x2_f32)", 1
         else:   # three f16 MFMA passes per useful multiply-add; priced against the dense f16 MFMA peak
@@ -288,6 +290,13 @@ def golden_actor():
     g = np.load(os.path.join(ROOT, "tests", "golden", "td3_actor_seed0.npz"))
     return {k: torch.from_numpy(g[k.replace(".", "_")]) for k in
             ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+
+
+def golden_datd3():
+    """the four nets of DATD3_MLP(6, 3, 0.7) under torch.manual_seed(0): golden G11 (produced by importing the reference's algo.DATD3)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "datd3_take_action_seed0.npz"))
+    keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+    return [{k: torch.from_numpy(g["%s_%s" % (n_, k.replace(".", "_"))]) for k in keys} for n_ in ("actor1", "actor2", "critic1", "critic2")]
 
 
 def secondary_leg(envs, dev, task, n, policy, precision, launches, pre_launches, fence_steps=0):
@@ -305,6 +314,8 @@ def secondary_leg(envs, dev, task, n, policy, precision, launches, pre_launches,
         pool = torch.randn((S, n, 3), device=dev, generator=gen) * sig
         if task == "reach":
             pool.clamp_(-bound, bound)
+    elif policy == "datd3":          # DATD3_MLP.take_action fused: two actors, two critics, the better-valued action
+        e.set_policy_datd3(*golden_datd3(), action_bound=bound, noise_sigma=sig, noise_clip=bound)
     else:
         e.set_policy(policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if task == "reach" else 1e9,
                      actor_state_dict=golden_actor() if policy.startswith("actor") else None)
@@ -983,6 +994,8 @@ def main():
             leg("config3_actor_f32", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor", args.precision, 4, 3))
             leg("config3_actor_f16x3", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "actor_f16x3", args.precision, 4, 3))
             leg("config4_push", lambda: secondary_leg(envs, dev, "push", 32768, "external", args.precision, 5, 6, args.fence_steps))
+            # beyond the configs: DATD3_MLP.take_action (a consumer north_star names) folded into the same rollout kernel
+            leg("datd3_fused", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "datd3", args.precision, 2, 2))
         if not multi and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline(args.precision))
         # the scalars a record that keeps only flat `config` values would otherwise lose
@@ -992,7 +1005,7 @@ def main():
         for k_ in ("value_median", "value_min", "value_max", "launch_us_median", "launch_us_min", "launch_us_max"):
             if k_ in line:
                 cfg[k_] = line[k_]
-        for k_, leg_ in (("actor_f32", "config3_actor_f32"), ("actor_f16x3", "config3_actor_f16x3"), ("push", "config4_push")):
+        for k_, leg_ in (("actor_f32", "config3_actor_f32"), ("actor_f16x3", "config3_actor_f16x3"), ("push", "config4_push"), ("datd3", "datd3_fused")):
             if isinstance(line.get(leg_), dict) and "us_per_step" in line[leg_]:
                 cfg[k_ + "_us_per_step"] = line[leg_]["us_per_step"]
                 cfg[k_ + "_env_steps_per_s"] = line[leg_]["value_kernel"]

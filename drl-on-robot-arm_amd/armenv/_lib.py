@@ -8,7 +8,7 @@ ABI_VERSION = 5
 TASK_REACH, TASK_PUSH, TASK_PICK = 0, 1, 2
 ROBOT_KUKA, ROBOT_DIANA = 0, 1
 FK_AUTO, FK_GENERIC = 0, 1
-POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR, POLICY_ACTOR_F16X3 = 0, 1, 2, 3
+POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR, POLICY_ACTOR_F16X3, POLICY_DATD3 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ARMENV_LIB: an alternative build of the same library (A/B timing of two kernel versions inside one GPU session)
@@ -50,6 +50,10 @@ class ArmEnvConfig(C.Structure):
     ]
 
 
+class ArmEnvMlp(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("W1", "b1", "W2", "b2", "W3", "b3")]
+
+
 class ArmEnvHerArgs(C.Structure):
     _fields_ = [
         ("T", C.c_int64), ("N", C.c_int64), ("ring_base", C.c_int64), ("ring_cap", C.c_int64),
@@ -83,6 +87,9 @@ SYMBOLS = {
     "armenv_summary": (C.c_int, [_P, _P, _P]),
     "armenv_set_policy": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
     "armenv_actor_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
+    "armenv_set_policy_datd3": (C.c_int, [_P, C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp),
+                                          C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "armenv_datd3_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "armenv_count_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P]),
     "armenv_write_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P, _P, _P]),
     "armenv_her_sample": (C.c_int, [C.c_int32, C.POINTER(ArmEnvHerArgs), _P]),

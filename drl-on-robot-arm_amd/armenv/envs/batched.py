@@ -196,6 +196,36 @@ class BatchedArmEnv:
         torch.cuda.current_stream(self.device).synchronize()
         self._policy = kind
 
+    def set_policy_datd3(self, actor1, actor2, critic1, critic2, action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7):
+        """Install DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) as the fused policy of
+        `rollout(actions=None)` / `step(None)`: a1 = actor1(s), a2 = actor2(s), the action whose own critic values it higher
+        (q1 = critic1(s, a1) >= q2 = critic2(s, a2) -> a1), then a = clip(a + N(0, noise_sigma), +-noise_clip).  Each argument is
+        a state dict of the reference's PolicyNet / QValueNet (fc1.weight ... fc3.bias).  Reach handles only."""
+        keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+        keep, mlps = [], []
+        for sd in (actor1, actor2, critic1, critic2):
+            w = [sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in keys]
+            keep.append(w)
+            mlps.append(L.ArmEnvMlp(*[t.data_ptr() for t in w]))
+        hidden = int(keep[0][0].shape[0])
+        with self._ordered():
+            L.check(self._lib.armenv_set_policy_datd3(self._h, *[C.byref(m) for m in mlps], hidden, float(action_bound),
+                                                      float(noise_sigma), float(noise_clip), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._policy = "datd3"
+
+    def datd3_forward(self, states, want_q=False):
+        """DATD3_MLP.take_action without noise for states f32 [n, 6]: actions [n, 3] (+ q1, q2 [n], picked_actor u8 [n])."""
+        st = states.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, 6)
+        n = st.shape[0]
+        out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        q1 = torch.empty(n, dtype=torch.float32, device=self.device) if want_q else None
+        q2 = torch.empty(n, dtype=torch.float32, device=self.device) if want_q else None
+        pk = torch.empty(n, dtype=torch.uint8, device=self.device) if want_q else None
+        with self._ordered():
+            L.check(self._lib.armenv_datd3_forward(self._h, n, _ptr(st), _ptr(out), _ptr(q1), _ptr(q2), _ptr(pk), self._stream()))
+        return (out, q1, q2, pk) if want_q else out
+
     def actor_forward(self, states):
         """TD3_MLP.take_action without noise (algo/TD3/TD3_mlp.py:82-97) for states f32 [n, obs_dim]."""
         st = states.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, self.obs_dim)

@@ -25,7 +25,7 @@ int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, con
   float *W1P = actor_buf, *W2P = actor_buf + n1, *B2W3 = actor_buf + n1 + n2;
   _Float16 *W2H = reinterpret_cast<_Float16 *>(actor_buf + n1 + n2 + n3), *W2L = W2H + n2;
   hipLaunchKernelGGL(actor_pack_kernel, dim3((unsigned)(n2 / 256)), dim3(256), 0, s, W1, b1, W2, b2, W3, in_dim, W1P, W2P, B2W3,
-                     W2H, W2L);
+                     W2H, W2L, 3);
   pol.actor_h.W2H = reinterpret_cast<const half8 *>(W2H);
   pol.actor_h.W2L = reinterpret_cast<const half8 *>(W2L);
   HIP_TRY(hipGetLastError());
@@ -38,6 +38,77 @@ int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, con
   for (int k = 0; k < 3; ++k) pol.actor.b3[k] = hb3[k];
   pol.actor.bound = bound;
   pol.actor.in_dim = in_dim;
+  pol.actor.raw = 0;
+  return ARMENV_OK;
+}
+
+// DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) for n reach states (6 floats): actions [n][3], and (nullable)
+// the two Q values and which actor was picked.
+static __global__ __launch_bounds__(256) void datd3_kernel(const ActorParams *nets, const ActorParamsH *nets_h, int64_t n, const float *states,
+                                                    float *actions, float *q1_out, float *q2_out, uint8_t *picked_out) {
+  __shared__ float4 w1_lds[ACTOR_W1_LDS_FLOATS_H / 4];
+  __shared__ uint4 w2_ring[ACTOR_RING_UINT4];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 256: every wave is live
+  const int64_t ic = i < n ? i : n - 1;
+  float s[6], a[3], q1, q2;
+  int picked;
+  static_for<0, 6>([&](auto DI) { constexpr int d = DI; s[d] = states[ic * 6 + d]; });
+  datd3_forward_wg(nets, nets_h, w1_lds, w2_ring, 4, s, a, q1, q2, picked);
+  actor_ring_drain();
+  if (i < n) {
+    actions[3 * i] = a[0]; actions[3 * i + 1] = a[1]; actions[3 * i + 2] = a[2];
+    if (q1_out) q1_out[i] = q1;
+    if (q2_out) q2_out[i] = q2;
+    if (picked_out) picked_out[i] = (uint8_t)picked;
+  }
+}
+
+// armenv_set_policy_datd3: the four nets packed like set_actor packs one (the W2P table of the exact-f32 actor is not needed: the
+// fused DATD3 policy runs the f16x3 passes only), every net as a NINE-input net (datd3_forward_wg): the actors' W1 rows carry zeros
+// in columns obs_dim..8, the critics' W1 is [hidden][obs_dim + 3] = 9 wide as it is.
+int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bound, hipStream_t s) {
+  const size_t n1 = ACTOR_HID * 12, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
+  const size_t per_net = n1 + n2 + n3 + n2;                      // floats: W1P | W2P (unused scratch of the packer) | B2W3 | W2H + W2L
+  const size_t tab = (4 * sizeof(ActorParams) + 4 * sizeof(ActorParamsH) + sizeof(float) - 1) / sizeof(float);
+  if (!datd3_buf && hipMalloc(reinterpret_cast<void **>(&datd3_buf), (4 * per_net + tab) * sizeof(float)) != hipSuccess)
+    return fail(ARMENV_ENOMEM, "armenv_set_policy_datd3: hipMalloc failed");
+  ActorParams A[4];
+  ActorParamsH H[4];
+  for (int k = 0; k < 4; ++k) {
+    const ArmEnvMlp &m = *nets[k];
+    const bool critic = k >= 2;
+    float *base = datd3_buf + k * per_net;
+    float *W1P = base, *W2P = base + n1, *B2W3 = base + n1 + n2;
+    _Float16 *W2H = reinterpret_cast<_Float16 *>(base + n1 + n2 + n3), *W2L = W2H + n2;
+    hipLaunchKernelGGL(actor_pack_kernel, dim3((unsigned)(n2 / 256)), dim3(256), 0, s, m.W1, m.b1, m.W2, m.b2, m.W3,
+                       critic ? obs_dim + 3 : obs_dim, W1P, W2P, B2W3, W2H, W2L, critic ? 1 : 3);
+    HIP_TRY(hipGetLastError());
+    float hb3[3] = {0.f, 0.f, 0.f};
+    HIP_TRY(hipMemcpyAsync(hb3, m.b3, sizeof(float) * (critic ? 1 : 3), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    A[k].W1P = W1P;
+    A[k].W2P = reinterpret_cast<const float4 *>(W2P);
+    A[k].B2W3 = reinterpret_cast<const float4 *>(B2W3);
+    for (int j = 0; j < 3; ++j) A[k].b3[j] = hb3[j];
+    A[k].bound = bound;
+    A[k].in_dim = 9;
+    A[k].raw = critic ? 1 : 0;
+    H[k].W2H = reinterpret_cast<const half8 *>(W2H);
+    H[k].W2L = reinterpret_cast<const half8 *>(W2L);
+  }
+  char *t = reinterpret_cast<char *>(datd3_buf + 4 * per_net);
+  HIP_TRY(hipMemcpyAsync(t, A, sizeof A, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(t + sizeof A, H, sizeof H, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  pol.datd3 = reinterpret_cast<const ActorParams *>(t);
+  pol.datd3_h = reinterpret_cast<const ActorParamsH *>(t + sizeof A);
+  return ARMENV_OK;
+}
+
+int EngineBase::datd3_forward(int64_t n, const float *states, float *actions, float *q1, float *q2, uint8_t *picked, hipStream_t s) {
+  if (!pol.datd3) return fail(ARMENV_ESTATE, "armenv_datd3_forward: no DATD3 policy installed (armenv_set_policy_datd3)");
+  hipLaunchKernelGGL(datd3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pol.datd3, pol.datd3_h, n, states, actions, q1, q2, picked);
+  HIP_TRY(hipGetLastError());
   return ARMENV_OK;
 }
 
@@ -341,7 +412,7 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
     return fail(ARMENV_ESTATE, "armenv_step: ik_updates_dev needs a handle created with fence_counters >= 1 (the bookkeeping build of the kernels)");
   if (diag_dev && env->cfg.fence_counters != 2)
     return fail(ARMENV_ESTATE, "armenv_step: diag_dev needs a handle created with fence_counters = 2");
-  if (diag_dev && !action_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
+  if (diag_dev && !action_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3 || env->eng->pol.kind == ARMENV_POLICY_DATD3))
     return fail(ARMENV_ESTATE, "armenv_step: diag_dev is not available with a fused actor");
   StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};
   if (!action_dev) {   // fused policy: a one-step rollout
@@ -430,6 +501,39 @@ int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const fl
   return ARMENV_OK;
 }
 
+int armenv_set_policy_datd3(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMlp *actor2, const ArmEnvMlp *critic1,
+                            const ArmEnvMlp *critic2, int32_t hidden_dim, float action_bound, float noise_sigma, float noise_clip,
+                            void *stream) {
+  ENV_ENTER(env);
+  const ArmEnvMlp *nets[4] = {actor1, actor2, critic1, critic2};
+  for (const ArmEnvMlp *m : nets)
+    if (!m || !m->W1 || !m->b1 || !m->W2 || !m->b2 || !m->W3 || !m->b3) return fail(ARMENV_EINVAL, "armenv_set_policy_datd3: NULL network or weight pointer");
+  if (!(noise_sigma >= 0.f && noise_clip > 0.f)) return fail(ARMENV_EINVAL, "armenv_set_policy_datd3: need noise_sigma >= 0 and noise_clip > 0");
+  if (hidden_dim != ACTOR_HID)
+    return fail(ARMENV_EINVAL, "armenv_set_policy_datd3: hidden_dim %d; the fused nets are built for %d (config.py:56)", hidden_dim, ACTOR_HID);
+  if (env->cfg.task != ARMENV_TASK_REACH)
+    return fail(ARMENV_ESTATE, "armenv_set_policy_datd3: the fused DATD3 policy is built for the reach task (6-float observations; the critics of "
+                               "push / pick would take 12 inputs)");
+  if (env->cfg.num_envs % 64 != 0) return fail(ARMENV_EINVAL, "armenv_set_policy_datd3: num_envs must be a multiple of 64 (full wavefronts)");
+  if (env->cfg.fence_counters)
+    return fail(ARMENV_ESTATE, "armenv_set_policy_datd3: not on a bookkeeping handle (fence_counters, ik_tip_offset)");
+  const int rc = env->eng->set_datd3(nets, 6, action_bound, static_cast<hipStream_t>(stream));
+  if (rc != ARMENV_OK) return rc;
+  env->eng->pol.kind = ARMENV_POLICY_DATD3;
+  env->eng->pol.sigma = noise_sigma;
+  env->eng->pol.clip = noise_clip;
+  env->eng->pol.bound = action_bound;
+  return ARMENV_OK;
+}
+
+int armenv_datd3_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, float *q1_dev, float *q2_dev,
+                         uint8_t *picked_dev, void *stream) {
+  ENV_ENTER(env);
+  if (n < 0 || (n > 0 && (!states_dev || !actions_dev))) return fail(ARMENV_EINVAL, "armenv_datd3_forward: bad arguments");
+  if (n == 0) return ARMENV_OK;
+  return env->eng->datd3_forward(n, states_dev, actions_dev, q1_dev, q2_dev, picked_dev, static_cast<hipStream_t>(stream));
+}
+
 int armenv_actor_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, void *stream) {
   ENV_ENTER(env);
   if (n < 0 || (n > 0 && (!states_dev || !actions_dev))) return fail(ARMENV_EINVAL, "armenv_actor_forward: bad arguments");
@@ -450,7 +554,7 @@ int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *
     return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev needs a handle created with fence_counters >= 1 (the bookkeeping build of the kernels)");
   if (diag_dev && env->cfg.fence_counters != 2)
     return fail(ARMENV_ESTATE, "armenv_rollout: diag_dev needs a handle created with fence_counters = 2");
-  if ((ik_updates_dev || diag_dev) && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3))
+  if ((ik_updates_dev || diag_dev) && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3 || env->eng->pol.kind == ARMENV_POLICY_DATD3))
     return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev / diag_dev are not available with a fused actor");
   StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};
   return env->eng->rollout(steps, actions_dev, io, actions_out_dev, static_cast<hipStream_t>(stream));

@@ -30,7 +30,8 @@ struct ActorParams {
   const float4 *B2W3;  // [256]: (b2[n], W3[0][n], W3[1][n], W3[2][n])
   float b3[3];
   float bound;
-  int32_t in_dim;      // 6 (reach obs) or 9 (push obs)
+  int32_t in_dim;      // 6 (reach obs) or 9 (push obs; DATD3: every net staged with 9 inputs, see datd3_forward_wg)
+  int32_t raw;         // 0: out = bound * tanh(z + b3) (PolicyNet); 1: out = z + b3 (QValueNet, net_mlp.py:43-58: row 0 of the table is fc3)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -55,14 +56,15 @@ constexpr int ACTOR_W1_LDS_FLOATS = ACTOR_W1A_FLOATS + ACTOR_HID * 4 + ACTOR_HID
 
 // fills the tables from W1P (global, [256][12] f32: w0..w8, 0, 0, b1) and B2W3 ([256] float4); every thread of the
 // block must call this once, then __syncthreads()
-AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, int in_dim) {
+AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, int in_dim, int nthreads = 0) {
+  if (nthreads == 0) nthreads = blockDim.x;      // (a ragged workgroup whose dead waves have exited passes its live thread count)
   float *w1a = reinterpret_cast<float *>(lds);
-  for (int i = threadIdx.x; i < ACTOR_W1A_FLOATS; i += blockDim.x) {
+  for (int i = threadIdx.x; i < ACTOR_W1A_FLOATS; i += nthreads) {
     const int l = i & 63, m = (i >> 6) % ACTOR_NK, R = (i >> 6) / ACTOR_NK;
     const int row = 32 * R + (l & 31), ka = 2 * m + (l >> 5);
     w1a[i] = ka < in_dim ? W1P[row * 12 + ka] : (ka == in_dim ? W1P[row * 12 + 11] : 0.f);
   }
-  for (int i = threadIdx.x; i < ACTOR_HID; i += blockDim.x) {
+  for (int i = threadIdx.x; i < ACTOR_HID; i += nthreads) {
     const float4 c = B2W3[i];
     lds[ACTOR_W1A_FLOATS / 4 + i] = c;
     reinterpret_cast<float *>(lds + ACTOR_W1A_FLOATS / 4 + ACTOR_HID)[i] = c.x;
@@ -286,9 +288,10 @@ constexpr int ACTOR_W1_LDS_FLOATS_H = ACTOR_W1_LDS_FLOATS + ACTOR_W1H_FLOATS;
 // W1aug = [W1 | b1 | 0...] split hi / lo in the A-operand order of v_mfma_f32_32x32x16_f16: lane l of row tile R holds
 // W1aug[32 R + (l & 31)][8 (l >> 5) + j], j = 0..7.  Every thread of the block calls this once (before the __syncthreads()
 // that follows actor_stage_w1); w1_lds must have ACTOR_W1_LDS_FLOATS_H floats.
-AE_DEV void actor_stage_w1h(const float *W1P, float4 *w1_lds, int in_dim) {
+AE_DEV void actor_stage_w1h(const float *W1P, float4 *w1_lds, int in_dim, int nthreads = 0) {
+  if (nthreads == 0) nthreads = blockDim.x;
   _Float16 *t = reinterpret_cast<_Float16 *>(w1_lds + ACTOR_W1_LDS_FLOATS / 4);
-  for (int i = threadIdx.x; i < 8 * 64 * 8; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 8 * 64 * 8; i += nthreads) {
     const int j = i & 7, l = (i >> 3) & 63, R = i >> 9;
     const int row = 32 * R + (l & 31), k = 8 * (l >> 5) + j;
     const float x = k < in_dim ? W1P[row * 12 + k] : (k == in_dim ? W1P[row * 12 + 11] : 0.f);
@@ -622,13 +625,55 @@ AE_DEV void actor_forward_wg_f16x3_impl(const ActorParams &A, const ActorParamsH
     });
     if constexpr (FULL) { ATL(4); ATL_FLUSH(t); }
   }
-  static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
+  if (A.raw) static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = z[o] + A.b3[o]; });          // QValueNet: net_mlp.py:57
+  else static_for<0, 3>([&](auto OI) { constexpr int o = OI; out[o] = tanhf(z[o] + A.b3[o]) * A.bound; });   // net_mlp.py:40
 }
 template <int IN>
 AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, const float4 *w1_lds, uint4 *ring, int nw,
                                    const float (&s)[IN], float (&out)[3]) {
   if (__builtin_expect(nw == 4, 1)) actor_forward_wg_f16x3_impl<IN, true>(A, H, w1_lds, ring, nw, s, out);
   else actor_forward_wg_f16x3_impl<IN, false>(A, H, w1_lds, ring, nw, s, out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) for the 256 envs of a workgroup:
+//     a1 = actor1(s), a2 = actor2(s), q1 = critic1(s, a1), q2 = critic2(s, a2), action = a1 if q1 >= q2 else a2
+// as four passes of the f16x3 workgroup actor above, one network after the other through the same LDS tables and the same W2 ring.
+// All four nets run as NINE-input nets: the critics take cat(s, a) (net_mlp.py:55; reach: 6 + 3), the actors see s padded with
+// three zeros against zero weight columns (their packed W1 rows carry zeros beyond in_dim: exact), so that ONE copy of the pass
+// serves the four calls (a pass is 2 400 instructions; the loop over the nets keeps it at that).  Between two nets every wave
+// drains its own ring DMA, the workgroup meets (everyone has finished reading the previous net's tables and ring), the tables and
+// the resident + first streamed k-steps of the next net are staged, and the workgroup meets again: ~48 KB of LDS writes and 112 KB of
+// LDS DMA per net and workgroup, from L2-resident weights.
+// nets / nets_h: device arrays [4] = actor1, actor2, critic1, critic2 (in_dim 9; the critics raw = 1 with fc3 in row 0 of their
+// B2W3 table).  s: the lane's observation (6 floats).  nw: live waves (a ragged last workgroup stages with its live threads).
+// picked: 0 actor1 / 1 actor2.
+AE_DEV void datd3_forward_wg(const ActorParams *nets, const ActorParamsH *nets_h, float4 *w1_lds, uint4 *ring, int nw, const float (&s)[6],
+                             float (&out)[3], float &q1, float &q2, int &picked) {
+  float x[9], a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};   // (no array indexed by `net`: a run-time subscript would put it in scratch)
+  q1 = q2 = 0.f;
+  static_for<0, 6>([&](auto DI) { constexpr int d = DI; x[d] = s[d]; });
+  x[6] = x[7] = x[8] = 0.f;
+  const int live = nw * 64;
+#pragma unroll 1
+  for (int net = 0; net < 4; ++net) {
+    const ActorParams A = nets[net];
+    const ActorParamsH H = nets_h[net];
+    actor_ring_drain();
+    __syncthreads();
+    actor_stage_w1(A.W1P, w1_lds, A.B2W3, 9, live);
+    actor_stage_w1h(A.W1P, w1_lds, 9, live);
+    actor_ring_init(H, ring, nw);
+    __syncthreads();
+    if (net >= 2) static_for<0, 3>([&](auto KI) { constexpr int k = KI; x[6 + k] = net == 2 ? a1[k] : a2[k]; });      // cat(s, a_i), net_mlp.py:55
+    float o[3];
+    actor_forward_wg_f16x3<9>(A, H, w1_lds, ring, nw, x, o);
+    static_for<0, 3>([&](auto KI) { constexpr int k = KI; a1[k] = net == 0 ? o[k] : a1[k]; a2[k] = net == 1 ? o[k] : a2[k]; });
+    q1 = net == 2 ? o[0] : q1;
+    q2 = net == 3 ? o[0] : q2;
+  }
+  picked = q1 >= q2 ? 0 : 1;                                                                               // DATD3_mlp.py:107
+  static_for<0, 3>([&](auto KI) { constexpr int k = KI; out[k] = picked ? a2[k] : a1[k]; });
 }
 
 }  // namespace armenv

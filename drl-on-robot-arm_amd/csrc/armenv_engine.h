@@ -75,6 +75,7 @@ template <class C> static inline bool chain_matches(const ArmEnvChain &ch) {
 struct EngineBase {
   virtual ~EngineBase() {
     if (actor_buf) (void)hipFree(actor_buf);
+    if (datd3_buf) (void)hipFree(datd3_buf);
   }
   virtual int init(const ArmEnvConfig &cfg) = 0;
   virtual int reset(const uint8_t *mask, const float *goal, float *obs, hipStream_t s) = 0;
@@ -84,6 +85,9 @@ struct EngineBase {
   float *actor_buf = nullptr;   // packed W1P | W2P | B2W3 on the handle's device
   int set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
                 int in_dim, float bound, hipStream_t s);
+  float *datd3_buf = nullptr;   // four packed nets + the device arrays of their ActorParams / ActorParamsH (armenv_set_policy_datd3)
+  int set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bound, hipStream_t s);
+  int datd3_forward(int64_t n, const float *states, float *actions, float *q1, float *q2, uint8_t *picked, hipStream_t s);
   int actor_forward(int64_t n, const float *states, float *actions, hipStream_t s);
   virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
   virtual int ik(int64_t n, const double *q, const double *tgt, double *q_out, int32_t *iters, hipStream_t s) = 0;
@@ -198,7 +202,7 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
       K.place_z = (T)cfg.push_place_z;
       K.tool_radius = (T)cfg.push_tool_radius;
       K.tool_below = (T)cfg.push_tool_below;
-      K.erp = (T)cfg.push_contact_erp;
+      K.erp_dt = (T)(cfg.push_contact_erp / cfg.push_dt);
       K.split = (T)cfg.push_contact_split;
       K.fric_dv = (T)(cfg.push_friction * cfg.push_gravity * cfg.push_dt);
       K.dt = (T)cfg.push_dt;
@@ -306,7 +310,7 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
   }
   template <int POLICY, class LaneX = Lane>
   void launch_rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
-    constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
+    constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3 || POLICY == ARMENV_POLICY_DATD3;
     if constexpr (!kActor) {
       if (two_waves()) {
         hipLaunchKernelGGL((env_rollout_kernel<LaneX, T, POLICY, 2>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, pol,
@@ -334,7 +338,7 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
   }
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     // lane-asynchronous form (ArmEnvConfig.rollout_ready_lanes > 0): external actions or the in-kernel random policy
-    const bool fused_actor = !actions && (pol.kind == ARMENV_POLICY_ACTOR || pol.kind == ARMENV_POLICY_ACTOR_F16X3);
+    const bool fused_actor = !actions && (pol.kind == ARMENV_POLICY_ACTOR || pol.kind == ARMENV_POLICY_ACTOR_F16X3 || pol.kind == ARMENV_POLICY_DATD3);
     if (ready_lanes > 0 && steps > 1 && !fused_actor) {
       if (fence_on) {
         with_book_lane([&](auto *tag) {
@@ -359,6 +363,9 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
     if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR_F16X3) launch_rollout<ARMENV_POLICY_ACTOR_F16X3>(steps, actions, io0, actions_out, s);
+    else if (pol.kind == ARMENV_POLICY_DATD3) {
+      if constexpr (Lane::kObs == 6) launch_rollout<ARMENV_POLICY_DATD3>(steps, actions, io0, actions_out, s);      // (armenv_set_policy_datd3 refuses the other tasks)
+    }
     else launch_rollout<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
   }
   int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {

@@ -28,7 +28,7 @@ template <typename T> struct EnvCold {
   T fall_c;                 // g dt^2 / 2: the cube is fall_c k (k + 1) below its spawn height after k free steps
   T fall_keep;              // 1 - push_drop_relax
   T place_z;                // spawn height
-  T tool_radius, tool_below, erp, split, fric_dv, dt;
+  T tool_radius, tool_below, erp_dt, split, fric_dv, dt;   // erp_dt = push_contact_erp / push_dt
 };
 
 template <typename T> struct EnvParams {
@@ -257,6 +257,8 @@ struct PolicyParams {
   float bound;       // actor output scale
   ActorParams actor; // ARMENV_POLICY_ACTOR / _F16X3
   ActorParamsH actor_h;  // ARMENV_POLICY_ACTOR_F16X3 only
+  const ActorParams *datd3;      // ARMENV_POLICY_DATD3: device arrays [4] = actor1, actor2, critic1, critic2 (armenv_actor.h datd3_forward_wg)
+  const ActorParamsH *datd3_h;
 };
 
 // TD3_MLP.take_action (/root/reference/algo/TD3/TD3_mlp.py:82-97) for n states; MODE 0 exact f32, 1 f16x3.
@@ -281,8 +283,9 @@ __global__ __launch_bounds__(256) void actor_kernel(ActorParams A, ActorParamsH 
 }
 
 // torch Linear layouts ([out][in]) -> the operand layouts of armenv_actor.h
+// out_dim: rows of W3 (3: PolicyNet; 1: QValueNet, whose fc3 becomes row 0 of the table and rows 1, 2 are zero)
 static __global__ void actor_pack_kernel(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
-                                  int in_dim, float *W1P, float *W2P, float *B2W3, _Float16 *W2H, _Float16 *W2L) {
+                                  int in_dim, float *W1P, float *W2P, float *B2W3, _Float16 *W2H, _Float16 *W2L, int out_dim) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ACTOR_HID * ACTOR_HID) {   // f16 hi/lo split of W2 in the 32x32x16 A-operand order
     const int j = t & 7, lane = (t >> 3) & 63, nt = (t >> 9) & 3, part = (t >> 11) & 1, ks = t >> 12;
@@ -301,7 +304,7 @@ static __global__ void actor_pack_kernel(const float *W1, const float *b1, const
   }
   if (t < ACTOR_HID * 4) {
     const int n = t >> 2, c = t & 3;
-    B2W3[t] = c == 0 ? b2[n] : W3[(c - 1) * ACTOR_HID + n];
+    B2W3[t] = c == 0 ? b2[n] : (c - 1 < out_dim ? W3[(c - 1) * ACTOR_HID + n] : 0.f);
   }
 }
 
@@ -711,6 +714,8 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
   // frame's xy, reaching tool_below under it), velocity-level contact along the horizontal normal unless the tool sits less deep in the
   // cube from above than from the side (then it presses the cube onto the table), Coulomb friction once the cube has landed, integration.
   AE_DEV void contact_dyn(const EnvParams<T> &P, const EnvCold<T> &K, const T (&p)[3], int k) {
+    // square roots and quotients through v_rsq + Newton (fast_rsqrt: a few ulp; an IEEE f64 sqrt and three divides were 7 % of the
+    // push step, and most wave-steps have a lane in here), the overlap test on squared lengths
     const T h = P.push_cube_half, r = K.tool_radius, dt = K.dt;
     const T lo = p[2] - K.tool_below;
     if (lo < cube[2] + h) {
@@ -718,11 +723,13 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
       const T qx = p[0] < lx ? lx : (p[0] > hx ? hx : p[0]);
       const T qy = p[1] < ly ? ly : (p[1] > hy ? hy : p[1]);
       const T gx = qx - p[0], gy = qy - p[1];
-      const T gap = M::sqrt(gx * gx + gy * gy);
-      if (gap < r) {
+      const T g2 = gx * gx + gy * gy;
+      if (g2 < r * r) {
         T pen, nx, ny;
-        if (gap > T(1e-9)) { pen = r - gap; nx = gx / gap; ny = gy / gap; }
-        else {   // tool axis inside the footprint: out through the nearest face (-x, +x, -y, +y in this order on ties)
+        if (g2 > T(1e-18)) {
+          const T rs = fast_rsqrt<T>(g2);
+          pen = r - g2 * rs; nx = gx * rs; ny = gy * rs;
+        } else {   // tool axis inside the footprint: out through the nearest face (-x, +x, -y, +y in this order on ties)
           const T e0 = hx - p[0], e1 = p[0] - lx, e2 = hy - p[1], e3 = p[1] - ly;
           T eb = e0; nx = T(-1); ny = T(0);
           if (e1 < eb) { eb = e1; nx = T(1); ny = T(0); }
@@ -733,19 +740,20 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
         const T pen_v = (cube[2] + h) - lo;
         if (!(pen_v < pen)) {
           const T vn = vel[0] * nx + vel[1] * ny;
-          const T tgt = pen < K.split ? K.erp * pen / dt : T(0);
+          const T tgt = pen < K.split ? K.erp_dt * pen : T(0);
           if (vn < tgt) { vel[0] += (tgt - vn) * nx; vel[1] += (tgt - vn) * ny; }
         }
       }
     }
-    if (k >= K.fall_land) {
-      const T sp = M::sqrt(vel[0] * vel[0] + vel[1] * vel[1]);
-      if (sp > T(0)) {
-        const T f = sp > K.fric_dv ? (sp - K.fric_dv) / sp : T(0);
-        vel[0] *= f; vel[1] *= f;
+    const T v2 = vel[0] * vel[0] + vel[1] * vel[1];
+    if (v2 > T(0)) {
+      if (k >= K.fall_land) {
+        const T f = T(1) - K.fric_dv * fast_rsqrt<T>(v2);       // (|v| - dec) / |v|
+        const T fc = f > T(0) ? f : T(0);
+        vel[0] *= fc; vel[1] *= fc;
       }
+      cube[0] += vel[0] * dt; cube[1] += vel[1] * dt;
     }
-    cube[0] += vel[0] * dt; cube[1] += vel[1] * dt;
   }
 
   // Pick: gripper and cube after the arm's teleport (rl_pick_env.py:349 stepSimulation, :412-417 getClosestPoints ->
@@ -983,13 +991,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 template <class Lane, typename T, int POLICY, int WAVES = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const float *actions, StepIO io0, float *actions_out) {
-  constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3;
+  constexpr bool kDatd3 = POLICY == ARMENV_POLICY_DATD3;     // four f16x3 passes per step; tables and ring re-staged per net (datd3_forward_wg)
+  constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3 || kDatd3;
+  constexpr bool kRing = POLICY == ARMENV_POLICY_ACTOR_F16X3 || kDatd3;
   static_assert(WAVES == 1 || (WAVES == 2 && !kActor), "the fused actors need the whole register file");
+  static_assert(!kDatd3 || Lane::kObs == 6, "the fused DATD3 policy is built for 6-float observations (reach)");
   constexpr bool kPrefetch = POLICY == ARMENV_POLICY_EXTERNAL && WAVES == 1;
-  __shared__ float4 w1_lds[kActor ? (POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_W1_LDS_FLOATS_H : ACTOR_W1_LDS_FLOATS) / 4 : 1];
-  __shared__ uint4 w2_ring[POLICY == ARMENV_POLICY_ACTOR_F16X3 ? ACTOR_RING_UINT4 : 1];
+  __shared__ float4 w1_lds[kActor ? (kRing ? ACTOR_W1_LDS_FLOATS_H : ACTOR_W1_LDS_FLOATS) / 4 : 1];
+  __shared__ uint4 w2_ring[kRing ? ACTOR_RING_UINT4 : 1];
   int nw = 4;   // live waves of this workgroup (the last one may be ragged; num_envs is a multiple of 64)
-  if constexpr (kActor) {   // layer-1 / layer-3 tables staged once per launch
+  if constexpr (kDatd3) {
+    const int64_t left = P.n - (int64_t)blockIdx.x * blockDim.x;
+    nw = (int)(((left < (int64_t)blockDim.x ? left : (int64_t)blockDim.x) + 63) >> 6);
+  } else if constexpr (kActor) {   // layer-1 / layer-3 tables staged once per launch
     actor_stage_w1(pol.actor.W1P, w1_lds, pol.actor.B2W3, Lane::kObs);
     if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) {   // W2 streams through the ring every step
       actor_stage_w1h(pol.actor.W1P, w1_lds, Lane::kObs);
@@ -1008,7 +1022,7 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
   Lane L;
   L.load(P, i);
   uint32_t episode = (POLICY != ARMENV_POLICY_EXTERNAL) ? P.episode[i] : 0u;
-  if constexpr (POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3) L.refresh_obs(P);
+  if constexpr (kActor) L.refresh_obs(P);
   float an[3] = {0.f, 0.f, 0.f};
   if constexpr (kPrefetch) {
     an[0] = actions[3 * i]; an[1] = actions[3 * i + 1]; an[2] = actions[3 * i + 2];
@@ -1044,6 +1058,13 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
         float s[kObs];
         L.policy_obs(s);
         actor_forward_wg_f16x3<kObs>(pol.actor, pol.actor_h, w1_lds, w2_ring, nw, s, mu);
+      } else if constexpr (kDatd3) {
+        if constexpr (kObs == 6) {
+          float s[6], q1, q2;
+          int picked;
+          L.policy_obs(s);
+          datd3_forward_wg(pol.datd3, pol.datd3_h, w1_lds, w2_ring, nw, s, mu, q1, q2, picked);    // take_action, DATD3_mlp.py:88-109
+        }
       }
       float nz[3];
       // the episode index of the stream is the number of resets so far minus one (the running episode)
@@ -1084,7 +1105,7 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     }
   }
   L.store(P, i);
-  if constexpr (POLICY == ARMENV_POLICY_ACTOR_F16X3) actor_ring_drain();
+  if constexpr (kRing) actor_ring_drain();
   if constexpr (Lane::kFence) flush_schedule(P.counters, w_trips, (uint32_t)steps);
   flush_env_steps(P.counters, i, (unsigned long long)n * (unsigned long long)steps);
 }

@@ -53,7 +53,8 @@ enum {
   ARMENV_POLICY_EXTERNAL = 0,
   ARMENV_POLICY_RANDOM = 1,
   ARMENV_POLICY_ACTOR = 2,        /* TD3 actor, exact f32 (layers 1 and 2 on the f32-input MFMA) */
-  ARMENV_POLICY_ACTOR_F16X3 = 3   /* same actor, layer 2 on the f16 MFMA with 3-pass hi/lo operand splitting (~1e-6) */
+  ARMENV_POLICY_ACTOR_F16X3 = 3,  /* same actor, layer 2 on the f16 MFMA with 3-pass hi/lo operand splitting (~1e-6) */
+  ARMENV_POLICY_DATD3 = 4         /* DATD3_MLP.take_action: two actors, two critics, the better-valued action (armenv_set_policy_datd3) */
 };
 
 typedef struct ArmEnv ArmEnv;
@@ -337,6 +338,29 @@ int armenv_summary(ArmEnv *env, double *out_dev, void *stream);
 int armenv_set_policy(ArmEnv *env, int32_t policy, const float *W1_dev, const float *b1_dev, const float *W2_dev,
                       const float *b2_dev, const float *W3_dev, const float *b3_dev, int32_t hidden_dim,
                       float action_bound, float noise_sigma, float noise_clip, void *stream);
+
+/* One three-layer perceptron of the reference's net_mlp.py (PolicyNet :29-40 or QValueNet :43-58): DEVICE pointers, torch Linear
+ * layout ([out][in], f32): W1 [hidden][in], b1 [hidden], W2 [hidden][hidden], b2 [hidden], W3 [out][hidden], b3 [out]. */
+typedef struct ArmEnvMlp {
+  const float *W1, *b1, *W2, *b2, *W3, *b3;
+} ArmEnvMlp;
+
+/* Installs DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) as the fused policy of armenv_rollout /
+ * armenv_step(action_dev = NULL):
+ *     a1 = actor1(s), a2 = actor2(s), q1 = critic1(cat(s, a1)), q2 = critic2(cat(s, a2)), a = a1 if q1 >= q2 else a2,
+ * then the rollout loop's exploration a = clip(a + N(0, noise_sigma), +-noise_clip) as in armenv_set_policy.  The four networks
+ * run inside the rollout kernel as four passes of the f16x3 MFMA actor (f32 emulated by three f16 passes, ~1e-6 of f32; the
+ * arg-max can differ from an f32 evaluation only where |q1 - q2| is of that order).  actors: in = obs_dim, out = 3, tanh x
+ * action_bound; critics: in = obs_dim + 3, out = 1, no output activation.  The weights are copied.  Built for the reach task
+ * (obs_dim 6) and hidden_dim 256; num_envs must be a multiple of 64; not on a bookkeeping handle (fence_counters). */
+int armenv_set_policy_datd3(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMlp *actor2, const ArmEnvMlp *critic1,
+                            const ArmEnvMlp *critic2, int32_t hidden_dim, float action_bound, float noise_sigma, float noise_clip,
+                            void *stream);
+
+/* The installed DATD3 policy alone (take_action without noise) for n states f32 [n][6]: actions f32 [n][3] and, nullable, the two
+ * Q values f32 [n] and the index of the actor whose action was taken u8 [n] (0: actor1, 1: actor2). */
+int armenv_datd3_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, float *q1_dev, float *q2_dev,
+                         uint8_t *picked_dev, void *stream);
 
 /* The installed actor alone (TD3_MLP.take_action without noise, /root/reference/algo/TD3/TD3_mlp.py:82-97):
  * states f32 [n][obs_dim] -> actions f32 [n][3]; both layers on the MFMA, exact f32 or the f16x3 emulation according to

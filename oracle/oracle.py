@@ -366,6 +366,28 @@ def actor_forward(sd, states, action_bound):
     return a
 
 
+def qvalue_forward(sd, states, actions):
+    """QValueNet.forward(state, action) (/root/reference/algo/DATD3/net_mlp.py:54-58): [n] f32."""
+    x = np.ascontiguousarray(np.concatenate([np.asarray(states, dtype=np.float32), np.asarray(actions, dtype=np.float32)], axis=1))
+    n, in_dim = x.shape
+    W1, b1, W2, b2, W3, b3 = (np.ascontiguousarray(sd[k], dtype=np.float32) for k in
+                              ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias"))
+    q = np.zeros(n, dtype=np.float32)
+    lib().orc_qvalue_forward(C.c_int64(n), C.c_int(in_dim), C.c_int(W1.shape[0]), _p(W1), _p(b1), _p(W2), _p(b2), _p(W3), _p(b3), _p(x), _p(q))
+    return q
+
+
+def datd3_take_action(nets, states, action_bound):
+    """DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109), batched: nets = (actor1, actor2, critic1, critic2)
+    state dicts.  Returns (action [n,3], q1 [n], q2 [n], picked [n] u8: 0 actor1, 1 actor2)."""
+    a1 = actor_forward(nets[0], states, action_bound)
+    a2 = actor_forward(nets[1], states, action_bound)
+    q1 = qvalue_forward(nets[2], states, a1)
+    q2 = qvalue_forward(nets[3], states, a2)
+    pick = ~(q1 >= q2)                                     # :107  action1 if q1 >= q2 else action2
+    return np.where(pick[:, None], a2, a1), q1, q2, pick.astype(np.uint8)
+
+
 def num_threads():
     return lib().orc_num_threads()
 

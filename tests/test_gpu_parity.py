@@ -1428,6 +1428,97 @@ def test_actor_f16x3_ragged_workgroups(envs, n):
     a.close(); b.close()
 
 
+def _datd3_nets(g):
+    keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+    return [{k: g["%s_%s" % (n, k.replace(".", "_"))] for k in keys} for n in ("actor1", "actor2", "critic1", "critic2")]
+
+
+def test_fused_datd3_take_action_matches_reference_golden(envs, O):
+    """DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) on the device -- armenv_set_policy_datd3 +
+    armenv_datd3_forward: four f16x3 MFMA passes (actor1, actor2, critic1 on cat(s, a1), critic2 on cat(s, a2)) through one set of LDS
+    tables and one W2 ring -- against the vectors produced by calling the reference's own take_action one state at a time (G11):
+    Q values within 1e-5, the same actor picked wherever |q1 - q2| > 1e-4 (both branches occur), actions within 1e-5; and against
+    the oracle on 4 096 + 192 random states (a ragged last workgroup), same bounds.  Refused on a push handle."""
+    g = golden_npz("datd3_take_action_seed0.npz")
+    nets = _datd3_nets(g)
+    tn = [{k: torch.from_numpy(v) for k, v in sd.items()} for sd in nets]
+    bound = float(g["action_bound"])
+    e = envs.BatchedReachEnv(4096 + 192, device=DEV, seed=3)
+    e.set_policy_datd3(*tn, action_bound=bound)
+    a, q1, q2, pk = (_np(x) for x in e.datd3_forward(torch.from_numpy(g["states"]).to(DEV), want_q=True))
+    assert np.abs(q1 - g["q1"]).max() < 1e-5 and np.abs(q2 - g["q2"]).max() < 1e-5
+    clear = np.abs(g["q1"] - g["q2"]) > 1e-4
+    assert clear.sum() >= 250 and np.array_equal(pk[clear], g["picked_actor"][clear].astype(np.uint8)) and 100 < pk[clear].sum() < 156
+    assert np.abs(a - g["actions"])[clear].max() < 1e-5
+    rng = np.random.default_rng(5)
+    lo, hi = np.float32([0.2, -0.3, 0.0] * 2), np.float32([0.7, 0.3, 0.55] * 2)
+    st = (lo + (hi - lo) * rng.random((4096 + 192, 6), dtype=np.float32)).astype(np.float32)
+    a, q1, q2, pk = (_np(x) for x in e.datd3_forward(torch.from_numpy(st).to(DEV), want_q=True))
+    ar, q1r, q2r, pr = O.datd3_take_action(nets, st, bound)
+    assert np.abs(q1 - q1r).max() < 1e-5 and np.abs(q2 - q2r).max() < 1e-5
+    clear = np.abs(q1r - q2r) > 1e-4
+    assert clear.mean() > 0.9 and np.array_equal(pk[clear], pr[clear]) and np.abs(a - ar)[clear].max() < 1e-5
+    assert np.array_equal(_np(e.datd3_forward(torch.from_numpy(st).to(DEV))), a)
+    e.close()
+    from armenv import ArmEnvError
+    p = envs.BatchedPushEnv(256, device=DEV)
+    with pytest.raises(ArmEnvError):
+        p.set_policy_datd3(*tn, action_bound=bound)
+    p.close()
+
+
+def test_fused_datd3_rollout_vs_oracle(envs, O, kuka):
+    """The DATD3 policy folded into the rollout kernel (ARMENV_POLICY_DATD3) at 65 536 reach envs, 2 x armenv_rollout(50) with
+    run()'s exploration noise, checked like BASELINE configs[2] on a strided sample of 2 048 envs: actions within 2e-5 of the
+    oracle's take_action + noise on the observations the fused policy saw (wherever the two critics are not within 1e-4 of each
+    other), observations within 1e-5 and identical flags with the oracle teacher-forced on the engine's actions; a 256 + 64-env
+    handle (ragged workgroup) gives rollout == step launches bit for bit."""
+    g = golden_npz("datd3_take_action_seed0.npz")
+    nets = _datd3_nets(g)
+    tn = [{k: torch.from_numpy(v) for k, v in sd.items()} for sd in nets]
+    n, T, stride = 65536, 50, 32
+    e = envs.BatchedReachEnv(n, device=DEV, seed=4)
+    e.set_policy_datd3(*tn, action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7)
+    obs0 = _np(e.reset()).copy()
+    ids = np.arange(0, n, stride)
+    cfg = O.default_config()
+    st = O.ReachState(ids.size)
+    st.q[:] = np.array(O.INIT_Q); st.goal[:] = obs0[ids, 3:]; st.episode[:] = 1
+    obs_prev = obs0[ids].copy()
+    worst_a = worst_o = 0.0
+    flags = unclear = 0
+    for launch in range(2):
+        out = e.rollout(T, None, want_actions=True, want_terminal_obs=True)
+        acts, obs, term, done, succ = (_np(out[k]) for k in ("actions", "obs", "terminal_obs", "done", "success"))
+        for t in range(T):
+            mu, q1, q2, _ = O.datd3_take_action(nets, obs_prev, 0.7)
+            nz = O.policy_noise_ids(4, ids, st.episode, st.step)
+            want = np.clip(mu + np.float32(0.7 * 0.98) * nz, -np.float32(0.7), np.float32(0.7))
+            a = acts[t][ids]
+            clear = np.abs(q1 - q2) > 1e-4
+            unclear += int((~clear).sum())
+            worst_a = max(worst_a, float(np.abs(a - want)[clear].max()))
+            o_r, r_r, d_r, s_r, iters = O.reach_step(kuka, cfg, st, a)
+            worst_o = max(worst_o, float(np.abs(term[t][ids] - o_r).max()))
+            flags += int((done[t][ids] != d_r.astype(bool)).sum() + (succ[t][ids] != s_r.astype(bool)).sum())
+            fin = d_r.astype(bool)
+            if fin.any():
+                st.q[fin] = np.array(O.INIT_Q); st.step[fin] = 0; st.episode[fin] += 1; st.ep_return[fin] = 0
+                st.goal[fin] = obs[t][ids][fin, 3:]
+            obs_prev = obs[t][ids].copy()
+    e.close()
+    assert worst_a < 2e-5 and worst_o < 1e-5 and flags == 0, (worst_a, worst_o, flags)
+    assert unclear < 0.02 * 2 * T * ids.size
+    a_env, b_env = (envs.BatchedReachEnv(256 + 64, device=DEV, seed=9, max_steps=12) for _ in range(2))
+    for x in (a_env, b_env):
+        x.set_policy_datd3(*tn, action_bound=0.7); x.reset()
+    out = a_env.rollout(30, None)
+    for t in range(30):
+        o, r, d, s = b_env.step(None)
+        _same_rollout_step(out, t, o, r, d)
+    a_env.close(); b_env.close()
+
+
 def test_fused_actor_nine_inputs_push(envs, O):
     """obs_dim 9 (push / pick): both fused actor variants against the oracle's actor on the observations they saw."""
     rng = np.random.default_rng(82)
