@@ -795,10 +795,17 @@ def main():
         return wall, gpu_ms, launches, gathers, ({k_: c1[k_] - c0[k_] for k_ in c1} if count else None), wall_steps
 
     scratch = Scratch(Env, n, dev, args.precision)
+    # the timed launches' output buffers are allocated (and touched) BEFORE the device is warmed: a fresh 60 MB block is a hipMalloc
+    # of milliseconds with the GPU idle, and an idle gap between the pre-warm and the contract's region costs that region its clocks
+    # (gpurun_out/r05/prewarm_*.json: the first region 125-131 us against 121 for its repeats, whatever the pre-warm's length)
+    env.bind_rollout(R, None if args.policy != "external" else pool[:R], out=bufs)
+    for v_ in bufs.values():
+        v_.zero_()
     scratch.prewarm(args.prewarm_ms)
     run(args.warmup)
     snap = {k: v.clone() for k, v in env.get_state().items()} if (not multi and args.repeat_regions > 0) else None
-    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=args.busy_ahead_ms)
+    # (three times the load in front of the contract's own region: it follows the host work above -- snapshot, planning, event creation)
+    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=3 * args.busy_ahead_ms)
     host_us_main = dict(host_us)
 
     # The headline is ONE sample of a short region (the driver's 20 steps are one ~120 us launch): the same region again, 15

@@ -308,19 +308,36 @@ static __global__ void actor_pack_kernel(const float *W1, const float *b1, const
   }
 }
 
+// sin and cos of 2 pi u for u in [0, 1): the quadrant k = rint(4 u) is taken off exactly (u - k / 4 is exact in f32), the remainder
+// |x| <= pi / 4 goes through the Cephes single-precision kernels (< 1 ulp there), the quadrant is put back by swaps and sign flips.
+// ~25 instructions for the pair; sincosf on 2 pi u carries a large-argument reduction path (v_alignbit / v_ffbh_u32 chains) that this
+// argument never needs: the two calls were ~230 of the ~570 instructions the in-kernel policy added to a step.
+struct SinCos { float s, c; };
+AE_DEV SinCos sincos_2pi(float u) {
+  const int k = (int)fmaf(u, 4.0f, 0.5f);               // the nearest quadrant boundary (ties either way: |x| <= pi / 4 both sides)
+  const float kf = (float)k;
+  const float x = 6.283185307179586f * fmaf(-0.25f, kf, u);
+  const float z = x * x;
+  const float sx = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, x, x);
+  const float cx = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+  const float ss = (k & 1) ? cx : sx, cc = (k & 1) ? sx : cx;
+  return SinCos{(k & 2) ? -ss : ss, ((k + 1) & 2) ? -cc : cc};
+}
+
 // Three N(0,1) draws for (env, episode, step): Philox block 0x80000000|step of the env's stream (reset draws use
-// blocks < 2^31), Box-Muller in f32 on u = (w + 1) * 2^-32 in (0, 1].
+// blocks < 2^31), Box-Muller in f32 on u = (w + 1) * 2^-32 in (0, 1]: r = sqrt(-2 ln u) through v_log_f32 / v_sqrt_f32 (1 ulp each),
+// the angle through sincos_2pi -- within 3e-7 relative of the libm forms (logf, sqrtf, cosf / sinf of 2 pi u) the parity tests hold
+// the stream against.
 AE_DEV void policy_noise(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step, float (&nz)[3]) {
   uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), episode, 0x80000000u | step};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   const float k = 2.3283064365386963e-10f;  // 2^-32
   const float u0 = ((float)c[0] + 1.0f) * k, u1 = (float)c[1] * k, u2 = ((float)c[2] + 1.0f) * k, u3 = (float)c[3] * k;
-  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
-  float s0, c0, s1, c1;
-  sincosf(6.283185307179586f * u1, &s0, &c0);
-  sincosf(6.283185307179586f * u3, &s1, &c1);
-  nz[0] = r0 * c0; nz[1] = r0 * s0; nz[2] = r1 * c1;
-  (void)s1;
+  // -2 ln u = -2 ln 2 * log2 u; u >= 2^-32 is a normal number (v_log_f32 needs no denormal scaling)
+  const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+  const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  const SinCos a0 = sincos_2pi(u1), a1 = sincos_2pi(u3);
+  nz[0] = r0 * a0.c; nz[1] = r0 * a0.s; nz[2] = r1 * a1.c;
 }
 
 // Per-lane state of one reach env and the body of one env step.  The single-step kernel and the T-step rollout
@@ -834,7 +851,11 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
       cq[NJ - 1] = c7s; sq[NJ - 1] = s7s;
       grip_step(P, p0, S);          // :349, :412-417
     } else {
-      const EnvCold<T> &K = *P.cold;
+      // (the constants are read HERE: behind an opaque copy of the pointer hipcc cannot hoist their scalar loads above the IK loop, where
+      // a dozen more live scalars cost the loop its f64 constants -- section 4b of DESIGN.md)
+      const EnvCold<T> *Kp = P.cold;
+      asm volatile("" : "+s"(Kp));
+      const EnvCold<T> &K = *Kp;
       if (K.push_model == 1) { cube_fall(K, step + 2); contact_dyn(P, K, S.p, step + 2); }      // :349
       else contact(P, p0, S.p);                                                                // :349, rounds 1-4
     }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the raw rocprofv3 outputs of profiles/collect.sh (gpurun_out/prof/) into the summaries kept in profiles/
-(ROUND = r04 unless given as argv[1]):
+(ROUND = r05 unless given as argv[1]):
   <round>_kernel_stats_<config>.csv   --stats tables, armenv kernels only (config "driver" = `bench.py --steps 20 --warmup 5`)
   <round>_kernel_stats_<config>_by_T.csv  the same launches from the per-dispatch kernel trace, one row per (kernel, steps per
                                       launch): rocprofv3's --stats merges the T = 5 warm-up, the T = 20 timed launches and the
@@ -26,7 +26,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def short(name):

@@ -2,7 +2,7 @@
 # Collects a round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only,
 #                                                               `bash profiles/collect.sh pick` to redo the pick row alone)
-# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r04_*).
+# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r05_*).
 # PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
 set -u
 REPO=$(pwd)

