@@ -39,6 +39,7 @@ int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, con
   pol.actor.bound = bound;
   pol.actor.in_dim = in_dim;
   pol.actor.raw = 0;
+  pol.actor.lds_image = nullptr;
   return ARMENV_OK;
 }
 
@@ -63,12 +64,22 @@ static __global__ __launch_bounds__(256) void datd3_kernel(const ActorParams *ne
   }
 }
 
+// the LDS tables of a nine-input net (actor_stage_w1 + actor_stage_w1h) built once in a workgroup's LDS and written out as an image
+static __global__ __launch_bounds__(256) void actor_lds_image_kernel(const float *W1P, const float4 *B2W3, float4 *image) {
+  __shared__ float4 tab[ACTOR_W1_LDS_FLOATS_H / 4];
+  actor_stage_w1(W1P, tab, B2W3, 9);
+  actor_stage_w1h(W1P, tab, 9);
+  __syncthreads();
+  for (int i = threadIdx.x; i < ACTOR_W1_LDS_FLOATS_H / 4; i += blockDim.x) image[i] = tab[i];
+}
+
 // armenv_set_policy_datd3: the four nets packed like set_actor packs one (the W2P table of the exact-f32 actor is not needed: the
 // fused DATD3 policy runs the f16x3 passes only), every net as a NINE-input net (datd3_forward_wg): the actors' W1 rows carry zeros
 // in columns obs_dim..8, the critics' W1 is [hidden][obs_dim + 3] = 9 wide as it is.
 int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bound, hipStream_t s) {
   const size_t n1 = ACTOR_HID * 12, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
-  const size_t per_net = n1 + n2 + n3 + n2;                      // floats: W1P | W2P (unused scratch of the packer) | B2W3 | W2H + W2L
+  const size_t n4 = ACTOR_W1_LDS_FLOATS_H;                       // the LDS table image
+  const size_t per_net = n1 + n2 + n3 + n2 + n4;                 // floats: W1P | W2P (unused scratch of the packer) | B2W3 | W2H + W2L | image
   const size_t tab = (4 * sizeof(ActorParams) + 4 * sizeof(ActorParamsH) + sizeof(float) - 1) / sizeof(float);
   if (!datd3_buf && hipMalloc(reinterpret_cast<void **>(&datd3_buf), (4 * per_net + tab) * sizeof(float)) != hipSuccess)
     return fail(ARMENV_ENOMEM, "armenv_set_policy_datd3: hipMalloc failed");
@@ -82,6 +93,8 @@ int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bou
     _Float16 *W2H = reinterpret_cast<_Float16 *>(base + n1 + n2 + n3), *W2L = W2H + n2;
     hipLaunchKernelGGL(actor_pack_kernel, dim3((unsigned)(n2 / 256)), dim3(256), 0, s, m.W1, m.b1, m.W2, m.b2, m.W3,
                        critic ? obs_dim + 3 : obs_dim, W1P, W2P, B2W3, W2H, W2L, critic ? 1 : 3);
+    float4 *image = reinterpret_cast<float4 *>(base + n1 + n2 + n3 + n2);
+    hipLaunchKernelGGL(actor_lds_image_kernel, dim3(1), dim3(256), 0, s, W1P, reinterpret_cast<const float4 *>(B2W3), image);
     HIP_TRY(hipGetLastError());
     float hb3[3] = {0.f, 0.f, 0.f};
     HIP_TRY(hipMemcpyAsync(hb3, m.b3, sizeof(float) * (critic ? 1 : 3), hipMemcpyDeviceToHost, s));
@@ -93,6 +106,7 @@ int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bou
     A[k].bound = bound;
     A[k].in_dim = 9;
     A[k].raw = critic ? 1 : 0;
+    A[k].lds_image = image;
     H[k].W2H = reinterpret_cast<const half8 *>(W2H);
     H[k].W2L = reinterpret_cast<const half8 *>(W2L);
   }

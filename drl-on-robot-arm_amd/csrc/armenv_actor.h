@@ -32,6 +32,8 @@ struct ActorParams {
   float bound;
   int32_t in_dim;      // 6 (reach obs) or 9 (push obs; DATD3: every net staged with 9 inputs, see datd3_forward_wg)
   int32_t raw;         // 0: out = bound * tanh(z + b3) (PolicyNet); 1: out = z + b3 (QValueNet, net_mlp.py:43-58: row 0 of the table is fc3)
+  const float4 *lds_image;   // nullable: the LDS tables of actor_stage_w1 + actor_stage_w1h for this net as ONE image in global memory
+                             // (ACTOR_W1_LDS_FLOATS_H floats, made once when the net is installed): staging is then a copy
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -367,6 +369,19 @@ AE_DEV void actor_ring_init(const ActorParamsH &H, uint4 *ring, int nw) {   // t
 }
 AE_DEV void actor_ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// The LDS tables of one net from their pre-built image: 1 KB pieces by direct-to-LDS loads, piece f taken by live wave f mod nw
+// (31 pieces: eight instructions per wave and no VALU, against ~4 us of element-wise address arithmetic and f16 splits when the
+// tables are computed in place -- DATD3 switches nets four times per env step).  The caller drains and meets afterwards.
+AE_DEV void actor_stage_image(const float4 *image, float4 *w1_lds, int nw) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned voff = (threadIdx.x & 63u) * 16u;
+  const uint64_t src = scalar_opaque((uint64_t)(uintptr_t)image);
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)w1_lds);
+  constexpr int pieces = ACTOR_W1_LDS_FLOATS_H * 4 / 1024;
+  static_assert(ACTOR_W1_LDS_FLOATS_H * 4 % 1024 == 0, "the table image is a whole number of 1 KB pieces");
+  for (int f = wave; f < pieces; f += nw) glds16(reinterpret_cast<const void *>(src + (uint64_t)f * 1024u), voff, dst + (unsigned)f * 1024u);
+}
+
 // Instrumented build only (make timeline): shader-clock time of workgroup 0's four waves by phase of the f16x3 pass, accumulated in
 // scalar registers and written once per pass to the buffer tests/tools/exp/run_actor_timeline.py installs (row = wave, 64 slots each:
 // 8 t + class; classes: 0 prologue, 1 bodies of the resident k-steps, 2 / 3 of the streamed even / odd k-steps, 4 layer 3 + epilogue,
@@ -661,9 +676,10 @@ AE_DEV void datd3_forward_wg(const ActorParams *nets, const ActorParamsH *nets_h
     const ActorParamsH H = nets_h[net];
     actor_ring_drain();
     __syncthreads();
-    actor_stage_w1(A.W1P, w1_lds, A.B2W3, 9, live);
-    actor_stage_w1h(A.W1P, w1_lds, 9, live);
+    if (A.lds_image) actor_stage_image(A.lds_image, w1_lds, nw);
+    else { actor_stage_w1(A.W1P, w1_lds, A.B2W3, 9, live); actor_stage_w1h(A.W1P, w1_lds, 9, live); }
     actor_ring_init(H, ring, nw);
+    actor_ring_drain();       // (the table image arrives by DMA like the ring: it must have landed before anyone reads a table)
     __syncthreads();
     if (net >= 2) static_for<0, 3>([&](auto KI) { constexpr int k = KI; x[6 + k] = net == 2 ? a1[k] : a2[k]; });      // cat(s, a_i), net_mlp.py:55
     float o[3];
