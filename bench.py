@@ -804,8 +804,7 @@ def main():
     scratch.prewarm(args.prewarm_ms)
     run(args.warmup)
     snap = {k: v.clone() for k, v in env.get_state().items()} if (not multi and args.repeat_regions > 0) else None
-    # (three times the load in front of the contract's own region: it follows the host work above -- snapshot, planning, event creation)
-    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=3 * args.busy_ahead_ms)
+    wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=args.busy_ahead_ms)
     host_us_main = dict(host_us)
 
     # The headline is ONE sample of a short region (the driver's 20 steps are one ~120 us launch): the same region again, 15

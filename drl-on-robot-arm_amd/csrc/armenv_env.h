@@ -724,51 +724,46 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
   // k = number of stepSimulation calls since the cube was spawned, this one included (reset() made the first, :241).
   // The cube's height: free fall through the step in which it reaches the table, then the overshoot decays towards the rest height.
   AE_DEV void cube_fall(const EnvCold<T> &K, int k) {
-    if (k <= K.fall_land) cube[2] = K.place_z - K.fall_c * (T)k * (T)(k + 1);
-    else cube[2] = (T)K.push_rest_z + (cube[2] - (T)K.push_rest_z) * K.fall_keep;
+    const T zf = K.place_z - K.fall_c * (T)k * (T)(k + 1);
+    const T zr = (T)K.push_rest_z + (cube[2] - (T)K.push_rest_z) * K.fall_keep;
+    cube[2] = k <= K.fall_land ? zf : zr;         // a select: a wave that has its SIMD to itself pays 20-50 ns per taken branch
   }
   // The cube in the plane: collision detection at the positions the step starts from (tool = vertical cylinder about the link-7
   // frame's xy, reaching tool_below under it), velocity-level contact along the horizontal normal unless the tool sits less deep in the
   // cube from above than from the side (then it presses the cube onto the table), Coulomb friction once the cube has landed, integration.
+  // Two exec-mask regions at most -- lanes in contact, lanes whose cube moves -- with selects inside (eight nested branches cost the
+  // push step 5 % of its cycles for 0.7 % more instructions, profiles/r05_pmc_push_pick.json); square roots and quotients through
+  // v_rsq + Newton (fast_rsqrt: a few ulp), the overlap test on squared lengths.
   AE_DEV void contact_dyn(const EnvParams<T> &P, const EnvCold<T> &K, const T (&p)[3], int k) {
-    // square roots and quotients through v_rsq + Newton (fast_rsqrt: a few ulp; an IEEE f64 sqrt and three divides were 7 % of the
-    // push step, and most wave-steps have a lane in here), the overlap test on squared lengths
     const T h = P.push_cube_half, r = K.tool_radius, dt = K.dt;
     const T lo = p[2] - K.tool_below;
-    if (lo < cube[2] + h) {
-      const T lx = cube[0] - h, hx = cube[0] + h, ly = cube[1] - h, hy = cube[1] + h;
-      const T qx = p[0] < lx ? lx : (p[0] > hx ? hx : p[0]);
-      const T qy = p[1] < ly ? ly : (p[1] > hy ? hy : p[1]);
-      const T gx = qx - p[0], gy = qy - p[1];
-      const T g2 = gx * gx + gy * gy;
-      if (g2 < r * r) {
-        T pen, nx, ny;
-        if (g2 > T(1e-18)) {
-          const T rs = fast_rsqrt<T>(g2);
-          pen = r - g2 * rs; nx = gx * rs; ny = gy * rs;
-        } else {   // tool axis inside the footprint: out through the nearest face (-x, +x, -y, +y in this order on ties)
-          const T e0 = hx - p[0], e1 = p[0] - lx, e2 = hy - p[1], e3 = p[1] - ly;
-          T eb = e0; nx = T(-1); ny = T(0);
-          if (e1 < eb) { eb = e1; nx = T(1); ny = T(0); }
-          if (e2 < eb) { eb = e2; nx = T(0); ny = T(-1); }
-          if (e3 < eb) { eb = e3; nx = T(0); ny = T(1); }
-          pen = eb + r;
-        }
-        const T pen_v = (cube[2] + h) - lo;
-        if (!(pen_v < pen)) {
-          const T vn = vel[0] * nx + vel[1] * ny;
-          const T tgt = pen < K.split ? K.erp_dt * pen : T(0);
-          if (vn < tgt) { vel[0] += (tgt - vn) * nx; vel[1] += (tgt - vn) * ny; }
-        }
-      }
+    const T lx = cube[0] - h, hx = cube[0] + h, ly = cube[1] - h, hy = cube[1] + h;
+    const T qx = p[0] < lx ? lx : (p[0] > hx ? hx : p[0]);
+    const T qy = p[1] < ly ? ly : (p[1] > hy ? hy : p[1]);
+    const T gx = qx - p[0], gy = qy - p[1];
+    const T g2 = gx * gx + gy * gy;
+    if ((lo < cube[2] + h) & (g2 < r * r)) {
+      const bool outside = g2 > T(1e-18);
+      const T rs = fast_rsqrt<T>(outside ? g2 : T(1));
+      // tool axis inside the footprint: out through the nearest face (-x, +x, -y, +y in this order on ties)
+      const T e0 = hx - p[0], e1 = p[0] - lx, e2 = hy - p[1], e3 = p[1] - ly;
+      T eb = e0, ix = T(-1), iy = T(0);
+      { const bool c = e1 < eb; eb = c ? e1 : eb; ix = c ? T(1) : ix; }
+      { const bool c = e2 < eb; eb = c ? e2 : eb; ix = c ? T(0) : ix; iy = c ? T(-1) : iy; }
+      { const bool c = e3 < eb; eb = c ? e3 : eb; ix = c ? T(0) : ix; iy = c ? T(1) : iy; }
+      const T pen = outside ? r - g2 * rs : eb + r;
+      const T nx = outside ? gx * rs : ix, ny = outside ? gy * rs : iy;
+      const T pen_v = (cube[2] + h) - lo;
+      const T vn = vel[0] * nx + vel[1] * ny;
+      const T tgt = pen < K.split ? K.erp_dt * pen : T(0);
+      const T dv = (!(pen_v < pen) & (vn < tgt)) ? tgt - vn : T(0);
+      vel[0] += dv * nx; vel[1] += dv * ny;
     }
     const T v2 = vel[0] * vel[0] + vel[1] * vel[1];
     if (v2 > T(0)) {
-      if (k >= K.fall_land) {
-        const T f = T(1) - K.fric_dv * fast_rsqrt<T>(v2);       // (|v| - dec) / |v|
-        const T fc = f > T(0) ? f : T(0);
-        vel[0] *= fc; vel[1] *= fc;
-      }
+      const T f = T(1) - K.fric_dv * fast_rsqrt<T>(v2);       // (|v| - dec) / |v|
+      const T fc = k >= K.fall_land ? (f > T(0) ? f : T(0)) : T(1);
+      vel[0] *= fc; vel[1] *= fc;
       cube[0] += vel[0] * dt; cube[1] += vel[1] * dt;
     }
   }
