@@ -15,6 +15,7 @@ enqueued right in front of its opening synchronise (the region starts from the c
                  per-step outputs written to [R][N][...] buffers (the trajectory of R armenv_step calls);
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
                  beside the headline and reported under "step_api".
+Ahead of that, once and untimed, a dress rehearsal of the same procedure (--rehearsals; env state and action cursor restored after it).
 Timing: W untimed steps, then barrier + synchronise, the clock, EXACTLY K steps, synchronise (incl. the logging all-gather of a
 multi-rank run) + barrier, the clock.  `value` = all ranks' env-steps / MAX over ranks of that wall time; `value_steps` = the same
 with each rank's clock stopped when its own launch stream is idle (no collective, no barrier); `value_kernel` = the same steps /
@@ -603,6 +604,9 @@ def main():
     ap.add_argument("--busy-ahead-ms", type=float, default=8.0,
                     help="scratch-handle work enqueued in front of every timed region's opening synchronise, so that the region starts "
                          "from the clocks of a chip under sustained load (0 = nothing in front, round 4's procedure)")
+    ap.add_argument("--rehearsals", type=int, default=1,
+                    help="untimed passes through the contract's own procedure (W warm-up steps + the bracketed K steps) before the real one; the "
+                         "env state and the action cursor are restored afterwards, so the timed trajectory is unchanged (0 = none)")
     ap.add_argument("--ab-regions", type=int, default=8,
                     help="single-GPU runs with --repeat-regions > 0: the region this many more times under each of round 4's two "
                          "regimes (nothing in front of the region; state restored through the host / on the device) with clock "
@@ -802,6 +806,20 @@ def main():
     for v_ in bufs.values():
         v_.zero_()
     scratch.prewarm(args.prewarm_ms)
+    # Dress rehearsal: the contract's own procedure -- W warm-up steps, then the bracketed K steps -- once, untimed, after which the env
+    # state and the action-pool cursor are put back, so that the contract's region below runs exactly the launches it would have run
+    # (bit for bit: --state-digest tests) but as the SECOND pass through this code path on this handle, like each of its repeats.
+    # Without it the contract's region is 5-15 us slower than the median of its repeats on every box of round 5
+    # (profiles/r05_region_clock_probe.txt; `clock_probe_ns_before` of that region reads 3.40-3.50 ns against 3.379).
+    if args.rehearsals > 0:
+        snap0 = {k: v.clone() for k, v in env.get_state().items()}
+        for _ in range(args.rehearsals):
+            c_keep = cursor[0]
+            run(args.warmup)
+            timed(args.steps, ahead_ms=args.busy_ahead_ms)
+            env.set_state(**snap0, sync=False)
+            cursor[0] = c_keep
+        del snap0
     run(args.warmup)
     snap = {k: v.clone() for k, v in env.get_state().items()} if (not multi and args.repeat_regions > 0) else None
     wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=args.busy_ahead_ms)
@@ -924,7 +942,7 @@ def main():
             "config": {"workload": workload,
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
-                       "busy_ahead_ms": args.busy_ahead_ms,
+                       "busy_ahead_ms": args.busy_ahead_ms, "rehearsals": args.rehearsals,
                        "gathers_in_timed_region": gathers, "state_digest": digests, "per_rank": per_rank,
                        "gathered_returns_sha256": gathered["sha256"] if gathered else None,
                        "gathered_returns_mean": gathered["mean"] if gathered else None,
