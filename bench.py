@@ -15,7 +15,6 @@ enqueued right in front of its opening synchronise (the region starts from the c
                  per-step outputs written to [R][N][...] buffers (the trajectory of R armenv_step calls);
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
                  beside the headline and reported under "step_api".
-Ahead of that, once and untimed, a dress rehearsal of the same procedure (--rehearsals; env state and action cursor restored after it).
 Timing: W untimed steps, then barrier + synchronise, the clock, EXACTLY K steps, synchronise (incl. the logging all-gather of a
 multi-rank run) + barrier, the clock.  `value` = all ranks' env-steps / MAX over ranks of that wall time; `value_steps` = the same
 with each rank's clock stopped when its own launch stream is idle (no collective, no barrier); `value_kernel` = the same steps /
@@ -529,13 +528,18 @@ class Scratch:
         if ms <= 0:
             return
         t0 = time.perf_counter()
-        k = 0
+        k, busy = 0, 0.0
+        duty = float(os.environ.get("ARMENV_BENCH_PREWARM_DUTY", "1.0"))
         while (time.perf_counter() - t0) * 1e3 < ms:
+            tb = time.perf_counter()
             for _ in range(4):
                 self.launch()
             k += 4
             torch.cuda.synchronize(self.dev)
-        self.ms_per_launch = (time.perf_counter() - t0) * 1e3 / k
+            busy += time.perf_counter() - tb
+            if duty < 1.0:      # (diagnostic, ARMENV_BENCH_PREWARM_DUTY: idle a share of the time -- a chip held at full f64 load may sit at its power cap)
+                time.sleep((time.perf_counter() - tb) * (1.0 / duty - 1.0))
+        self.ms_per_launch = busy * 1e3 / k
 
     def ahead(self, ms):
         for _ in range(int(round(ms / self.ms_per_launch))):
@@ -604,7 +608,10 @@ def main():
     ap.add_argument("--busy-ahead-ms", type=float, default=8.0,
                     help="scratch-handle work enqueued in front of every timed region's opening synchronise, so that the region starts "
                          "from the clocks of a chip under sustained load (0 = nothing in front, round 4's procedure)")
-    ap.add_argument("--rehearsals", type=int, default=1,
+    ap.add_argument("--repeat-same-rows", action="store_true",
+                    help="diagnostic: the repeated regions re-use the contract region's own rows of the action pool (the same work, bit "
+                         "for bit) instead of fresh ones: separates what a region costs because of WHEN it runs from what its action window costs")
+    ap.add_argument("--rehearsals", type=int, default=0,
                     help="untimed passes through the contract's own procedure (W warm-up steps + the bracketed K steps) before the real one; the "
                          "env state and the action cursor are restored afterwards, so the timed trajectory is unchanged (0 = none)")
     ap.add_argument("--ab-regions", type=int, default=8,
@@ -806,11 +813,10 @@ def main():
     for v_ in bufs.values():
         v_.zero_()
     scratch.prewarm(args.prewarm_ms)
-    # Dress rehearsal: the contract's own procedure -- W warm-up steps, then the bracketed K steps -- once, untimed, after which the env
-    # state and the action-pool cursor are put back, so that the contract's region below runs exactly the launches it would have run
-    # (bit for bit: --state-digest tests) but as the SECOND pass through this code path on this handle, like each of its repeats.
-    # Without it the contract's region is 5-15 us slower than the median of its repeats on every box of round 5
-    # (profiles/r05_region_clock_probe.txt; `clock_probe_ns_before` of that region reads 3.40-3.50 ns against 3.379).
+    # Dress rehearsal (--rehearsals, default 0): the contract's own procedure -- W warm-up steps, then the bracketed K steps -- untimed,
+    # after which the env state and the action-pool cursor are put back, so that the contract's region below runs exactly the launches
+    # it would have run.  Built to test whether the contract's region is 5-8 us slower than the median of its repeats because it is the
+    # FIRST pass through this code path: it is not (profiles/r05_region_clock_probe.txt, appendix) -- kept as an option.
     if args.rehearsals > 0:
         snap0 = {k: v.clone() for k, v in env.get_state().items()}
         for _ in range(args.rehearsals):
@@ -821,7 +827,10 @@ def main():
             cursor[0] = c_keep
         del snap0
     run(args.warmup)
+    cursor0 = cursor[0]
     snap = {k: v.clone() for k, v in env.get_state().items()} if (not multi and args.repeat_regions > 0) else None
+    if snap is not None and os.environ.get("ARMENV_BENCH_RESTORE_FIRST") == "1":
+        env.set_state(**snap, sync=False)       # diagnostic: the contract region behind the same (idempotent) restore as its repeats
     wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=args.busy_ahead_ms)
     host_us_main = dict(host_us)
 
@@ -836,7 +845,10 @@ def main():
     if snap is not None:
         for j in range(args.repeat_regions):
             env.set_state(**snap, sync=False)
-            w_, g_, l_, _, _, _ = timed(args.steps, tag="r%d" % (j + 1), count=False, ahead_ms=args.busy_ahead_ms)
+            if args.repeat_same_rows:
+                cursor[0] = cursor0
+            w_, g_, l_, _, _, _ = timed(args.steps, tag="r%d" % (j + 1), count=os.environ.get("ARMENV_BENCH_COUNT_REPEATS") == "1",
+                                        ahead_ms=args.busy_ahead_ms)
             repeats.append((w_, g_ * 1e3 / l_))
         # Round 4's procedure beside it, eight regions each, same clock probes: NOTHING in front of the region, the state restored
         #   host_restore:   through the host (set_state + synchronise, armenv_counters D2H before and after: ~0.3 ms between regions);
