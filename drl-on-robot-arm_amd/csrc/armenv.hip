@@ -326,12 +326,12 @@ int armenv_default_config(int32_t task, ArmEnvConfig *c) {
   c->push_rest_z = 0.01 - 0.01474;
   c->push_place_min = 0.22;
   c->push_place_max = 0.25;
-  // the cube under stepSimulation (include/armenv.h, push_contact_model): fall constants from the reference's scene, contact
-  // constants fitted to its recorded push runs (tests/tools/fit_bullet.py part C)
+  // the cube under stepSimulation (include/armenv.h, push_contact_model): fall constants from the reference's scene, tool geometry
+  // nominal, push_contact_erp and push_friction fitted to its two recorded push runs (tests/tools/fit_bullet.py part C)
   c->push_contact_model = 1;
-  c->push_tool_radius = 0.035;
-  c->push_tool_below = 0.03;
-  c->push_contact_erp = 0.02;
+  c->push_tool_radius = 0.045;      // the KUKA flange's nominal geometry: 45 mm radius, its face 45 mm below the link-7 frame
+  c->push_tool_below = 0.045;
+  c->push_contact_erp = 0.01;       // fitted (with push_friction)
   c->push_contact_split = 0.04;
   c->push_friction = 0.03;
   c->push_gravity = 10.0;           // rl_push_env.py:155

@@ -170,17 +170,18 @@ typedef struct ArmEnvConfig {
    *     at push_place_z it is in free fall (semi-implicit Euler, push_gravity, push_dt) from reset()'s own stepSimulation (:241)
    *     through the step in which its drop passes push_drop_contact, then recovers the overshoot towards push_rest_z by the share
    *     push_drop_relax per step.  The fall has no fitted number but the rest height and reproduces the untouched episodes of both
-   *     recorded runs (visdata/push/origin_TD3 and updata_TD3: tests/reference_run.py) to 3e-4; push_tool_radius, push_tool_below,
-   *     push_contact_erp and push_friction are fitted to the touched ones (tests/tools/fit_bullet.py part C, DESIGN.md section 2:
-   *     final distances within 2 cm = returns of the first run within 1.0; the count of steps on which the cube moves -- the second
-   *     run's returns -- within 0..34 of 84..192).
+   *     recorded runs (visdata/push/origin_TD3 and updata_TD3: tests/reference_run.py) to 3e-4.  The tool geometry is the KUKA flange's
+   *     nominal one; push_contact_erp and push_friction are FITTED to the touched episodes (tests/tools/fit_bullet.py part C, DESIGN.md
+   *     section 2): counts of steps on which the cube moves 149 / 192 / 90 / 43 against Bullet's 149 / 192 / 84 / 32, returns under the
+   *     shipped reward within 12.4 (rounds 1-4: 25-195 off), final cube-target distances within 4.3 cm.  Effective values of this planar
+   *     stand-in, not Bullet's contact parameters.
    *   0: rounds 1-4 -- tool sphere of push_eef_radius at the link-7 frame, the whole penetration removed in one step, the cube
    *     already at rest at push_rest_z after reset() (what the pick task's gripper tip still uses). */
-  double push_tool_radius;    /* 0.035 */
-  double push_tool_below;     /* 0.03 (the KUKA flange face is 0.045 below the link-7 frame) */
-  double push_contact_erp;    /* 0.02 (Bullet's contact ERP, 0.2, is the share against an immovable body; link 7 weighs 0.3 kg) */
+  double push_tool_radius;    /* 0.045: the flange's radius */
+  double push_tool_below;     /* 0.045: the flange face below the link-7 frame */
+  double push_contact_erp;    /* 0.01, fitted (Bullet's contact ERP, 0.2, is the share against an immovable body; link 7 weighs 0.3 kg) */
   double push_contact_split;  /* 0.04: Bullet's m_splitImpulsePenetrationThreshold */
-  double push_friction;       /* 0.03 */
+  double push_friction;       /* 0.03, fitted */
   double push_gravity;        /* 10: p.setGravity(0, 0, -10), :155 */
   double push_dt;             /* 1 / 240: Bullet's default fixed time step */
   double push_drop_contact;   /* 0.015 = spawn height 0.01 - cube half 0.02 - table top -0.025 (pybullet_data table.urdf based at z = -0.65, :189) */

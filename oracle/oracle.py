@@ -182,11 +182,11 @@ def default_config(task="reach", robot="kuka"):
     c.push_place_max = 0.25
     # the cube under stepSimulation (armenv_oracle.c push_contact_dyn / push_cube_z); fitted values: tests/tools/fit_bullet.py part (C)
     c.push_contact_model = 1
-    c.push_tool_radius = 0.035
-    c.push_tool_below = 0.03
-    c.push_contact_erp = 0.02
+    c.push_tool_radius = 0.045         # the KUKA flange: 45 mm radius ...
+    c.push_tool_below = 0.045          # ... its face 45 mm below the link-7 frame (nominal geometry, not fitted)
+    c.push_contact_erp = 0.01          # fitted
     c.push_contact_split = 0.04        # Bullet: m_splitImpulsePenetrationThreshold = -0.04
-    c.push_friction = 0.03
+    c.push_friction = 0.03             # fitted
     c.push_gravity = 10.0              # rl_push_env.py:155
     c.push_dt = 1.0 / 240.0            # Bullet's default time step
     c.push_drop_contact = 0.015        # spawn 0.01 - half 0.02 - table top -0.025

@@ -569,28 +569,29 @@ def test_oracle_push_env_on_the_recorded_runs_first_episodes(O):
     torch.manual_seed(0), N(0, 0.392) exploration from np.random.seed(0); same trajectories, two rewards -- tests/reference_run.py)
     on the oracle's push env.
     * The runs are consistent: the count of moving steps M derived from the two returns of an episode is an integer to 1e-2.
-    * Untouched episode 4: BOTH returns to 3e-4 -- the shipped reward's -504.1221 (the cube's free fall: eight steps above the 1e-5
-      threshold, nothing fitted but the rest height) and the earlier reward's -512.0719.  Rounds 1-4 (push_contact_model = 0: cube at
-      rest from reset on) return -512.07 under the SHIPPED reward, 7.95 off.
-    * Touched episodes 1, 2, 3, 5 (Bullet's contact dynamics are not restated; a planar stand-in with four fitted numbers): same touched
-      pattern, final cube-target distances within 2.1 cm of Bullet's (the earlier reward's returns within 1.05; rounds 1-4: up to 3.3),
-      counts of moving steps within 35 of Bullet's 149 / 192 / 84 / 32 (rounds 1-4: 4-5 against them).  The shipped reward's return of
-      a touched episode is M-dominated and is NOT reproduced (off by up to 35): row P3 stays partial."""
+    * Episode 4, which Bullet's arm does not touch: BOTH returns to 2e-3 -- the shipped reward's -504.1221 (the cube's free fall:
+      eight steps above the 1e-5 threshold, nothing fitted but the rest height) and the earlier reward's -512.0719 (the stand-in's
+      tool grazes the cube on three steps, 2e-5 of cube travel).  Rounds 1-4 (push_contact_model = 0: cube at rest from reset on)
+      return -512.07 under the SHIPPED reward, 7.95 off.
+    * Touched episodes 1, 2, 3, 5 (Bullet's contact dynamics are not restated: a planar stand-in, nominal flange geometry, TWO fitted
+      numbers): counts of moving steps 149 / 192 / 90 / 43 against Bullet's 149 / 192 / 84 / 32 (rounds 1-4: 5 / 6 / 5 / 4), returns
+      under the SHIPPED reward within 12.4 (rounds 1-4: 25-195 off), final cube-target distances within 4.3 cm (the earlier reward's
+      returns within 2.2; rounds 1-4: 3.3).  Row P3 stays partial."""
     import reference_run as R
     org, upd = R.push_fixture_returns("origin"), R.push_fixture_returns("updata")
     rec = R.push_recorded_observables(6)
     assert [round(m) for _, m, _ in rec] == [149, 192, 84, 8, 32, 8] and max(abs(m - round(m)) for _, m, _ in rec) < 1e-2
     out = R.replay_push_on_oracle(O, 5)
     assert [o["n"] for o in out] == [501] * 5
-    assert abs(out[3]["ret"] - upd[3]) < 3e-4 and abs(out[3]["ret_origin"] - org[3]) < 1e-4 and out[3]["M"] == 8 and out[3]["moved"] == 0, out[3]
-    assert [o["M"] > 8 for o in out] == [True, True, True, False, True] and [o["moved"] > 0 for o in out] == [True, True, True, False, True]
+    assert abs(out[3]["ret"] - upd[3]) < 2e-3 and abs(out[3]["ret_origin"] - org[3]) < 2e-3 and out[3]["M"] == 8 and out[3]["moved"] <= 5, out[3]
+    assert [o["M"] > 8 for o in out] == [True, True, True, False, True] and [o["moved"] > 20 for o in out] == [True, True, True, False, True]
     for k in (0, 1, 2, 4):
-        assert abs(out[k]["d_f"] - rec[k][0]) < 0.021, (k, out[k], rec[k])
-        assert abs(out[k]["ret_origin"] - org[k]) < 1.05, (k, out[k]["ret_origin"], org[k])
-        assert abs(out[k]["M"] - rec[k][1]) <= 35, (k, out[k]["M"], rec[k][1])
+        assert abs(out[k]["M"] - rec[k][1]) <= 12, (k, out[k]["M"], rec[k][1])
+        assert abs(out[k]["ret"] - upd[k]) < 13.0, (k, out[k]["ret"], upd[k])
+        assert abs(out[k]["d_f"] - rec[k][0]) < 0.045 and abs(out[k]["ret_origin"] - org[k]) < 2.2, (k, out[k], rec[k])
     legacy = R.replay_push_on_oracle(O, 5, lambda c: setattr(c, "push_contact_model", 0))
     assert abs(legacy[3]["ret"] - upd[3]) > 7.9 and max(abs(legacy[k]["ret_origin"] - org[k]) for k in (0, 1, 2, 4)) > 3.0
-    assert max(legacy[k]["M"] for k in range(5)) <= 6
+    assert max(legacy[k]["M"] for k in range(5)) <= 6 and min(abs(legacy[k]["ret"] - upd[k]) for k in (0, 1, 2, 4)) > 24.0
 
 
 def test_oracle_datd3_take_action_matches_reference_golden(O):
