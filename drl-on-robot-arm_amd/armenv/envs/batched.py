@@ -200,7 +200,7 @@ class BatchedArmEnv:
         """Install DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) as the fused policy of
         `rollout(actions=None)` / `step(None)`: a1 = actor1(s), a2 = actor2(s), the action whose own critic values it higher
         (q1 = critic1(s, a1) >= q2 = critic2(s, a2) -> a1), then a = clip(a + N(0, noise_sigma), +-noise_clip).  Each argument is
-        a state dict of the reference's PolicyNet / QValueNet (fc1.weight ... fc3.bias).  Reach handles only."""
+        a state dict of the reference's PolicyNet / QValueNet (fc1.weight ... fc3.bias) for this task's observation width."""
         keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
         keep, mlps = [], []
         for sd in (actor1, actor2, critic1, critic2):
@@ -215,8 +215,8 @@ class BatchedArmEnv:
         self._policy = "datd3"
 
     def datd3_forward(self, states, want_q=False):
-        """DATD3_MLP.take_action without noise for states f32 [n, 6]: actions [n, 3] (+ q1, q2 [n], picked_actor u8 [n])."""
-        st = states.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, 6)
+        """DATD3_MLP.take_action without noise for states f32 [n, obs_dim]: actions [n, 3] (+ q1, q2 [n], picked_actor u8 [n])."""
+        st = states.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, self.obs_dim)
         n = st.shape[0]
         out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         q1 = torch.empty(n, dtype=torch.float32, device=self.device) if want_q else None

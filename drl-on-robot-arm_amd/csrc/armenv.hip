@@ -18,7 +18,7 @@ int armenv_fail(int code, const char *fmt, ...) {
 
 int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                           const float *b3, int in_dim, float bound, hipStream_t s) {
-  const size_t n1 = ACTOR_HID * 12, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
+  const size_t n1 = ACTOR_HID * ACTOR_W1P_COLS, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
   // f32 tables, then the two f16 tables (n2 halfs each = n2 floats together)
   if (!actor_buf && hipMalloc(reinterpret_cast<void **>(&actor_buf), (n1 + n2 + n3 + n2) * sizeof(float)) != hipSuccess)
     return fail(ARMENV_ENOMEM, "armenv_set_policy: hipMalloc failed");
@@ -45,16 +45,17 @@ int EngineBase::set_actor(const float *W1, const float *b1, const float *W2, con
 
 // DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) for n reach states (6 floats): actions [n][3], and (nullable)
 // the two Q values and which actor was picked.
+template <int OBS>
 static __global__ __launch_bounds__(256) void datd3_kernel(const ActorParams *nets, const ActorParamsH *nets_h, int64_t n, const float *states,
                                                     float *actions, float *q1_out, float *q2_out, uint8_t *picked_out) {
   __shared__ float4 w1_lds[ACTOR_W1_LDS_FLOATS_H / 4];
   __shared__ uint4 w2_ring[ACTOR_RING_UINT4];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers n rounded up to 256: every wave is live
   const int64_t ic = i < n ? i : n - 1;
-  float s[6], a[3], q1, q2;
+  float s[OBS], a[3], q1, q2;
   int picked;
-  static_for<0, 6>([&](auto DI) { constexpr int d = DI; s[d] = states[ic * 6 + d]; });
-  datd3_forward_wg(nets, nets_h, w1_lds, w2_ring, 4, s, a, q1, q2, picked);
+  static_for<0, OBS>([&](auto DI) { constexpr int d = DI; s[d] = states[ic * OBS + d]; });
+  datd3_forward_wg<OBS>(nets, nets_h, w1_lds, w2_ring, 4, s, a, q1, q2, picked);
   actor_ring_drain();
   if (i < n) {
     actions[3 * i] = a[0]; actions[3 * i + 1] = a[1]; actions[3 * i + 2] = a[2];
@@ -65,19 +66,19 @@ static __global__ __launch_bounds__(256) void datd3_kernel(const ActorParams *ne
 }
 
 // the LDS tables of a nine-input net (actor_stage_w1 + actor_stage_w1h) built once in a workgroup's LDS and written out as an image
-static __global__ __launch_bounds__(256) void actor_lds_image_kernel(const float *W1P, const float4 *B2W3, float4 *image) {
+static __global__ __launch_bounds__(256) void actor_lds_image_kernel(const float *W1P, const float4 *B2W3, float4 *image, int in_dim) {
   __shared__ float4 tab[ACTOR_W1_LDS_FLOATS_H / 4];
-  actor_stage_w1(W1P, tab, B2W3, 9);
-  actor_stage_w1h(W1P, tab, 9);
+  actor_stage_w1(W1P, tab, B2W3, in_dim);
+  actor_stage_w1h(W1P, tab, in_dim);
   __syncthreads();
   for (int i = threadIdx.x; i < ACTOR_W1_LDS_FLOATS_H / 4; i += blockDim.x) image[i] = tab[i];
 }
 
 // armenv_set_policy_datd3: the four nets packed like set_actor packs one (the W2P table of the exact-f32 actor is not needed: the
-// fused DATD3 policy runs the f16x3 passes only), every net as a NINE-input net (datd3_forward_wg): the actors' W1 rows carry zeros
-// in columns obs_dim..8, the critics' W1 is [hidden][obs_dim + 3] = 9 wide as it is.
+// fused DATD3 policy runs the f16x3 passes only), every net as an (obs_dim + 3)-input net (datd3_forward_wg): the actors' W1 rows carry
+// zeros in the three columns behind obs_dim, the critics' W1 is [hidden][obs_dim + 3] as it is.
 int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bound, hipStream_t s) {
-  const size_t n1 = ACTOR_HID * 12, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
+  const size_t n1 = ACTOR_HID * ACTOR_W1P_COLS, n2 = (size_t)ACTOR_HID * ACTOR_HID, n3 = ACTOR_HID * 4;
   const size_t n4 = ACTOR_W1_LDS_FLOATS_H;                       // the LDS table image
   const size_t per_net = n1 + n2 + n3 + n2 + n4;                 // floats: W1P | W2P (unused scratch of the packer) | B2W3 | W2H + W2L | image
   const size_t tab = (4 * sizeof(ActorParams) + 4 * sizeof(ActorParamsH) + sizeof(float) - 1) / sizeof(float);
@@ -94,7 +95,7 @@ int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bou
     hipLaunchKernelGGL(actor_pack_kernel, dim3((unsigned)(n2 / 256)), dim3(256), 0, s, m.W1, m.b1, m.W2, m.b2, m.W3,
                        critic ? obs_dim + 3 : obs_dim, W1P, W2P, B2W3, W2H, W2L, critic ? 1 : 3);
     float4 *image = reinterpret_cast<float4 *>(base + n1 + n2 + n3 + n2);
-    hipLaunchKernelGGL(actor_lds_image_kernel, dim3(1), dim3(256), 0, s, W1P, reinterpret_cast<const float4 *>(B2W3), image);
+    hipLaunchKernelGGL(actor_lds_image_kernel, dim3(1), dim3(256), 0, s, W1P, reinterpret_cast<const float4 *>(B2W3), image, obs_dim + 3);
     HIP_TRY(hipGetLastError());
     float hb3[3] = {0.f, 0.f, 0.f};
     HIP_TRY(hipMemcpyAsync(hb3, m.b3, sizeof(float) * (critic ? 1 : 3), hipMemcpyDeviceToHost, s));
@@ -104,7 +105,7 @@ int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bou
     A[k].B2W3 = reinterpret_cast<const float4 *>(B2W3);
     for (int j = 0; j < 3; ++j) A[k].b3[j] = hb3[j];
     A[k].bound = bound;
-    A[k].in_dim = 9;
+    A[k].in_dim = obs_dim + 3;
     A[k].raw = critic ? 1 : 0;
     A[k].lds_image = image;
     H[k].W2H = reinterpret_cast<const half8 *>(W2H);
@@ -116,12 +117,14 @@ int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bou
   HIP_TRY(hipStreamSynchronize(s));
   pol.datd3 = reinterpret_cast<const ActorParams *>(t);
   pol.datd3_h = reinterpret_cast<const ActorParamsH *>(t + sizeof A);
+  datd3_obs = obs_dim;
   return ARMENV_OK;
 }
 
 int EngineBase::datd3_forward(int64_t n, const float *states, float *actions, float *q1, float *q2, uint8_t *picked, hipStream_t s) {
   if (!pol.datd3) return fail(ARMENV_ESTATE, "armenv_datd3_forward: no DATD3 policy installed (armenv_set_policy_datd3)");
-  hipLaunchKernelGGL(datd3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pol.datd3, pol.datd3_h, n, states, actions, q1, q2, picked);
+  if (datd3_obs == 6) hipLaunchKernelGGL(datd3_kernel<6>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pol.datd3, pol.datd3_h, n, states, actions, q1, q2, picked);
+  else hipLaunchKernelGGL(datd3_kernel<9>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pol.datd3, pol.datd3_h, n, states, actions, q1, q2, picked);
   HIP_TRY(hipGetLastError());
   return ARMENV_OK;
 }
@@ -525,13 +528,10 @@ int armenv_set_policy_datd3(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMl
   if (!(noise_sigma >= 0.f && noise_clip > 0.f)) return fail(ARMENV_EINVAL, "armenv_set_policy_datd3: need noise_sigma >= 0 and noise_clip > 0");
   if (hidden_dim != ACTOR_HID)
     return fail(ARMENV_EINVAL, "armenv_set_policy_datd3: hidden_dim %d; the fused nets are built for %d (config.py:56)", hidden_dim, ACTOR_HID);
-  if (env->cfg.task != ARMENV_TASK_REACH)
-    return fail(ARMENV_ESTATE, "armenv_set_policy_datd3: the fused DATD3 policy is built for the reach task (6-float observations; the critics of "
-                               "push / pick would take 12 inputs)");
   if (env->cfg.num_envs % 64 != 0) return fail(ARMENV_EINVAL, "armenv_set_policy_datd3: num_envs must be a multiple of 64 (full wavefronts)");
   if (env->cfg.fence_counters)
     return fail(ARMENV_ESTATE, "armenv_set_policy_datd3: not on a bookkeeping handle (fence_counters, ik_tip_offset)");
-  const int rc = env->eng->set_datd3(nets, 6, action_bound, static_cast<hipStream_t>(stream));
+  const int rc = env->eng->set_datd3(nets, armenv_obs_dim(env), action_bound, static_cast<hipStream_t>(stream));
   if (rc != ARMENV_OK) return rc;
   env->eng->pol.kind = ARMENV_POLICY_DATD3;
   env->eng->pol.sigma = noise_sigma;

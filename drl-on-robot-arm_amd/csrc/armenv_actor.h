@@ -23,9 +23,10 @@ namespace armenv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ACTOR_HID = 256;
+constexpr int ACTOR_W1P_COLS = 16;   // a packed layer-1 row: up to 15 input weights (12 = the critics of the cube tasks: obs 9 + action 3), then the bias
 
 struct ActorParams {
-  const float *W1P;    // [256 k][12]: w0..w8 (zero beyond in_dim), 0, 0, b1 -- source of the LDS tables (actor_stage_w1)
+  const float *W1P;    // [256 k][ACTOR_W1P_COLS = 16]: w0..w14 (zero beyond in_dim), b1 -- source of the LDS tables (actor_stage_w1)
   const float4 *W2P;   // [256 k][2 part][32 lane]: (W2[32*(4 part + c) + lane][k], c = 0..3)
   const float4 *B2W3;  // [256]: (b2[n], W3[0][n], W3[1][n], W3[2][n])
   float b3[3];
@@ -56,7 +57,7 @@ constexpr int ACTOR_NK = 5;
 constexpr int ACTOR_W1A_FLOATS = 8 * ACTOR_NK * 64;
 constexpr int ACTOR_W1_LDS_FLOATS = ACTOR_W1A_FLOATS + ACTOR_HID * 4 + ACTOR_HID;
 
-// fills the tables from W1P (global, [256][12] f32: w0..w8, 0, 0, b1) and B2W3 ([256] float4); every thread of the
+// fills the tables from W1P (global, [256][16] f32: w0..w14, b1) and B2W3 ([256] float4); every thread of the
 // block must call this once, then __syncthreads()
 AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, int in_dim, int nthreads = 0) {
   if (nthreads == 0) nthreads = blockDim.x;      // (a ragged workgroup whose dead waves have exited passes its live thread count)
@@ -64,7 +65,7 @@ AE_DEV void actor_stage_w1(const float *W1P, float4 *lds, const float4 *B2W3, in
   for (int i = threadIdx.x; i < ACTOR_W1A_FLOATS; i += nthreads) {
     const int l = i & 63, m = (i >> 6) % ACTOR_NK, R = (i >> 6) / ACTOR_NK;
     const int row = 32 * R + (l & 31), ka = 2 * m + (l >> 5);
-    w1a[i] = ka < in_dim ? W1P[row * 12 + ka] : (ka == in_dim ? W1P[row * 12 + 11] : 0.f);
+    w1a[i] = ka < in_dim ? W1P[row * ACTOR_W1P_COLS + ka] : (ka == in_dim ? W1P[row * ACTOR_W1P_COLS + ACTOR_W1P_COLS - 1] : 0.f);
   }
   for (int i = threadIdx.x; i < ACTOR_HID; i += nthreads) {
     const float4 c = B2W3[i];
@@ -296,7 +297,7 @@ AE_DEV void actor_stage_w1h(const float *W1P, float4 *w1_lds, int in_dim, int nt
   for (int i = threadIdx.x; i < 8 * 64 * 8; i += nthreads) {
     const int j = i & 7, l = (i >> 3) & 63, R = i >> 9;
     const int row = 32 * R + (l & 31), k = 8 * (l >> 5) + j;
-    const float x = k < in_dim ? W1P[row * 12 + k] : (k == in_dim ? W1P[row * 12 + 11] : 0.f);
+    const float x = k < in_dim ? W1P[row * ACTOR_W1P_COLS + k] : (k == in_dim ? W1P[row * ACTOR_W1P_COLS + ACTOR_W1P_COLS - 1] : 0.f);
     const _Float16 hi = (_Float16)x;
     t[((R * 2 + 0) * 64 + l) * 8 + j] = hi;
     t[((R * 2 + 1) * 64 + l) * 8 + j] = (_Float16)(x - (float)hi);
@@ -654,21 +655,22 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
 // DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) for the 256 envs of a workgroup:
 //     a1 = actor1(s), a2 = actor2(s), q1 = critic1(s, a1), q2 = critic2(s, a2), action = a1 if q1 >= q2 else a2
 // as four passes of the f16x3 workgroup actor above, one network after the other through the same LDS tables and the same W2 ring.
-// All four nets run as NINE-input nets: the critics take cat(s, a) (net_mlp.py:55; reach: 6 + 3), the actors see s padded with
-// three zeros against zero weight columns (their packed W1 rows carry zeros beyond in_dim: exact), so that ONE copy of the pass
-// serves the four calls (a pass is 2 400 instructions; the loop over the nets keeps it at that).  Between two nets every wave
-// drains its own ring DMA, the workgroup meets (everyone has finished reading the previous net's tables and ring), the tables and
-// the resident + first streamed k-steps of the next net are staged, and the workgroup meets again: ~48 KB of LDS writes and 112 KB of
-// LDS DMA per net and workgroup, from L2-resident weights.
-// nets / nets_h: device arrays [4] = actor1, actor2, critic1, critic2 (in_dim 9; the critics raw = 1 with fc3 in row 0 of their
-// B2W3 table).  s: the lane's observation (6 floats).  nw: live waves (a ragged last workgroup stages with its live threads).
+// All four nets run as (OBS + 3)-input nets: the critics take cat(s, a) (net_mlp.py:55; reach 6 + 3, push / pick 9 + 3), the actors
+// see s padded with three zeros against zero weight columns (their packed W1 rows carry zeros beyond in_dim: exact), so that ONE copy
+// of the pass serves the four calls (a pass is 2 400 instructions; the loop over the nets keeps it at that).  Between two nets every
+// wave drains its own ring DMA, the workgroup meets (everyone has finished reading the previous net's tables and ring), the next net's
+// tables arrive as one pre-built image and its resident + first streamed k-steps are requested, and the workgroup meets again.
+// nets / nets_h: device arrays [4] = actor1, actor2, critic1, critic2 (in_dim OBS + 3; the critics raw = 1 with fc3 in row 0 of their
+// B2W3 table).  s: the lane's observation.  nw: live waves (a ragged last workgroup stages with its live threads).
 // picked: 0 actor1 / 1 actor2.
-AE_DEV void datd3_forward_wg(const ActorParams *nets, const ActorParamsH *nets_h, float4 *w1_lds, uint4 *ring, int nw, const float (&s)[6],
+template <int OBS>
+AE_DEV void datd3_forward_wg(const ActorParams *nets, const ActorParamsH *nets_h, float4 *w1_lds, uint4 *ring, int nw, const float (&s)[OBS],
                              float (&out)[3], float &q1, float &q2, int &picked) {
-  float x[9], a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};   // (no array indexed by `net`: a run-time subscript would put it in scratch)
+  constexpr int IN = OBS + 3;
+  float x[IN], a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};   // (no array indexed by `net`: a run-time subscript would put it in scratch)
   q1 = q2 = 0.f;
-  static_for<0, 6>([&](auto DI) { constexpr int d = DI; x[d] = s[d]; });
-  x[6] = x[7] = x[8] = 0.f;
+  static_for<0, OBS>([&](auto DI) { constexpr int d = DI; x[d] = s[d]; });
+  x[OBS] = x[OBS + 1] = x[OBS + 2] = 0.f;
   const int live = nw * 64;
 #pragma unroll 1
   for (int net = 0; net < 4; ++net) {
@@ -677,13 +679,13 @@ AE_DEV void datd3_forward_wg(const ActorParams *nets, const ActorParamsH *nets_h
     actor_ring_drain();
     __syncthreads();
     if (A.lds_image) actor_stage_image(A.lds_image, w1_lds, nw);
-    else { actor_stage_w1(A.W1P, w1_lds, A.B2W3, 9, live); actor_stage_w1h(A.W1P, w1_lds, 9, live); }
+    else { actor_stage_w1(A.W1P, w1_lds, A.B2W3, IN, live); actor_stage_w1h(A.W1P, w1_lds, IN, live); }
     actor_ring_init(H, ring, nw);
     actor_ring_drain();       // (the table image arrives by DMA like the ring: it must have landed before anyone reads a table)
     __syncthreads();
-    if (net >= 2) static_for<0, 3>([&](auto KI) { constexpr int k = KI; x[6 + k] = net == 2 ? a1[k] : a2[k]; });      // cat(s, a_i), net_mlp.py:55
+    if (net >= 2) static_for<0, 3>([&](auto KI) { constexpr int k = KI; x[OBS + k] = net == 2 ? a1[k] : a2[k]; });      // cat(s, a_i), net_mlp.py:55
     float o[3];
-    actor_forward_wg_f16x3<9>(A, H, w1_lds, ring, nw, x, o);
+    actor_forward_wg_f16x3<IN>(A, H, w1_lds, ring, nw, x, o);
     static_for<0, 3>([&](auto KI) { constexpr int k = KI; a1[k] = net == 0 ? o[k] : a1[k]; a2[k] = net == 1 ? o[k] : a2[k]; });
     q1 = net == 2 ? o[0] : q1;
     q2 = net == 3 ? o[0] : q2;

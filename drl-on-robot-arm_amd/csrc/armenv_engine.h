@@ -87,6 +87,7 @@ struct EngineBase {
                 int in_dim, float bound, hipStream_t s);
   float *datd3_buf = nullptr;   // four packed nets + the device arrays of their ActorParams / ActorParamsH (armenv_set_policy_datd3)
   int set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bound, hipStream_t s);
+  int datd3_obs = 0;            // observation width the installed DATD3 nets were packed for (6 | 9)
   int datd3_forward(int64_t n, const float *states, float *actions, float *q1, float *q2, uint8_t *picked, hipStream_t s);
   int actor_forward(int64_t n, const float *states, float *actions, hipStream_t s);
   virtual int fk(int64_t n, const double *q, double *pos, double *quat, hipStream_t s) = 0;
@@ -363,9 +364,7 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
     if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR_F16X3) launch_rollout<ARMENV_POLICY_ACTOR_F16X3>(steps, actions, io0, actions_out, s);
-    else if (pol.kind == ARMENV_POLICY_DATD3) {
-      if constexpr (Lane::kObs == 6) launch_rollout<ARMENV_POLICY_DATD3>(steps, actions, io0, actions_out, s);      // (armenv_set_policy_datd3 refuses the other tasks)
-    }
+    else if (pol.kind == ARMENV_POLICY_DATD3) launch_rollout<ARMENV_POLICY_DATD3>(steps, actions, io0, actions_out, s);
     else launch_rollout<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
   }
   int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {

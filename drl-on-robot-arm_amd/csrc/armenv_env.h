@@ -294,9 +294,9 @@ static __global__ void actor_pack_kernel(const float *W1, const float *b1, const
     W2H[t] = hi;
     W2L[t] = (_Float16)(x - (float)hi);
   }
-  if (t < ACTOR_HID * 12) {   // [kk][row k = 2kk + r][12] == [k][12]
-    const int k = t / 12, j = t % 12;
-    W1P[t] = j < in_dim ? W1[k * in_dim + j] : (j == 11 ? b1[k] : 0.f);
+  if (t < ACTOR_HID * ACTOR_W1P_COLS) {   // [k][16]: the row's input weights, zeros, the bias last
+    const int k = t / ACTOR_W1P_COLS, j = t % ACTOR_W1P_COLS;
+    W1P[t] = j < in_dim ? W1[k * in_dim + j] : (j == ACTOR_W1P_COLS - 1 ? b1[k] : 0.f);
   }
   if (t < ACTOR_HID * ACTOR_HID) {
     const int c = t & 3, l32 = (t >> 2) & 31, part = (t >> 7) & 1, k = t >> 8;
@@ -1011,7 +1011,6 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
   constexpr bool kActor = POLICY == ARMENV_POLICY_ACTOR || POLICY == ARMENV_POLICY_ACTOR_F16X3 || kDatd3;
   constexpr bool kRing = POLICY == ARMENV_POLICY_ACTOR_F16X3 || kDatd3;
   static_assert(WAVES == 1 || (WAVES == 2 && !kActor), "the fused actors need the whole register file");
-  static_assert(!kDatd3 || Lane::kObs == 6, "the fused DATD3 policy is built for 6-float observations (reach)");
   constexpr bool kPrefetch = POLICY == ARMENV_POLICY_EXTERNAL && WAVES == 1;
   __shared__ float4 w1_lds[kActor ? (kRing ? ACTOR_W1_LDS_FLOATS_H : ACTOR_W1_LDS_FLOATS) / 4 : 1];
   __shared__ uint4 w2_ring[kRing ? ACTOR_RING_UINT4 : 1];
@@ -1075,12 +1074,10 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
         L.policy_obs(s);
         actor_forward_wg_f16x3<kObs>(pol.actor, pol.actor_h, w1_lds, w2_ring, nw, s, mu);
       } else if constexpr (kDatd3) {
-        if constexpr (kObs == 6) {
-          float s[6], q1, q2;
-          int picked;
-          L.policy_obs(s);
-          datd3_forward_wg(pol.datd3, pol.datd3_h, w1_lds, w2_ring, nw, s, mu, q1, q2, picked);    // take_action, DATD3_mlp.py:88-109
-        }
+        float s[kObs], q1, q2;
+        int picked;
+        L.policy_obs(s);
+        datd3_forward_wg<kObs>(pol.datd3, pol.datd3_h, w1_lds, w2_ring, nw, s, mu, q1, q2, picked);    // take_action, DATD3_mlp.py:88-109
       }
       float nz[3];
       // the episode index of the stream is the number of resets so far minus one (the running episode)

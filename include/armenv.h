@@ -352,13 +352,13 @@ typedef struct ArmEnvMlp {
  * then the rollout loop's exploration a = clip(a + N(0, noise_sigma), +-noise_clip) as in armenv_set_policy.  The four networks
  * run inside the rollout kernel as four passes of the f16x3 MFMA actor (f32 emulated by three f16 passes, ~1e-6 of f32; the
  * arg-max can differ from an f32 evaluation only where |q1 - q2| is of that order).  actors: in = obs_dim, out = 3, tanh x
- * action_bound; critics: in = obs_dim + 3, out = 1, no output activation.  The weights are copied.  Built for the reach task
- * (obs_dim 6) and hidden_dim 256; num_envs must be a multiple of 64; not on a bookkeeping handle (fence_counters). */
+ * action_bound; critics: in = obs_dim + 3, out = 1, no output activation (obs_dim 6 reach, 9 push / pick).  The weights are copied.
+ * hidden_dim 256; num_envs must be a multiple of 64; not on a bookkeeping handle (fence_counters). */
 int armenv_set_policy_datd3(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMlp *actor2, const ArmEnvMlp *critic1,
                             const ArmEnvMlp *critic2, int32_t hidden_dim, float action_bound, float noise_sigma, float noise_clip,
                             void *stream);
 
-/* The installed DATD3 policy alone (take_action without noise) for n states f32 [n][6]: actions f32 [n][3] and, nullable, the two
+/* The installed DATD3 policy alone (take_action without noise) for n states f32 [n][obs_dim]: actions f32 [n][3] and, nullable, the two
  * Q values f32 [n] and the index of the actor whose action was taken u8 [n] (0: actor1, 1: actor2). */
 int armenv_datd3_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, float *q1_dev, float *q2_dev,
                          uint8_t *picked_dev, void *stream);

@@ -478,7 +478,44 @@ def g13_visdata_push_td3():
                         **{k.replace(".", "_"): v.detach().numpy().copy() for k, v in agent.actor.state_dict().items()})
 
 
+def g14_datd3_take_action_nine_inputs():
+    """G14: DATD3_MLP.take_action of the reference for the cube tasks' 9-float observations (actors 9 -> 256 -> 256 -> 3, critics
+    12 -> 256 -> 256 -> 1; algo/DATD3/DATD3_mlp.py:88-109, action_bound 0.4 as train_push_with_TD3 sets it, main.py:457), produced like
+    G11 by importing the reference's agent and calling its own take_action one state at a time: datd3_take_action9_seed0.npz."""
+    sys.path.insert(0, REF)
+    import torch
+    from algo.DATD3.DATD3_mlp import DATD3_MLP
+    rng = np.random.default_rng(14)
+    lo = np.array([0.2, -0.3, 0.0, 0.2, -0.3, -0.006, 0.2, -0.3, 0.0]); hi = np.array([0.7, 0.3, 0.1, 0.7, 0.3, 0.01, 0.7, 0.3, 0.011])
+    states = (lo + (hi - lo) * rng.random((256, 9))).astype(np.float32)
+    cpu = torch.device("cpu")
+    torch.manual_seed(0)
+    agent = DATD3_MLP(9, 3, 0.4, device=cpu)
+    with torch.no_grad():       # as in G11: both branches of `action1 if q1 >= q2 else action2` must occur, some by a narrow margin
+        for c in (agent.critic1, agent.critic2):
+            torch.nn.init.normal_(c.fc3.weight, std=0.5)
+            c.fc3.bias.zero_()
+        sb = torch.from_numpy(states)
+        gap = agent.critic1(sb, agent.actor1(sb)) - agent.critic2(sb, agent.actor2(sb))
+        agent.critic2.fc3.bias += gap.median()
+    acts, q1s, q2s, pick = [], [], [], []
+    for s in states:
+        st = torch.tensor([s], dtype=torch.float)
+        with torch.no_grad():
+            a1, a2 = agent.actor1(st), agent.actor2(st)
+            q1, q2 = float(agent.critic1(st, a1)), float(agent.critic2(st, a2))
+        a = agent.take_action(s)
+        acts.append(a); q1s.append(q1); q2s.append(q2)
+        pick.append(0 if np.array_equal(a, a1.numpy().flatten()) else 1)
+    out = {"states": states, "actions": np.stack(acts).astype(np.float32), "q1": np.float32(q1s), "q2": np.float32(q2s),
+           "picked_actor": np.uint8(pick), "action_bound": np.float32(0.4)}
+    for name in ("actor1", "actor2", "critic1", "critic2"):
+        out.update({name + "_" + k.replace(".", "_"): v.detach().numpy().copy() for k, v in getattr(agent, name).state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, "datd3_take_action9_seed0.npz"), **out)
+
+
 if __name__ == "__main__":
+    g14_datd3_take_action_nine_inputs()
     g13_visdata_push_td3()
     g12_visdata_reach_td3()
     g1_fk_kat(); g2_joint_info(); g3_td3_actor(); g4_py_random(); g5_reward_truth(); g7_push_reward_truth(); g6_her_samples(); g8_td3_train(); g9_py_random_placements(); g10_config_fields(); g11_ddpg_datd3_take_action()

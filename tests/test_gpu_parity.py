@@ -1433,26 +1433,30 @@ def _datd3_nets(g):
     return [{k: g["%s_%s" % (n, k.replace(".", "_"))] for k in keys} for n in ("actor1", "actor2", "critic1", "critic2")]
 
 
-def test_fused_datd3_take_action_matches_reference_golden(envs, O):
+@pytest.mark.parametrize("task", ["reach", "push"])
+def test_fused_datd3_take_action_matches_reference_golden(envs, O, task):
     """DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) on the device -- armenv_set_policy_datd3 +
     armenv_datd3_forward: four f16x3 MFMA passes (actor1, actor2, critic1 on cat(s, a1), critic2 on cat(s, a2)) through one set of LDS
-    tables and one W2 ring -- against the vectors produced by calling the reference's own take_action one state at a time (G11):
-    Q values within 1e-5, the same actor picked wherever |q1 - q2| > 1e-4 (both branches occur), actions within 1e-5; and against
-    the oracle on 4 096 + 192 random states (a ragged last workgroup), same bounds.  Refused on a push handle."""
-    g = golden_npz("datd3_take_action_seed0.npz")
+    tables and one W2 ring -- against the vectors produced by calling the reference's own take_action one state at a time (G11: reach,
+    6-float observations, critics 9 -> 256 -> 256 -> 1; G14: push / pick, 9-float observations, critics 12 -> ...): Q values within 1e-5,
+    the same actor picked wherever |q1 - q2| > 1e-4 (both branches occur), actions within 1e-5; and against the oracle on 4 096 + 192
+    random states (a ragged last workgroup), same bounds."""
+    g = golden_npz("datd3_take_action_seed0.npz" if task == "reach" else "datd3_take_action9_seed0.npz")
     nets = _datd3_nets(g)
     tn = [{k: torch.from_numpy(v) for k, v in sd.items()} for sd in nets]
     bound = float(g["action_bound"])
-    e = envs.BatchedReachEnv(4096 + 192, device=DEV, seed=3)
+    Env = envs.BatchedReachEnv if task == "reach" else envs.BatchedPushEnv
+    e = Env(4096 + 192, device=DEV, seed=3)
     e.set_policy_datd3(*tn, action_bound=bound)
     a, q1, q2, pk = (_np(x) for x in e.datd3_forward(torch.from_numpy(g["states"]).to(DEV), want_q=True))
     assert np.abs(q1 - g["q1"]).max() < 1e-5 and np.abs(q2 - g["q2"]).max() < 1e-5
     clear = np.abs(g["q1"] - g["q2"]) > 1e-4
-    assert clear.sum() >= 250 and np.array_equal(pk[clear], g["picked_actor"][clear].astype(np.uint8)) and 100 < pk[clear].sum() < 156
+    assert clear.sum() >= 245 and np.array_equal(pk[clear], g["picked_actor"][clear].astype(np.uint8)) and 100 < pk[clear].sum() < 156
     assert np.abs(a - g["actions"])[clear].max() < 1e-5
     rng = np.random.default_rng(5)
-    lo, hi = np.float32([0.2, -0.3, 0.0] * 2), np.float32([0.7, 0.3, 0.55] * 2)
-    st = (lo + (hi - lo) * rng.random((4096 + 192, 6), dtype=np.float32)).astype(np.float32)
+    D = g["states"].shape[1]
+    lo, hi = g["states"].min(0), g["states"].max(0)
+    st = (lo + (hi - lo) * rng.random((4096 + 192, D), dtype=np.float32)).astype(np.float32)
     a, q1, q2, pk = (_np(x) for x in e.datd3_forward(torch.from_numpy(st).to(DEV), want_q=True))
     ar, q1r, q2r, pr = O.datd3_take_action(nets, st, bound)
     assert np.abs(q1 - q1r).max() < 1e-5 and np.abs(q2 - q2r).max() < 1e-5
@@ -1460,10 +1464,48 @@ def test_fused_datd3_take_action_matches_reference_golden(envs, O):
     assert clear.mean() > 0.9 and np.array_equal(pk[clear], pr[clear]) and np.abs(a - ar)[clear].max() < 1e-5
     assert np.array_equal(_np(e.datd3_forward(torch.from_numpy(st).to(DEV))), a)
     e.close()
-    from armenv import ArmEnvError
-    p = envs.BatchedPushEnv(256, device=DEV)
-    with pytest.raises(ArmEnvError):
-        p.set_policy_datd3(*tn, action_bound=bound)
+
+
+def test_fused_datd3_push_rollout(envs, O, kuka):
+    """The DATD3 policy of the cube tasks (9-float observations, G14 nets) folded into the push rollout kernel: on a 2 048 + 64-env handle
+    (ragged last workgroup) the actions of 40 fused steps are the oracle's take_action + noise on the observations the policy saw
+    (wherever the critics are not within 1e-4 of each other) to 2e-5, and rollout(T) equals T step(None) launches bit for bit; the same
+    on a pick handle runs and stays finite."""
+    g = golden_npz("datd3_take_action9_seed0.npz")
+    nets = _datd3_nets(g)
+    tn = [{k: torch.from_numpy(v) for k, v in sd.items()} for sd in nets]
+    n, T = 2048 + 64, 40
+    mk = lambda: envs.BatchedPushEnv(n, device=DEV, seed=12, max_steps=25)
+    e, e2 = mk(), mk()
+    for x in (e, e2):
+        x.set_policy_datd3(*tn, action_bound=0.4, noise_sigma=0.4 * 0.98, noise_clip=1e9)
+    obs_prev = _np(e.reset()).copy(); e2.reset()
+    out = e.rollout(T, None, want_actions=True)
+    acts, obs = _np(out["actions"]), _np(out["obs"])
+    ids = np.arange(n)
+    episode, step = np.ones(n, dtype=np.uint32), np.zeros(n, dtype=np.int32)
+    done = _np(out["done"])
+    worst = 0.0
+    for t in range(T):
+        mu, q1, q2, _ = O.datd3_take_action(nets, obs_prev, 0.4)
+        nz = O.policy_noise_ids(12, ids, episode, step)
+        want = mu + np.float32(0.4 * 0.98) * nz
+        clear = np.abs(q1 - q2) > 1e-4
+        worst = max(worst, float(np.abs(acts[t] - want)[clear].max()))
+        step += 1
+        fin = done[t]
+        episode[fin] += 1; step[fin] = 0
+        obs_prev = obs[t].copy()
+    assert worst < 2e-5 and done.sum() >= n, (worst, int(done.sum()))
+    for t in range(T):
+        o, r, d, s = e2.step(None)
+        _same_rollout_step(out, t, o, r, d)
+    e.close(); e2.close()
+    p = envs.BatchedPickEnv(256, device=DEV, seed=2)
+    p.set_policy_datd3(*tn, action_bound=0.4, noise_sigma=0.4 * 0.98, noise_clip=1e9)
+    p.reset()
+    o = p.rollout(20, None)
+    assert bool(torch.isfinite(o["obs"]).all()) and p.counters()["nonfinite"] == 0
     p.close()
 
 

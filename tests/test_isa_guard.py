@@ -124,9 +124,9 @@ def test_action_prefetch_agprs_are_untouched_between_issue_and_settle(kernels):
 
 def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
     sel = [(sn, md, ins) for sn, _, md, ins in kernels if any(i.mnem == "v_mfma_f32_32x32x16_f16" for i in ins)]
-    # the fused-actor rollout of every (task, precision, chain) + the two standalone actors + the fused DATD3 rollout of the reach
-    # task (2 precisions x 3 chains: ONE copy of the nine-input pass inside the loop over the four nets) + its standalone kernel
-    assert len(sel) == 18 + 2 + 6 + 1
+    # the fused-actor rollout of every (task, precision, chain) + the two standalone actors + the fused DATD3 rollout of every (task,
+    # precision, chain) (ONE copy of the (obs + 3)-input pass inside the loop over the four nets) + its two standalone kernels
+    assert len(sel) == 18 + 2 + 18 + 2
     for sn, md, ins in sel:
         m = [k for k, i in enumerate(ins) if i.mnem == "v_mfma_f32_32x32x16_f16"]
         # two copies of the env-tile pass since round 4 (armenv_actor.h actor_forward_wg_f16x3_impl): the full-workgroup one with its
@@ -134,7 +134,7 @@ def test_f16x3_k_loop_has_no_compiler_vmem(kernels):
         # layer 1 of the next row tile (3) between them -- and the ragged-workgroup one with the rolled row-tile loop
         # (the unrolled copy's layer 1 of a ninth row tile is dead code: 3 + 8 * 51 - 3; the standalone actor kernels have four live
         # waves by construction and no ragged copy)
-        standalone = sn.startswith(("actor_", "datd3_"))
+        standalone = sn.startswith(("actor_", "datd3"))
         assert len(m) == (408 if standalone else 408 + 54), (sn, len(m))
         # the k-step regions: runs of f16 MFMAs less than 150 instructions apart with at least 48 of them (the three MFMAs of an env
         # tile's first layer 1 sit apart, wherever the compiler lays the top of the env-tile loop out)

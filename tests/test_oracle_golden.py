@@ -594,17 +594,18 @@ def test_oracle_push_env_on_the_recorded_runs_first_episodes(O):
     assert max(legacy[k]["M"] for k in range(5)) <= 6 and min(abs(legacy[k]["ret"] - upd[k]) for k in (0, 1, 2, 4)) > 24.0
 
 
-def test_oracle_datd3_take_action_matches_reference_golden(O):
-    """G11: the oracle's batched DATD3 take_action (two actors, two critics on cat(s, a_i), the better-valued action) against vectors
+@pytest.mark.parametrize("fixture", ["datd3_take_action_seed0.npz", "datd3_take_action9_seed0.npz"])
+def test_oracle_datd3_take_action_matches_reference_golden(O, fixture):
+    """G11 (reach, 6-float observations) / G14 (push / pick, 9): the oracle's batched DATD3 take_action (two actors, two critics on cat(s, a_i), the better-valued action) against vectors
     produced by calling the reference's own DATD3_MLP.take_action one state at a time (algo/DATD3/DATD3_mlp.py:88-109): Q values to
     1e-5, the same actor picked wherever the two Q values are not within rounding of each other (both branches occur), actions 1e-6."""
-    g = golden_npz("datd3_take_action_seed0.npz")
+    g = golden_npz(fixture)
     nets = [{k: g["%s_%s" % (n, k.replace(".", "_"))] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
             for n in ("actor1", "actor2", "critic1", "critic2")]
     a, q1, q2, pick = O.datd3_take_action(nets, g["states"], float(g["action_bound"]))
     assert np.abs(q1 - g["q1"]).max() < 1e-5 and np.abs(q2 - g["q2"]).max() < 1e-5
     clear = np.abs(g["q1"] - g["q2"]) > 1e-4
-    assert clear.sum() >= 250 and 100 < g["picked_actor"][clear].sum() < 156
+    assert clear.sum() >= 245 and 100 < g["picked_actor"][clear].sum() < 156
     assert np.array_equal(pick[clear], g["picked_actor"][clear].astype(np.uint8)) and np.abs(a - g["actions"])[clear].max() < 1e-6
 
 
