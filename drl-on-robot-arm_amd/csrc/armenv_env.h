@@ -1047,8 +1047,6 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
     asm volatile("" ::"v"(an[0]), "v"(an[1]), "v"(an[2]));
   }
   ActionPrefetch an_next{0.f, 0.f, 0.f};
-  [[maybe_unused]] float nz_spec[3] = {0.f, 0.f, 0.f};               // in-kernel random policy: the next step's draws (see below)
-  [[maybe_unused]] uint32_t spec_step = 0xFFFFFFFFu, spec_ep = 0u;
   [[maybe_unused]] uint32_t w_trips = 0;
   // the link frames travel from step to step in registers -- except across a fused actor, which needs the whole register file
   // between two env steps (the lanes then recompute the frame at the top of every step)
@@ -1083,17 +1081,7 @@ void env_rollout_kernel(EnvParams<T> P, PolicyParams pol, int32_t steps, const f
       }
       float nz[3];
       // the episode index of the stream is the number of resets so far minus one (the running episode)
-      if constexpr (POLICY == ARMENV_POLICY_RANDOM && !Lane::Chain::kGeneric) {   // (the generic-chain kernels have no registers to carry the draws in)
-        // The draws of step t + 1 are made during step t, ahead of its IK: Philox + Box-Muller are ~250 integer / f32 instructions
-        // with no tie to the IK's dependent f64 chains, and in one block with the peeled trips hipcc can issue them into those chains'
-        // waits.  Speculative on "the env does not finish at step t": the key (episode, step) is checked, a reset re-draws.
-        if (__builtin_expect(spec_step == (uint32_t)L.step && spec_ep == episode - 1u, 1)) { nz[0] = nz_spec[0]; nz[1] = nz_spec[1]; nz[2] = nz_spec[2]; }
-        else policy_noise(P.seed, P.env_id0 + (uint64_t)i, episode - 1u, (uint32_t)L.step, nz);
-        spec_step = (uint32_t)L.step + 1u; spec_ep = episode - 1u;
-        policy_noise(P.seed, P.env_id0 + (uint64_t)i, spec_ep, spec_step, nz_spec);
-      } else {
-        policy_noise(P.seed, P.env_id0 + (uint64_t)i, episode - 1u, (uint32_t)L.step, nz);
-      }
+      policy_noise(P.seed, P.env_id0 + (uint64_t)i, episode - 1u, (uint32_t)L.step, nz);
       static_for<0, 3>([&](auto KI) {
         constexpr int k = KI;
         float v = fmaf(nz[k], pol.sigma, mu[k]);                          // + N(0, sigma), main.py:116
