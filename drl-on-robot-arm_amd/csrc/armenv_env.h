@@ -731,9 +731,9 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
   // The cube in the plane: collision detection at the positions the step starts from (tool = vertical cylinder about the link-7
   // frame's xy, reaching tool_below under it), velocity-level contact along the horizontal normal unless the tool sits less deep in the
   // cube from above than from the side (then it presses the cube onto the table), Coulomb friction once the cube has landed, integration.
-  // Two exec-mask regions at most -- lanes in contact, lanes whose cube moves -- with selects inside (eight nested branches cost the
-  // push step 5 % of its cycles for 0.7 % more instructions, profiles/r05_pmc_push_pick.json); square roots and quotients through
-  // v_rsq + Newton (fast_rsqrt: a few ulp), the overlap test on squared lengths.
+  // Two exec-mask regions at most -- lanes in contact, lanes whose cube moves -- with selects inside (a wave that has its SIMD to itself
+  // pays 20-50 ns per taken branch); square roots and quotients through v_rsq + Newton (fast_rsqrt: a few ulp), the overlap test on
+  // squared lengths.
   AE_DEV void contact_dyn(const EnvParams<T> &P, const EnvCold<T> &K, const T (&p)[3], int k) {
     const T h = P.push_cube_half, r = K.tool_radius, dt = K.dt;
     const T lo = p[2] - K.tool_below;
