@@ -69,14 +69,15 @@ class RLPickEnv:
     def reset(self):
         self.step_counter = 0
         cube, target = draw_pick_placement()
-        # the cube is spawned at z = 0.01 (the placement test above sees it there) and comes to rest on the table: what the
-        # reference's first observation shows (fitted to its recorded push run, ArmEnvConfig.push_rest_z); the target stays
-        cube = [cube[0], cube[1], float(self._eng.cfg.push_rest_z)]
+        # the cube (the push task's body, :210) is spawned at z = 0.01 (the placement test above sees it there); its height is the
+        # engine's from there on: one step into its fall after reset()'s own stepSimulation (:242), on the table within seven env steps
+        # (two stepSimulation calls per env step, :348 and :417; ArmEnvConfig.push_contact_model); the target stays
         goal = torch.tensor([cube + target], dtype=torch.float64).to(torch.float32)
         obs = self._eng.reset(goal=goal)[0].cpu().numpy()
         # keep the f64 placement exactly (the engine's reset_with_goal takes f32)
         st = self._eng.get_state()["aux"].cpu().numpy()
-        st[0, 0:3], st[0, 3:6] = cube, target
+        st[0, 0:2], st[0, 3:6] = cube[0:2], target
+        cube = [cube[0], cube[1], float(st[0, 2])]
         st[0, 6] = math.sqrt(sum((a - b) ** 2 for a, b in zip(cube, target)))
         self._eng.set_state(aux=st)
         self._d_last = float(np.linalg.norm(np.asarray(cube) - np.asarray(target), axis=-1))   # last_object_pos / last_target_pos (:243-245)

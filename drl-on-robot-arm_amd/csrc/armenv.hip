@@ -377,7 +377,7 @@ int armenv_create(const ArmEnvConfig *cfg, ArmEnv **out) {
     return fail(ARMENV_EINVAL, "armenv_create: rollout_straggler_trips must be in 0..64");
   if (cfg->rollout_waves_per_simd < 0 || cfg->rollout_waves_per_simd > 2) return fail(ARMENV_EINVAL, "armenv_create: rollout_waves_per_simd must be 0, 1 or 2");
   if (cfg->push_contact_model < 0 || cfg->push_contact_model > 1 || cfg->reserved0 != 0) return fail(ARMENV_EINVAL, "armenv_create: push_contact_model must be 0 or 1 (reserved0 0)");
-  if (cfg->task == ARMENV_TASK_PUSH && cfg->push_contact_model == 1 &&
+  if (cfg->task != ARMENV_TASK_REACH && cfg->push_contact_model == 1 &&
       !(cfg->push_dt > 0.0 && cfg->push_gravity > 0.0 && cfg->push_drop_contact > 0.0 && cfg->push_drop_contact < 1.0 && cfg->push_drop_relax > 0.0 &&
         cfg->push_drop_relax <= 1.0 && cfg->push_contact_erp >= 0.0 && cfg->push_friction >= 0.0 && cfg->push_tool_radius > 0.0))
     return fail(ARMENV_EINVAL, "armenv_create: push_contact_model 1 needs push_dt, push_gravity, push_tool_radius > 0, push_drop_contact in (0, 1), push_drop_relax in (0, 1], push_contact_erp, push_friction >= 0");

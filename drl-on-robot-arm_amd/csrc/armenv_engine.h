@@ -194,6 +194,7 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
     K.push_place_z = cfg.push_place_z;
     {   // the cube under stepSimulation (CubeLane::cube_fall / contact_dyn): constants folded on the host in f64
       K.push_model = cfg.task == ARMENV_TASK_PUSH ? cfg.push_contact_model : 0;
+      K.fall_on = cfg.task != ARMENV_TASK_REACH && cfg.push_contact_model == 1 ? 1 : 0;
       const double c = 0.5 * cfg.push_gravity * cfg.push_dt * cfg.push_dt;
       int kl = 1;
       while (kl < 100000 && c * (double)kl * (double)(kl + 1) < cfg.push_drop_contact) ++kl;

@@ -23,7 +23,8 @@ template <typename T> struct EnvCold {
   uint64_t seed, env_id0;
   // push task, ArmEnvConfig.push_contact_model = 1: the cube under stepSimulation (CubeLane::cube_fall, contact_dyn).  Read once per
   // step, behind the IK loop.
-  int32_t push_model;       // 0: rounds 1-4 (tool sphere, full push-out; always 0 for the pick task), 1: fall + velocity-level contact
+  int32_t push_model;       // contact: 0 rounds 1-4 (tool sphere, full push-out; always 0 for the pick task), 1 velocity-level contact
+  int32_t fall_on;          // 1: the cube falls from its spawn height (push and pick: the same body in the same scene); 0: at rest from reset on
   int32_t fall_land;        // the stepSimulation call (counted from the spawn) in which the falling cube reaches the table
   T fall_c;                 // g dt^2 / 2: the cube is fall_c k (k + 1) below its spawn height after k free steps
   T fall_keep;              // 1 - push_drop_relax
@@ -581,7 +582,7 @@ AE_DEV void cube_sample(const EnvParams<T> &P, int64_t i, uint32_t episode, T (&
   }
   // push_contact_model 1: spawned at push_place_z, the cube has begun to fall in reset()'s own stepSimulation (:241); otherwise it
   // is already at rest on the table
-  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = K.push_model == 1 ? K.place_z - K.fall_c * T(1) * T(2) : (T)K.push_rest_z;
+  cube[0] = (T)cx; cube[1] = (T)cy; cube[2] = K.fall_on ? K.place_z - K.fall_c * T(1) * T(2) : (T)K.push_rest_z;
   target[0] = (T)tx; target[1] = (T)ty; target[2] = (T)tz;
 }
 
@@ -644,7 +645,7 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     if (goal_in) {
       static_for<0, 3>([&](auto KI) { constexpr int k = KI; cube[k] = (T)goal_in[6 * i + k]; target[k] = (T)goal_in[6 * i + 3 + k]; });
       // the caller places the cube in the plane; its height is the engine's (one step into its fall, as in cube_sample)
-      if (P.cold->push_model == 1) cube[2] = P.cold->place_z - P.cold->fall_c * T(1) * T(2);
+      if (P.cold->fall_on) cube[2] = P.cold->place_z - P.cold->fall_c * T(1) * T(2);
     } else {
       cube_sample<PICK, T>(P, i, ep, cube, target);
     }
@@ -844,6 +845,11 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     if constexpr (PICK) {
       q[NJ - 1] = q7s;              // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
       cq[NJ - 1] = c7s; sq[NJ - 1] = s7s;
+      // RLPickEnv calls stepSimulation twice per env step -- step() :348 and, behind the observation, _reward() :417 -- so env step j
+      // observes the cube after call 2 j of its fall (reset() made call 1) and leaves it after call 2 j + 1; a held cube rides the gripper
+      const EnvCold<T> *Kp = P.cold;
+      asm volatile("" : "+s"(Kp));
+      if (Kp->fall_on && grip != T(2)) cube_fall(*Kp, 2 * (step + 1));
       grip_step(P, p0, S);          // :349, :412-417
     } else {
       // (the constants are read HERE: behind an opaque copy of the pointer hipcc cannot hoist their scalar loads above the IK loop, where
@@ -889,6 +895,9 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     const bool rederive = kTrigRederive > 0 && (step & (kTrigRederive - 1)) == 0;     // step >= 1 here
     store_obs9<T>(io.obs, i, S.p, cube, target);                                     // :308 (a reset overwrites it below)
     cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
+    if constexpr (PICK) {
+      if (P.cold->fall_on && grip != T(2)) cube_fall(*P.cold, 2 * step + 1);       // :417, behind the observation
+    }
     if (__builtin_expect(done | rederive, 0)) {
       if (done) {
         P.last_return[i] = ep_ret;

@@ -176,7 +176,10 @@ typedef struct ArmEnvConfig {
    *     shipped reward within 12.4 (rounds 1-4: 25-195 off), final cube-target distances within 4.3 cm.  Effective values of this planar
    *     stand-in, not Bullet's contact parameters.
    *   0: rounds 1-4 -- tool sphere of push_eef_radius at the link-7 frame, the whole penetration removed in one step, the cube
-   *     already at rest at push_rest_z after reset() (what the pick task's gripper tip still uses). */
+   *     already at rest at push_rest_z after reset().
+   * The pick task loads the SAME body into the same scene (rl_pick_env.py:210): with push_contact_model = 1 its cube falls the same way
+   * -- RLPickEnv calls stepSimulation twice per env step (:348, and :417 behind the observation), so it lands within seven env steps --
+   * unless the gripper holds it; its gripper tip keeps the model-0 contact (build-defined). */
   double push_tool_radius;    /* 0.045: the flange's radius */
   double push_tool_below;     /* 0.045: the flange face below the link-7 frame */
   double push_contact_erp;    /* 0.01, fitted (Bullet's contact ERP, 0.2, is the share against an immovable body; link 7 weighs 0.3 kg) */

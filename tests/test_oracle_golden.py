@@ -398,7 +398,7 @@ def test_pick_placement_and_reset(O, kuka):
     spawn = st.aux[:, 0:3].copy(); spawn[:, 2] = 0.01                    # :194: the placement test sees the cube at its spawn height
     ds = np.linalg.norm(spawn - st.aux[:, 3:6], axis=1)
     assert (ds >= 0.22).all() and (ds <= 0.25).all()                     # rl_pick_env.py:205-208 (3-D distance)
-    assert (st.aux[:, 2] == cfg.push_rest_z).all()                       # the cube at rest on the table
+    assert np.allclose(st.aux[:, 2], 0.01 - 10.0 / 240.0 ** 2, atol=1e-15)  # the push task's cube in the same scene (:210): one step into its fall
     assert st.aux[:, 5].min() >= 0.0 and st.aux[:, 5].max() <= 0.26 and st.aux[:, 5].std() > 0.03   # :200 floating target
     assert np.allclose(st.aux[:, 6], d) and not st.aux[:, 7:].any() and (st.episode == 1).all()
     assert np.abs(obs[:, 3:9] - st.aux[:, :6].astype(np.float32)).max() == 0
@@ -409,8 +409,10 @@ def test_pick_placement_and_reset(O, kuka):
 def test_pick_arm_pipeline_and_gripper(O, kuka):
     """rl_pick_env.py:310-351: dv = 0.08, z <= 0.55 + 0.257, start position rounded through float32, joint 7 never
     written; build-defined gripper: closes within 6 mm of the cube (:412), holds a cube centred under the tool, the
-    held cube rides with the tip, success when it reaches the floating target (:425)."""
+    held cube rides with the tip, success when it reaches the floating target (:425).  Gripper mechanics on the caller's cube
+    height (push_contact_model = 0: no fall, the cube stays where reset_with_goal puts it); the fall has its own test below."""
     cfg = O.default_config("pick")
+    cfg.push_contact_model = 0
     L = cfg.pick_gripper_length
     st = O.PickState(1)
     O.pick_reset_with_goal(kuka, cfg, st, [[0.5, 0.0, 0.01, 0.5, 0.1, 0.2]])
@@ -456,6 +458,27 @@ def test_pick_arm_pipeline_and_gripper(O, kuka):
         a = (way - tip) / 0.08
         obs, r, d, s, it = O.pick_step(kuka, cfg, st, (a / max(np.abs(a).max(), 2.0))[None])
     assert st.aux[0, 7] == 1 and abs(st.aux[0, 2] - 0.01) < 1e-8 and st.aux[0, 1] > 0.02    # pushed along +y on the table, never lifted
+
+
+def test_pick_cube_falls_like_the_push_cube_two_calls_per_step(O, kuka):
+    """RLPickEnv loads the push task's cube into the same scene (rl_pick_env.py:210: models/cube_small_push.urdf at z = 0.01 over the
+    table) and calls stepSimulation in reset() (:242) and TWICE per env step (step() :348, and _reward() :417 behind the observation):
+    the cube's fall -- pinned for that body and scene by the reference's recorded push runs -- is observed after call 2 j at env step j:
+    free fall through call 13, 0.8 mm into the table, then back up to the rest height; on the table from step 7 on."""
+    cfg = O.default_config("pick")
+    assert cfg.push_contact_model == 1
+    st = O.PickState(1)
+    O.pick_reset_with_goal(kuka, cfg, st, [[0.5, 0.0, 0.01, 0.5, 0.1, 0.2]])
+    c = 0.5 * 10.0 / 240.0 ** 2
+    assert abs(st.aux[0, 2] - (0.01 - c * 2)) < 1e-15
+    zs = []
+    for j in range(1, 31):
+        obs, r, d, s, it = O.pick_step(kuka, cfg, st, np.array([[0.0, 0.0, 1.0]]))       # the arm goes up, away from the cube
+        zs.append(float(obs[0, 5]))
+    for j in range(1, 7):                                                   # observed after call 2 j <= 12: free fall
+        assert abs(zs[j - 1] - (0.01 - c * (2 * j) * (2 * j + 1))) < 1e-7, j
+    assert zs[6] < cfg.push_rest_z and all(zs[j] >= zs[j - 1] for j in range(7, 30)) and abs(zs[29] - cfg.push_rest_z) < 1e-5
+    assert st.aux[0, 7] == 0 and np.allclose(st.aux[0, 0:2], [0.5, 0.0], atol=1e-7)
 
 
 # ------------------------------------------------------------------------------ trajectory store + HER (next row 8f.1)
