@@ -846,10 +846,14 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
       q[NJ - 1] = q7s;              // rl_pick_env.py:343: joints 0..5 only; link-7 position and tool axis do not depend on q7
       cq[NJ - 1] = c7s; sq[NJ - 1] = s7s;
       // RLPickEnv calls stepSimulation twice per env step -- step() :348 and, behind the observation, _reward() :417 -- so env step j
-      // observes the cube after call 2 j of its fall (reset() made call 1) and leaves it after call 2 j + 1; a held cube rides the gripper
+      // observes the cube after call 2 j of its fall (reset() made call 1).  The state between two steps is the OBSERVED one: the call
+      // that follows an observation is made up for here, ahead of call 2 j.  A held cube rides the gripper instead.
       const EnvCold<T> *Kp = P.cold;
       asm volatile("" : "+s"(Kp));
-      if (Kp->fall_on && grip != T(2)) cube_fall(*Kp, 2 * (step + 1));
+      if (Kp->fall_on && grip != T(2)) {
+        if (step > 0) cube_fall(*Kp, 2 * step + 1);
+        cube_fall(*Kp, 2 * step + 2);
+      }
       grip_step(P, p0, S);          // :349, :412-417
     } else {
       // (the constants are read HERE: behind an opaque copy of the pointer hipcc cannot hoist their scalar loads above the IK loop, where
@@ -895,9 +899,6 @@ template <class C, typename T, bool PICK, int MODE = 0> struct CubeLane {
     const bool rederive = kTrigRederive > 0 && (step & (kTrigRederive - 1)) == 0;     // step >= 1 here
     store_obs9<T>(io.obs, i, S.p, cube, target);                                     // :308 (a reset overwrites it below)
     cur_obs[0] = (float)S.p[0]; cur_obs[1] = (float)S.p[1]; cur_obs[2] = (float)S.p[2];
-    if constexpr (PICK) {
-      if (P.cold->fall_on && grip != T(2)) cube_fall(*P.cold, 2 * step + 1);       // :417, behind the observation
-    }
     if (__builtin_expect(done | rederive, 0)) {
       if (done) {
         P.last_return[i] = ep_ret;

@@ -178,7 +178,8 @@ typedef struct ArmEnvConfig {
    *   0: rounds 1-4 -- tool sphere of push_eef_radius at the link-7 frame, the whole penetration removed in one step, the cube
    *     already at rest at push_rest_z after reset().
    * The pick task loads the SAME body into the same scene (rl_pick_env.py:210): with push_contact_model = 1 its cube falls the same way
-   * -- RLPickEnv calls stepSimulation twice per env step (:348, and :417 behind the observation), so it lands within seven env steps --
+   * -- RLPickEnv calls stepSimulation twice per env step (:348, and :417 behind the observation), so it lands within seven env steps;
+   * the state between two steps holds the cube as the last observation showed it --
    * unless the gripper holds it; its gripper tip keeps the model-0 contact (build-defined). */
   double push_tool_radius;    /* 0.045: the flange's radius */
   double push_tool_below;     /* 0.045: the flange face below the link-7 frame */

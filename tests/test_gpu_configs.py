@@ -114,11 +114,9 @@ def test_n1_cube_envs_return_the_f64_reward(envs, O, kuka, kind):
     st = (O.PushState if kind == "push" else O.PickState)(1)
     reset_g, stepf = (O.push_reset_with_goal, O.push_step) if kind == "push" else (O.pick_reset_with_goal, O.pick_step)
     reset_g(kuka, cfg, st, state[3:9].reshape(1, 6))
-    if kind == "push":       # the cube's height is the engine's on both sides (one step into its fall); the f64 placement in the plane
-        assert abs(st.aux[0, 2] - state[5]) < 1e-15 and abs(state[5] - (0.01 - 10.0 / 240.0 ** 2)) < 1e-15
-        st.aux[0, 0:2] = state[3:5]; st.aux[0, 3:6] = state[6:9]
-    else:
-        st.aux[0, :6] = state[3:9]                               # the f64 placement (reset_with_goal takes f32)
+    # the cube's height is the engine's on both sides (one step into its fall); the f64 placement in the plane (reset_with_goal takes f32)
+    assert abs(st.aux[0, 2] - state[5]) < 1e-15 and abs(state[5] - (0.01 - 10.0 / 240.0 ** 2)) < 1e-15
+    st.aux[0, 0:2] = state[3:5]; st.aux[0, 3:6] = state[6:9]
     st.aux[0, 6] = np.linalg.norm(st.aux[0, 0:3] - st.aux[0, 3:6])
     worst = 0.0
     moved = 0
