@@ -121,7 +121,7 @@ def _free_run(envs, O, kuka, task, n, launches, R, sigma, seed, max_steps=500, s
     book = FenceBook(n, int(cfg.ik_max_iters), float(cfg.fence_pivot))
     iters, minpiv = np.zeros(n, dtype=np.int32), np.zeros(n)
     worst_obs = worst_rew = 0.0
-    upd_mismatch = flag_mismatch = 0
+    upd_mismatch = flag_mismatch = rew_flips = 0
     gpu_cap = 0
     ep_g = ep_o = 0
     bufs = {}
@@ -141,7 +141,12 @@ def _free_run(envs, O, kuka, task, n, launches, R, sigma, seed, max_steps=500, s
             flag_mismatch += int(fl[chk].sum())
             book.task_space(d, fl, np.abs(obs_g[t][:, :3] - obs_o[:, :3]).max(1))
             same = chk & (done_g[t] == done_o)
-            worst_rew = max(worst_rew, float(np.abs(rew_g[t].astype(np.float64) - rew_o)[same].max(initial=0.0)))
+            # the shaped reward has a threshold (rl_push_env.py:393-394: -1 when the distance moved by less than 1e-5, -100 x the
+            # change otherwise): a change within rounding of 1e-5 -- the falling / settling cube passes through it -- lands on either side
+            rg = rew_g[t].astype(np.float64)
+            flip = ((rg == -1.0) ^ (rew_o == -1.0)) & (np.minimum(np.abs(rg), np.abs(rew_o)) < 2e-3)
+            rew_flips += int((flip & same).sum())
+            worst_rew = max(worst_rew, float(np.abs(rg - rew_o)[same & ~flip].max(initial=0.0)))
             upd_mismatch += int((upd_g[t].astype(np.int32) != iters)[chk].sum())
             ep_g += int(done_g[t].sum()); ep_o += int(done_o.sum())
             book.advance(done_g[t], done_o)
@@ -149,7 +154,8 @@ def _free_run(envs, O, kuka, task, n, launches, R, sigma, seed, max_steps=500, s
             book.resync(st, {k: _np(v) for k, v in e.get_state().items()})
     cnt = e.counters()
     e.close()
-    return dict(book=book, worst_obs=worst_obs, worst_rew=worst_rew, upd_mismatch=upd_mismatch, flag_mismatch=flag_mismatch,
+    assert rew_flips <= 1e-5 * book.total + 2, rew_flips
+    return dict(book=book, worst_obs=worst_obs, worst_rew=worst_rew, upd_mismatch=upd_mismatch, flag_mismatch=flag_mismatch, rew_flips=rew_flips,
                 gpu_cap=gpu_cap, counters=cnt, ep_g=ep_g, ep_o=ep_o)
 
 
@@ -159,7 +165,7 @@ def _report(task, r):
             f"ill-conditioned IK call {b.tainted} ({100.0 * b.tainted / b.total:.2f} %), out of step {b.desynced} "
             f"({100.0 * b.desynced / b.total:.3f} %); capped calls oracle {b.cap_calls} gpu {r['gpu_cap']} (counter {c['cap_steps']}), "
             f"ill-conditioned calls oracle {b.cond_calls} gpu counter {c['illcond_steps']}; worst |obs| {r['worst_obs']:.2e} "
-            f"worst |reward| {r['worst_rew']:.2e}; IK update counts differing {r['upd_mismatch']}; flags differing {r['flag_mismatch']}; "
+            f"worst |reward| {r['worst_rew']:.2e} ({r['rew_flips']} steps on either side of the reward's 1e-5 threshold); IK update counts differing {r['upd_mismatch']}; flags differing {r['flag_mismatch']}; "
             f"episodes gpu {r['ep_g']} oracle {r['ep_o']} || task-space tier: {b.t2_steps} env-steps ({100.0 * b.t2_steps / b.total:.3f} %), "
             f"within 1e-4 {100.0 * b.t2_within_1e4 / max(1, b.t2_steps):.4f} %, within 1e-3 {100.0 * b.t2_within_1e3 / max(1, b.t2_steps):.4f} %, "
             f"worst |obs| {b.t2_worst:.2e} (end-effector part {b.t2_worst_eef:.2e}), flags differing where obs agree {b.t2_flags}")
