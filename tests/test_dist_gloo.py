@@ -60,3 +60,66 @@ def test_return_all_gather_world2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+BARRIER_WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from armenv.dist import ReturnGatherer, ShmBarrier, init_process_group
+    rank, local_rank, world = init_process_group("gloo", "cpu")
+    b = ShmBarrier(rank, world, timeout_s=60.0)
+    # a barrier orders the ranks: nobody leaves barrier k before the slowest rank has entered it
+    stamps = np.zeros((50, 2))
+    for k in range(50):
+        if rank == k %% world:
+            time.sleep(0.002)                   # the slow rank of this round
+        stamps[k, 0] = time.monotonic()
+        b.wait()
+        stamps[k, 1] = time.monotonic()
+    allst = [None] * world
+    dist.all_gather_object(allst, stamps)
+    if rank == 0:
+        st = np.stack(allst)                    # [world, 50, (enter, leave)]; CLOCK_MONOTONIC is one clock for the node
+        assert (st[:, :, 1].min(axis=0) >= st[:, :, 0].max(axis=0) - 1e-6).all()
+        assert (st[:, 1:, 0] >= st[:, :-1, 1]).all()
+    assert b.epoch == 50
+    # the callable form of ReturnGatherer.launch (the producer runs where the gatherer wants it)
+    g = ReturnGatherer(3, "cpu", world)
+    g.launch(lambda: torch.full((3,), float(rank)))
+    assert torch.equal(g.result(), torch.arange(world, dtype=torch.float32).repeat_interleave(3))
+    g.order_after_read()                        # no stream on CPU: nothing to order, must not fail
+    b.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shm_barrier_orders_the_ranks_of_a_node(tmp_path, world):
+    """armenv.dist.ShmBarrier -- the barrier of bench.py's timed bracket since round 6 (one cache line per rank in a page of
+    /dev/shm, named by rank 0 and unlinked once mapped): 50 rounds with a different slow rank each, entry / exit stamps on the
+    node's monotonic clock."""
+    script = tmp_path / "worker.py"
+    script.write_text(BARRIER_WORKER % PKG)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("armenv-barrier-")]
+
+
+def test_shm_barrier_single_rank_is_the_same_code():
+    from armenv.dist import ShmBarrier
+    b = ShmBarrier(0, 1)
+    for _ in range(1000):
+        b.wait()
+    assert b.epoch == 1000 and not [f for f in os.listdir("/dev/shm") if f.startswith("armenv-barrier-")]
+    b.close()

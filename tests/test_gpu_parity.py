@@ -2223,11 +2223,13 @@ def test_bench_driver_shape_with_gathers_every_region():
     # a kernel-time figure beside the wall-clock one, and the host-side costs of the bracket (barrier, gather wait) stated
     assert d["value_kernel"] >= d["value"] > 0 and len(d["config"]["per_rank"]["kernel_ms"]) == 2
     assert d["value_kernel"] == pytest.approx(16384 * 20 / (max(d["config"]["per_rank"]["kernel_ms"]) * 1e-3), rel=1e-6)
-    for k in ("barrier", "closing_sync", "gather_wait", "enqueue", "wait_for_gpu"):
+    for k in ("barrier", "shm_barrier", "gather_issue", "gather_wait", "enqueue", "wait_for_gpu", "collective"):
         assert k in d["config"]["host_us"], k
-    # `value` runs on the contract's bracket (closing synchronise incl. the logging collective, then the barrier);
-    # the rank-local clock is a separate key
-    assert d["value_steps"] >= d["value"] and len(d["config"]["per_rank"]["wall_steps_ms"]) == 2
+    # round 6: `value` runs on synchronise + shared-memory barrier | K steps | launch-stream synchronise + shared-memory barrier (the
+    # same code at N = 1); the rank-local clock and rounds 1-5's bracket (collective + RCCL barrier inside) are separate keys
+    assert d["value_steps"] >= d["value"] >= d["value_bracketed"] and len(d["config"]["per_rank"]["wall_steps_ms"]) == 2
+    assert d["config"]["collective_verified"] is True and "shared-memory barrier" in d["config"]["bracket"]
+    assert max(d["config"]["per_rank"]["wall_ms"]) <= max(d["config"]["per_rank"]["wall_bracketed_ms"])
     assert max(d["config"]["per_rank"]["wall_steps_ms"]) <= max(d["config"]["per_rank"]["wall_ms"])
     assert d["config"]["rccl_ranks_seen"] == {"world_size": 2, "backend": "gloo"}
 
