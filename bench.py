@@ -990,6 +990,10 @@ def main():
                        "envs_per_gpu": n, "total_envs": total_envs, "kernel": kernel, "mode": args.mode, "policy": args.policy,
                        "steps_per_launch": steps_per_launch, "launches": launches, "device_prewarm_ms": args.prewarm_ms,
                        "busy_ahead_ms": args.busy_ahead_ms, "rehearsals": args.rehearsals,
+                       # how `value` is taken: 1 = rounds 1-4 (W warm-up steps, then the K steps after host round trips:
+                       # this line's ab_host_restore is that regime); 2 = round 5 (--busy-ahead-ms of scratch work in front of every
+                       # region); 3 = round 6 (2 + the shared-memory bracket, identical for 1 and N ranks)
+                       "procedure_version": 3,
                        "gathers_in_timed_region": gathers, "state_digest": digests, "per_rank": per_rank,
                        "gathered_returns_sha256": gathered["sha256"] if gathered else None,
                        "gathered_returns_mean": gathered["mean"] if gathered else None,

@@ -88,8 +88,10 @@ class BatchedArmEnv:
             return
         cur = torch.cuda.current_stream(self.device)
         fs.wait_stream(cur)
-        yield
-        cur.wait_stream(fs)
+        try:
+            yield
+        finally:
+            cur.wait_stream(fs)     # also when the call in between raised: the caller's tensors stay ordered behind the fixed stream
 
     @property
     def kernel_name(self):
@@ -111,6 +113,24 @@ class BatchedArmEnv:
         if action.device != self.device or action.dtype != torch.float32 or tuple(action.shape) != (self.num_envs, 3) \
                 or not action.is_contiguous():
             raise ValueError(f"action must be a contiguous float32 tensor [{self.num_envs}, 3] on {self.device}")
+
+    _MLP_KEYS = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+
+    def _mlp_tensors(self, sd, in_dim, out_dim, what):
+        """The six tensors of one of the reference's PolicyNet / QValueNet state dicts (algo/TD3/net_mlp.py:29-71) on the device, f32,
+        contiguous -- after checking every shape: the C ABI takes bare pointers and the packing kernel indexes them with the strides
+        of [256][in_dim], [256][256], [out_dim][256] (a net of another width would be read out of bounds, silently)."""
+        want = {"fc1.weight": (256, in_dim), "fc1.bias": (256,), "fc2.weight": (256, 256), "fc2.bias": (256,),
+                "fc3.weight": (out_dim, 256), "fc3.bias": (out_dim,)}
+        w = []
+        for k in self._MLP_KEYS:
+            if k not in sd:
+                raise ValueError(f"{what}: state dict has no {k!r}")
+            if tuple(sd[k].shape) != want[k]:
+                raise ValueError(f"{what}: {k} has shape {tuple(sd[k].shape)}, this task's net needs {want[k]} "
+                                 f"(obs_dim {self.obs_dim}, hidden 256)")
+            w.append(sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous())
+        return w
 
     # ------------------------------------------------------------------ gym-style API, batched
     def reset(self, mask=None, goal=None):
@@ -187,8 +207,7 @@ class BatchedArmEnv:
         w = [None] * 6
         hidden = 0
         if code in (L.POLICY_ACTOR, L.POLICY_ACTOR_F16X3):
-            keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
-            w = [actor_state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in keys]
+            w = self._mlp_tensors(actor_state_dict, self.obs_dim, 3, "set_policy(%r) actor" % kind)
             hidden = int(w[0].shape[0])
         with self._ordered():
             L.check(self._lib.armenv_set_policy(self._h, code, *[_ptr(t) for t in w], hidden, float(action_bound),
@@ -201,10 +220,10 @@ class BatchedArmEnv:
         `rollout(actions=None)` / `step(None)`: a1 = actor1(s), a2 = actor2(s), the action whose own critic values it higher
         (q1 = critic1(s, a1) >= q2 = critic2(s, a2) -> a1), then a = clip(a + N(0, noise_sigma), +-noise_clip).  Each argument is
         a state dict of the reference's PolicyNet / QValueNet (fc1.weight ... fc3.bias) for this task's observation width."""
-        keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
         keep, mlps = [], []
-        for sd in (actor1, actor2, critic1, critic2):
-            w = [sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in keys]
+        for name, sd in (("actor1", actor1), ("actor2", actor2), ("critic1", critic1), ("critic2", critic2)):
+            critic = name.startswith("critic")
+            w = self._mlp_tensors(sd, self.obs_dim + (3 if critic else 0), 1 if critic else 3, "set_policy_datd3 " + name)
             keep.append(w)
             mlps.append(L.ArmEnvMlp(*[t.data_ptr() for t in w]))
         hidden = int(keep[0][0].shape[0])

@@ -1,8 +1,9 @@
 """N=1 drop-in for ``envs.RLPushEnv`` (/root/reference/envs/rl_push_env.py:43-448): same constructor, attributes,
 ``reset() -> np.float64[9]``, ``step(a) -> (np.float64[9], reward, done, {'is_success': np.float32})`` and the same
 consumption of Python's global ``random`` (6 draws per placement try :197-209, 3 unused draws per step :435-437).
-The arm pipeline and the reward logic run in the HIP kernels; the cube follows the build's simplified push-out model
-(BASELINE.json config 4), not Bullet's rigid-body dynamics."""
+The arm pipeline, the cube and the reward logic run in the HIP kernels.  The cube's free fall after reset() is Bullet's (pinned
+by the reference's recorded runs); its contact with the tool is ArmEnvConfig.push_contact_model's stand-in for Bullet's rigid-body
+step over the KUKA meshes (not parity-checkable here)."""
 import math
 import random
 
@@ -43,6 +44,7 @@ class RLPushEnv:
         self.observation_space = Box(low=[0.2, -0.3, 0], high=[0.7, 0.3, 0.55])  # :100-103
         self.step_counter = 0
         self._eng = BatchedPushEnv(1, device=device, auto_reset=False, precision=64, fk_path=1,
+                                   fence_counters=2,
                                    max_steps=int(self.max_steps_one_episode))
         self.seed()
         self.reset()                                                            # :137
@@ -69,36 +71,26 @@ class RLPushEnv:
         st[0, 0:2], st[0, 3:6] = cube[0:2], target
         cube = [cube[0], cube[1], float(st[0, 2])]
         st[0, 6] = math.sqrt(sum((a - b) ** 2 for a, b in zip(cube, target)))
-        self._eng.set_state(aux=st)
-        self._d_last = float(np.linalg.norm(np.asarray(cube) - np.asarray(target), axis=-1))   # last_object_pos / last_target_pos (:243-245)
+        self._eng.set_state(aux=st)       # aux[6] = d_last: last_object_pos / last_target_pos (:243-245) live in the engine's state
         return self._obs64(obs)
 
     def step(self, action):
+        """One armenv_step launch.  Reward, done and is_success are the kernel's (push_step's f64 diagnostics, armenv_step diag_dev:
+        the C ABI's reward buffer is f32, the reference returns a Python float computed in f64 -- the shaped -100 * (d_now - d_last)
+        of :388-397 / :427 with d_last carried in the engine's state, +100 on success :422-424, the float32-state time-limit reward
+        :400 / :418-420); nothing of the reward is computed on the host."""
         a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 3), dtype=torch.float32).to(self._eng.device)
-        obs, reward, done, success = self._eng.step(a)
+        obs, reward, done, success = self._eng.step(a, want_diag=True)
         self.step_counter += 1
         for k in range(3):
             random.uniform(_LO[k], _HI[k])                                      # :435-437 unused draws
-        o = obs[0].cpu().numpy()
-        r = float(reward[0].item())
-        self.terminated = bool(done[0].item())
-        info = {'is_success': np.float32(bool(success[0].item()))}              # :430-432
-        obs64 = self._obs64(o)
-        # The shaped reward -100 * (d_now - d_last) (:388-397, :427) recomputed in f64 from the env's f64 cube / target state with
-        # the reference's own numpy expressions (armenv_step's reward buffer is f32); the two other branches are exact in f32:
-        # +100 on success (:422-424), and the time-limit reward, which the reference computes from float32 states (:400, :418-420).
-        d_cur = float(np.linalg.norm(obs64[3:6] - obs64[6:9], axis=-1))
-        test = d_cur - self._d_last
-        if abs(test) < 1e-5:
-            test = 0.01
-        self._d_last = d_cur
-        if r == 100.0:
-            reward64 = 100
-        elif self.step_counter > self.max_steps_one_episode:
-            reward64 = r
-        else:
-            reward64 = -test * 100
-        return obs64, reward64, self.terminated, info
+        aux = self._eng.get_state()["aux"][0]
+        packed = torch.cat([obs[0, :3].double(), aux[:6], done.double(), success.double(), self._eng.diag[0, 3:4]]).cpu().numpy()   # one host sync
+        self._aux = packed[3:9]
+        self.terminated = bool(packed[9])
+        info = {'is_success': np.float32(bool(packed[10]))}                     # :430-432
+        obs64 = np.hstack((packed[:3].astype(np.float32), packed[3:6], packed[6:9]))   # :308 (f32 eef, f64 cube, f64 target)
+        return obs64, float(packed[11]), self.terminated, info
 
     def close(self):
         self._eng.close()

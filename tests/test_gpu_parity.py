@@ -1657,9 +1657,22 @@ def test_set_policy_errors(envs):
     e = _mk(envs, 64)
     with pytest.raises(ArmEnvError, match="no actor"):
         e.actor_forward(torch.zeros(4, 6))
+    # every shape is checked before a pointer is taken (the packing kernel indexes with assumed strides)
     bad = dict(tsd); bad["fc1.weight"] = torch.zeros(128, 6); bad["fc1.bias"] = torch.zeros(128)
-    with pytest.raises(ArmEnvError, match="hidden_dim"):
+    with pytest.raises(ValueError, match="fc1.weight has shape"):
         e.set_policy("actor", actor_state_dict=bad)
+    bad = dict(tsd); bad["fc1.weight"] = torch.zeros(256, 9)                 # an actor trained for the push / pick observation
+    with pytest.raises(ValueError, match=r"fc1.weight has shape \(256, 9\)"):
+        e.set_policy("actor_f16x3", actor_state_dict=bad)
+    bad = dict(tsd); del bad["fc3.bias"]
+    with pytest.raises(ValueError, match="no 'fc3.bias'"):
+        e.set_policy("actor", actor_state_dict=bad)
+    critic = dict(tsd); critic["fc1.weight"] = torch.zeros(256, 9); critic["fc3.weight"] = torch.zeros(1, 256); critic["fc3.bias"] = torch.zeros(1)
+    with pytest.raises(ValueError, match="critic2: fc1.weight"):
+        e.set_policy_datd3(tsd, tsd, critic, tsd)                            # an actor where critic 2 belongs
+    with pytest.raises(ValueError, match="actor2: fc1.weight"):
+        e.set_policy_datd3(tsd, critic, critic, critic)
+    e.set_policy_datd3(tsd, tsd, critic, critic)                             # the right shapes pass
     with pytest.raises(ArmEnvError, match="noise"):
         e.set_policy("random", noise_sigma=-1.0)
     e.close()

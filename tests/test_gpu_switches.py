@@ -298,3 +298,39 @@ def test_pipelined_env_equals_the_single_handle_bitwise(envs, task, parts):
     o2, r2, _, _ = pe.run_closed_loop(policy, 40)
     assert torch.equal(o2, want[0]) and torch.equal(r2, want[1]) and torch.equal(pe.get_state()["q"], want[2])
     pe.close(); one.close()
+
+
+def test_pipelined_get_state_with_steps_in_flight(envs):
+    """PipelinedEnv.get_state / episode_stats rely on the per-part ordering of BatchedArmEnv._ordered alone (no join()).
+    With a queue of un-joined launches on the parts' streams, the unjoined read equals the joined one -- and when the wrapped call
+    raises, the caller's stream is still ordered behind the fixed stream (try / finally), so the next read is sound."""
+    n, K = 8192, 40
+    gen = torch.Generator(device=DEV); gen.manual_seed(5)
+    acts = (torch.randn((K, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7).contiguous()
+    one = envs.BatchedReachEnv(n, device=DEV, seed=4, max_steps=25)
+    one.reset()
+    for t in range(K):
+        one.step(acts[t])
+    want, want_stats = one.get_state(), one.episode_stats()
+    one.close()
+    for attempt in range(3):
+        pe = envs.PipelinedEnv(envs.BatchedReachEnv, n, parts=4, device=DEV, seed=4, max_steps=25)
+        pe.reset()
+        torch.cuda.synchronize()
+        for f in pe.bind_steps(acts):
+            f()                                   # 160 launches queued on four streams, nothing joined
+        got = pe.get_state()                      # read while they are in flight
+        stats = pe.episode_stats()
+        junk = [torch.full_like(v, -3.0) for v in got.values()]     # allocator traffic on the caller's stream right behind the read
+        del junk
+        for k in want:
+            assert torch.equal(got[k], want[k]), (attempt, k)
+        for x, y in zip(stats, want_stats):
+            assert torch.equal(x, y), attempt
+        # a failing call inside _ordered() leaves the streams ordered
+        e0 = pe.envs[0]
+        with pytest.raises(Exception):
+            with e0._ordered():
+                raise RuntimeError("boom")
+        assert torch.equal(pe.get_state()["q"], want["q"])
+        pe.close()
