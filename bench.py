@@ -271,10 +271,10 @@ def rooflines(task, policy, precision, n, steps_per_launch, launch_us, updates, 
             "traffic": traffic, "traffic_key": key, "kernel": kernel, "avg_launch_us": launch_us, "algo_bytes_per_launch": algo,
             "binding_bound": "valu", "valu": valu}
     mfma = None
-    if policy.startswith("actor") or policy == "datd3":
+    if policy.startswith("actor") or policy in ("datd3", "daddpg"):
         # 2 * (6*256 + 256*256 + 256*3) flop per env-step; both layers on the MFMA
         af = 2 * (6 * 256 + 256 * 256 + 256 * 3) * n * steps_per_launch
-        if policy == "datd3":     # two actors + two critics (9 -> 256 -> 256 -> 1): DATD3_mlp.py:88-109
+        if policy in ("datd3", "daddpg"):     # two actors + two critic passes (9 -> 256 -> 256 -> 1): DATD3_mlp.py:88-109, DADDPG_mlp.py:90-94
             af = 2 * (2 * (6 * 256 + 256 * 256 + 256 * 3) + 2 * (9 * 256 + 256 * 256 + 256)) * n * steps_per_launch
         if policy == "actor":
             peak, dt, mult = 157.3, "f32 (v_mfma_f32_32x32x2_f32)", 1
@@ -299,6 +299,13 @@ def golden_datd3():
     return [{k: torch.from_numpy(g["%s_%s" % (n_, k.replace(".", "_"))]) for k in keys} for n_ in ("actor1", "actor2", "critic1", "critic2")]
 
 
+def golden_daddpg():
+    """the three nets of DADDPG_MLP(6, 3, 0.7) -- the reference's default agent, config.py:33: golden G15 (produced by importing algo.DADDPG)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "daddpg_take_action_seed0.npz"))
+    keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+    return [{k: torch.from_numpy(g["%s_%s" % (n_, k.replace(".", "_"))]) for k in keys} for n_ in ("actor1", "actor2", "critic")]
+
+
 def secondary_leg(envs, dev, task, n, policy, precision, launches, pre_launches, fence_steps=0):
     """One more BASELINE config timed by the same command: `launches` x armenv_rollout(100) on a fresh
     handle after `pre_launches` untimed ones, HIP events on the launch stream, with the same roofline bookkeeping as the
@@ -316,6 +323,8 @@ def secondary_leg(envs, dev, task, n, policy, precision, launches, pre_launches,
             pool.clamp_(-bound, bound)
     elif policy == "datd3":          # DATD3_MLP.take_action fused: two actors, two critics, the better-valued action
         e.set_policy_datd3(*golden_datd3(), action_bound=bound, noise_sigma=sig, noise_clip=bound)
+    elif policy == "daddpg":         # DADDPG_MLP.take_action fused: two actors, ONE critic on both proposals (three staged nets, four passes)
+        e.set_policy_daddpg(*golden_daddpg(), action_bound=bound, noise_sigma=sig, noise_clip=bound)
     else:
         e.set_policy(policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if task == "reach" else 1e9,
                      actor_state_dict=golden_actor() if policy.startswith("actor") else None)
@@ -705,13 +714,13 @@ def main():
     def do_gather():
         """A logging all-gather in the middle of a region: armenv_episode_stats on the launch stream (the next launch overwrites
         what it reads, so it has to sit in front of it anyway), the collective on the side stream."""
-        gather.launch(env.episode_stats()[0])
+        gather.launch(env.episode_returns_f32())
 
     def do_gather_trailing():
         """The all-gather that ends a region: armenv_episode_stats too goes to the side stream (behind the region's steps), so the
         launch stream carries the K steps and nothing else and its synchronise closes the clock on them; the collective is waited
         for -- and checked -- after the clock (logging only, never on the step critical path)."""
-        gather.launch(lambda: env.episode_stats()[0])
+        gather.launch_into(lambda stage: env.episode_returns_f32(out=stage))
 
     def plan(k):
         """The launches of exactly k env steps of every env of this rank, prepared up front (buffers, pointers, the
@@ -1009,6 +1018,9 @@ def main():
                        "collective_us": host_us_main.get("collective", 0.0), "barrier_us": host_us_main.get("shm_barrier", 0.0),
                        "rccl_barrier_us": host_us_main.get("barrier", 0.0),
                        "collective_verified": (collective_ok if multi else None),
+                       # how the logging all-gather is issued: RCCL's own C API on the side stream (armenv.dist.RcclComm) or torch.distributed
+                       "collective_transport": ("rccl-direct" if gather.rccl is not None else ("torch.distributed" if multi else None)),
+                       "collective_direct_error": gather.direct_error,
                        "parallelism": "env-sharded x%d, %s all-gather of episode returns every %d steps and at least once per "
                                       "timed region (logging only, side stream; issued INSIDE the clock of `value`, waited for and verified "
                                       "right after it -- config.collective_us; inside the clock of `value_bracketed`)"
@@ -1079,6 +1091,8 @@ def main():
             leg("config4_push", lambda: secondary_leg(envs, dev, "push", 32768, "external", args.precision, 5, 6, args.fence_steps))
             # beyond the configs: DATD3_MLP.take_action (a consumer north_star names) folded into the same rollout kernel
             leg("datd3_fused", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "datd3", args.precision, 2, 2))
+            # the reference's DEFAULT agent (config.py:33 opt.algo = 'DADDPG_MLP'): two actors, one critic valuing both proposals
+            leg("daddpg_fused", lambda: secondary_leg(envs, dev, "reach", ENVS_PER_GPU, "daddpg", args.precision, 2, 2))
         if not multi and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline(args.precision))
         # the scalars a record that keeps only flat `config` values would otherwise lose
@@ -1088,7 +1102,7 @@ def main():
         for k_ in ("value_median", "value_min", "value_max", "launch_us_median", "launch_us_min", "launch_us_max"):
             if k_ in line:
                 cfg[k_] = line[k_]
-        for k_, leg_ in (("actor_f32", "config3_actor_f32"), ("actor_f16x3", "config3_actor_f16x3"), ("push", "config4_push"), ("datd3", "datd3_fused")):
+        for k_, leg_ in (("actor_f32", "config3_actor_f32"), ("actor_f16x3", "config3_actor_f16x3"), ("push", "config4_push"), ("datd3", "datd3_fused"), ("daddpg", "daddpg_fused")):
             if isinstance(line.get(leg_), dict) and "us_per_step" in line[leg_]:
                 cfg[k_ + "_us_per_step"] = line[leg_]["us_per_step"]
                 cfg[k_ + "_env_steps_per_s"] = line[leg_]["value_kernel"]
@@ -1112,6 +1126,8 @@ def main():
             cfg["cpu_cores"] = line["cpu_baseline"]["cores"]
         print(json.dumps(line), flush=True)
     env.close()
+    gather.close()
+    shm.close()
     if multi:
         dist.destroy_process_group()
 

@@ -4,11 +4,11 @@ import ctypes as C
 import os
 
 NJ = 7
-ABI_VERSION = 5
+ABI_VERSION = 6
 TASK_REACH, TASK_PUSH, TASK_PICK = 0, 1, 2
 ROBOT_KUKA, ROBOT_DIANA = 0, 1
 FK_AUTO, FK_GENERIC = 0, 1
-POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR, POLICY_ACTOR_F16X3, POLICY_DATD3 = 0, 1, 2, 3, 4
+POLICY_EXTERNAL, POLICY_RANDOM, POLICY_ACTOR, POLICY_ACTOR_F16X3, POLICY_DATD3, POLICY_DADDPG = 0, 1, 2, 3, 4, 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ARMENV_LIB: an alternative build of the same library (A/B timing of two kernel versions inside one GPU session)
@@ -89,7 +89,10 @@ SYMBOLS = {
     "armenv_actor_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "armenv_set_policy_datd3": (C.c_int, [_P, C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp),
                                           C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "armenv_set_policy_daddpg": (C.c_int, [_P, C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp), C.POINTER(ArmEnvMlp),
+                                           C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
     "armenv_datd3_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "armenv_episode_returns_f32": (C.c_int, [_P, _P, _P]),
     "armenv_count_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P]),
     "armenv_write_episodes": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P, _P, _P]),
     "armenv_her_sample": (C.c_int, [C.c_int32, C.POINTER(ArmEnvHerArgs), _P]),

@@ -4,8 +4,10 @@ collective the path has -- an all-gather of per-env episode returns for logging
 
 Works with backend "nccl" (= RCCL over xGMI on ROCm) on GPUs and with "gloo" on CPU tensors (tests).
 """
+import ctypes
 import mmap
 import os
+import threading
 import time
 import uuid
 
@@ -103,6 +105,84 @@ class ShmBarrier:
             pass
 
 
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]        # rccl.h: NCCL_UNIQUE_ID_BYTES
+
+
+class RcclComm:
+    """A communicator of this job's ranks made with RCCL's own C API, through the librccl.so this process has already loaded (the one
+    torch.distributed's "nccl" backend runs on): ncclGetUniqueId on rank 0, the id handed round with the job's process group, then
+    ncclCommInitRank on every rank.  Why, beside torch.distributed: the one collective of this path -- the logging all-gather -- is
+    issued from inside the rollout loop, and its ISSUE is what the loop pays; `dist.all_gather_into_tensor(async_op=True)` costs the
+    host 150-250 us per call (measured: gpurun_out/r06/bench_rccl_world1_*.json host_us.gather_issue), more than a 20-step rollout
+    launch runs; ncclAllGather on a stream the caller names is one C call.  Creation happens in a helper thread with a time limit: a
+    rank that cannot make the communicator reports so, the ranks agree (all-reduce), and the caller falls back to torch.distributed."""
+
+    FLOAT32 = 7           # rccl.h ncclDataType_t
+
+    def __init__(self, device, timeout_s=120.0):
+        self.comm = None
+        self.lib = None
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ok, why = 1, ""
+        try:
+            path = next((l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l or "libnccl" in l), None)
+            if path is None:
+                raise OSError("no RCCL library is loaded in this process")
+            lib = ctypes.CDLL(path)
+            lib.ncclGetUniqueId.restype, lib.ncclGetUniqueId.argtypes = ctypes.c_int, [ctypes.POINTER(_NcclUniqueId)]
+            lib.ncclCommInitRank.restype = ctypes.c_int
+            lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+            lib.ncclAllGather.restype = ctypes.c_int
+            lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            lib.ncclCommDestroy.restype, lib.ncclCommDestroy.argtypes = ctypes.c_int, [ctypes.c_void_p]
+            lib.ncclGetErrorString.restype, lib.ncclGetErrorString.argtypes = ctypes.c_char_p, [ctypes.c_int]
+            self.lib = lib
+        except Exception as e:      # noqa: BLE001
+            ok, why = 0, "binding: %s" % e
+        uid = _NcclUniqueId()
+        if ok and rank == 0 and self.lib.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+            ok, why = 0, "ncclGetUniqueId failed"
+        box = [bytes(uid.internal) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        if ok:
+            ctypes.memmove(ctypes.byref(uid), box[0], 128)
+            res = {}
+
+            def make():
+                torch.cuda.set_device(device)
+                h = ctypes.c_void_p()
+                res["rc"] = self.lib.ncclCommInitRank(ctypes.byref(h), world, uid, rank)
+                res["h"] = h
+            th = threading.Thread(target=make, daemon=True)
+            th.start()
+            th.join(timeout_s)
+            if th.is_alive():
+                ok, why = 0, "ncclCommInitRank did not return within %.0f s" % timeout_s
+            elif res.get("rc", -1) != 0:
+                ok, why = 0, "ncclCommInitRank: %s" % self.lib.ncclGetErrorString(res["rc"]).decode()
+            else:
+                self.comm = res["h"]
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if self.comm is not None:
+                self.lib.ncclCommDestroy(self.comm)
+                self.comm = None
+            raise RuntimeError("RcclComm: not every rank could create the communicator (this rank: %s)" % (why or "ok"))
+        self.world = world
+
+    def all_gather_f32(self, send_ptr, recv_ptr, count, stream_ptr):
+        rc = self.lib.ncclAllGather(send_ptr, recv_ptr, count, self.FLOAT32, self.comm, stream_ptr)
+        if rc != 0:
+            raise RuntimeError("ncclAllGather: %s" % self.lib.ncclGetErrorString(rc).decode())
+
+    def close(self):
+        if self.comm is not None:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 class ReturnGatherer:
     """All-gathers a per-env f32 vector (episode returns) to every rank, off the step's critical path:
     on GPUs the collective runs on a side stream that waits for the producer stream only.
@@ -113,7 +193,10 @@ class ReturnGatherer:
     same n_local on every rank: `shard_range` gives uneven shards when world does not divide the env count, so the
     constructor checks."""
 
-    def __init__(self, n_local, device, world=None, collective=None):
+    def __init__(self, n_local, device, world=None, collective=None, direct=None):
+        """direct: issue the collective with RCCL's C API on the side stream (RcclComm) instead of torch.distributed's call -- default
+        on GPUs with the "nccl" backend unless ARMENV_DIST_DIRECT_RCCL=0; falls back to torch.distributed (with `direct_error` set)
+        when the communicator cannot be made."""
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         # collective: go through torch.distributed even when there is only one rank (a one-rank RCCL communicator: what a
         # 1-GPU box can execute of the multi-GPU path); default: only when there is someone to exchange with
@@ -129,6 +212,14 @@ class ReturnGatherer:
         self.launches = 0
         self._last = None
         self.read_done = None        # (GPU) event on the side stream: the last launch's source has been copied into its slot
+        self.rccl, self.direct_error = None, None
+        if direct is None:
+            direct = os.environ.get("ARMENV_DIST_DIRECT_RCCL", "1") != "0"
+        if direct and self.collective and self.side is not None and dist.is_initialized() and dist.get_backend() == "nccl":
+            try:
+                self.rccl = RcclComm(self.device)
+            except Exception as e:      # noqa: BLE001
+                self.direct_error = str(e)
         if self.collective and dist.is_initialized():
             host = dist.get_backend() != "nccl"
             t = torch.tensor([self.n_local, -self.n_local], dtype=torch.int64, device="cpu" if host else self.device)
@@ -143,6 +234,18 @@ class ReturnGatherer:
         if tuple(t.shape) != (self.n_local,):
             raise ValueError(f"local_returns must have shape ({self.n_local},)")
         return t
+
+    _fills = False      # launch_into: the producer writes the f32 vector straight into the slot's send buffer
+
+    def launch_into(self, fill):
+        """As launch(callable), for a producer that WRITES the vector: `fill(stage)` is called with the slot's f32 send buffer
+        [n_local] (on GPUs with the side stream current) -- BatchedArmEnv.episode_returns_f32(out=stage): one kernel, no
+        intermediate tensor, no conversion copy."""
+        self._fills = True
+        try:
+            self.launch(fill)
+        finally:
+            self._fills = False
 
     def launch(self, local_returns):
         """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs: the side stream waits for
@@ -162,11 +265,24 @@ class ReturnGatherer:
         if self._host_backend():
             # debugging path (several ranks sharing one GPU cannot use RCCL): stage through the host with gloo
             if producer is not None:
-                local_returns = self._check(producer())
+                local_returns = self._produce(producer, slot)
             host = local_returns.detach().to("cpu", torch.float32)
             parts = [torch.empty_like(host) for _ in range(self.world)]
             dist.all_gather(parts, host)
             slot["out"].copy_(torch.cat(parts))
+            return
+        if self.rccl is not None:
+            # RCCL's own call on the side stream: everything of this slot's earlier use is in that stream's order already
+            cur = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(cur)         # the producer of the vector; consumers of the result() of two launches ago
+            with torch.cuda.stream(self.side):
+                src = local_returns if producer is None else self._produce(producer, slot)
+                if src is not slot["stage"]:
+                    slot["stage"].copy_(src)
+                if producer is None:
+                    local_returns.record_stream(self.side)
+                self.read_done = self.side.record_event()
+                self.rccl.all_gather_f32(slot["stage"].data_ptr(), slot["out"].data_ptr(), self.n_local, self.side.cuda_stream)
             return
         if self.side is not None:
             cur = torch.cuda.current_stream(self.device)
@@ -177,8 +293,9 @@ class ReturnGatherer:
                 if prev is not None:
                     prev.wait()               # orders the SIDE stream (where the slot is refilled) behind that collective
                 if producer is not None:
-                    local_returns = self._check(producer())     # allocated and produced on the side stream
-                slot["stage"].copy_(local_returns)
+                    local_returns = self._produce(producer, slot)     # allocated and produced on the side stream
+                if local_returns is not slot["stage"]:
+                    slot["stage"].copy_(local_returns)
                 if producer is None:
                     # the producer's tensor is read on the side stream: keep the caching allocator from recycling it early
                     local_returns.record_stream(self.side)
@@ -189,14 +306,28 @@ class ReturnGatherer:
                     slot["out"].copy_(slot["stage"])
         else:
             if producer is not None:
-                local_returns = self._check(producer())
-            slot["stage"].copy_(local_returns)
+                local_returns = self._produce(producer, slot)
+            if local_returns is not slot["stage"]:
+                slot["stage"].copy_(local_returns)
             if self.collective:
                 parts = [torch.empty_like(slot["stage"]) for _ in range(self.world)]
                 dist.all_gather(parts, slot["stage"])
                 slot["out"].copy_(torch.cat(parts))
             else:
                 slot["out"].copy_(slot["stage"])
+
+    def _produce(self, producer, slot):
+        if self._fills:
+            producer(slot["stage"])
+            return slot["stage"]
+        return self._check(producer())
+
+    def close(self):
+        if self.rccl is not None:
+            if self.side is not None:
+                self.side.synchronize()
+            self.rccl.close()
+            self.rccl = None
 
     def order_after_read(self, stream=None):
         """Make `stream` (default: the current one) wait until the last launch's source vector has been read."""

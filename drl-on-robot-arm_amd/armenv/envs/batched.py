@@ -233,8 +233,44 @@ class BatchedArmEnv:
         torch.cuda.current_stream(self.device).synchronize()
         self._policy = "datd3"
 
+    def set_policy_darc(self, actor1, actor2, critic1, critic2, **kw):
+        """DARC_MLP.take_action (/root/reference/algo/DARC/DARC_mlp.py:92-113): the same two-actor / two-critic selection as DATD3's
+        (`action1 if q1 >= q2 else action2`; the exploration noise the method carries is commented out there, :111) -- one fused
+        policy serves both agents."""
+        self.set_policy_datd3(actor1, actor2, critic1, critic2, **kw)
+        self._policy = "darc"
+
+    def set_policy_daddpg(self, actor1, actor2, critic, action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7):
+        """Install DADDPG_MLP.take_action (/root/reference/algo/DADDPG/DADDPG_mlp.py:77-97 -- opt.algo's default, config.py:33) as
+        the fused policy of `rollout(actions=None)` / `step(None)`: a1 = actor1(s), a2 = actor2(s), the proposal the ONE critic values
+        higher (q1 = critic(s, a1) >= q2 = critic(s, a2) -> a1), then a = clip(a + N(0, noise_sigma), +-noise_clip).  Three nets are
+        packed; the critic's second pass re-uses what its first left in LDS.  `datd3_forward` evaluates it without noise."""
+        keep, mlps = [], []
+        for name, sd in (("actor1", actor1), ("actor2", actor2), ("critic", critic)):
+            is_c = name == "critic"
+            w = self._mlp_tensors(sd, self.obs_dim + (3 if is_c else 0), 1 if is_c else 3, "set_policy_daddpg " + name)
+            keep.append(w)
+            mlps.append(L.ArmEnvMlp(*[t.data_ptr() for t in w]))
+        with self._ordered():
+            L.check(self._lib.armenv_set_policy_daddpg(self._h, *[C.byref(m) for m in mlps], 256, float(action_bound),
+                                                       float(noise_sigma), float(noise_clip), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._policy = "daddpg"
+
+    def episode_returns_f32(self, out=None):
+        """Return of each env's most recently finished episode as ONE f32 vector [N] (armenv_episode_returns_f32: the send buffer
+        of the logging all-gather, written by one kernel on the launch stream; `out` to write into a caller's buffer)."""
+        if out is None:
+            out = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or tuple(out.shape) != (self.num_envs,) or out.device != self.device or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous float32 tensor [{self.num_envs}] on {self.device}")
+        with self._ordered():
+            L.check(self._lib.armenv_episode_returns_f32(self._h, _ptr(out), self._stream()))
+        return out
+
     def datd3_forward(self, states, want_q=False):
-        """DATD3_MLP.take_action without noise for states f32 [n, obs_dim]: actions [n, 3] (+ q1, q2 [n], picked_actor u8 [n])."""
+        """DATD3_MLP / DARC_MLP / DADDPG_MLP.take_action without noise (whichever set_policy_* installed) for states f32 [n, obs_dim]:
+        actions [n, 3] (+ q1, q2 [n], picked_actor u8 [n])."""
         st = states.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, self.obs_dim)
         n = st.shape[0]
         out = torch.empty((n, 3), dtype=torch.float32, device=self.device)

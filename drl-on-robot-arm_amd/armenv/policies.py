@@ -1,16 +1,17 @@
-"""Batched `take_action` of the reference's other two agents that consume these envs (north_star: algo/{DDPG,TD3,DATD3}):
+"""Batched `take_action` of the reference's other agents that consume these envs (north_star: algo/{DDPG,TD3,DATD3}) as stock torch
+modules -- the EXTERNAL-ACTIONS form (`policy.take_action(obs)` feeding `armenv_step`, e.g. through `PipelinedEnv.run_closed_loop`):
 
   DDPG_MLP.take_action   /root/reference/algo/DDPG/DDPG_mlp.py:76-91     a = actor(s)
   DATD3_MLP.take_action  /root/reference/algo/DATD3/DATD3_mlp.py:88-109  a = actor1(s) if critic1(s, a1) >= critic2(s, a2) else actor2(s)
 
-for [N, D] observation tensors on the env's device, returning the [N, 3] float32 action tensor `BatchedArmEnv.step`
-takes -- no host round trip.  How each agent reaches the engine:
+for [N, D] observation tensors on the env's device, returning the [N, 3] float32 action tensor `BatchedArmEnv.step` takes -- no host
+round trip.  Every one of them also has a FUSED form inside the rollout kernel (no torch, MFMA passes between two env steps):
 
-  * DDPG's actor IS the TD3 `PolicyNet` (algo/DDPG/net_mlp.py:29-40 == algo/TD3/net_mlp.py:29-40): its state_dict goes
-    straight into `BatchedArmEnv.set_policy("actor" | "actor_f16x3", actor_state_dict=...)`, i.e. the fused MFMA actor of
-    the rollout kernel; `DDPGPolicy` is the external-action form of the same thing.
-  * DATD3's two-actor / two-critic arg-max has NO fused form in the rollout kernel (four MLP forwards per step): it is an
-    EXTERNAL-ACTIONS consumer -- `DATD3Policy.take_action(obs)` (stock torch ops on the device) feeding `armenv_step`.
+  * DDPG's actor IS the TD3 `PolicyNet` (algo/DDPG/net_mlp.py:29-40 == algo/TD3/net_mlp.py:29-40): its state_dict goes straight into
+    `BatchedArmEnv.set_policy("actor" | "actor_f16x3", actor_state_dict=...)`;
+  * DATD3 / DARC (algo/DARC/DARC_mlp.py:92-113, the same selection): `BatchedArmEnv.set_policy_datd3` / `set_policy_darc`;
+  * DADDPG -- the reference's default agent (config.py:33; two actors, ONE critic: algo/DADDPG/DADDPG_mlp.py:77-97):
+    `BatchedArmEnv.set_policy_daddpg`.
 
 Parameter names follow the reference modules (fc1 / fc2 / fc3), so their state_dicts load unchanged."""
 import torch

@@ -89,6 +89,14 @@ int EngineBase::set_datd3(const ArmEnvMlp *const nets[4], int obs_dim, float bou
   for (int k = 0; k < 4; ++k) {
     const ArmEnvMlp &m = *nets[k];
     const bool critic = k >= 2;
+    // DADDPG (armenv_set_policy_daddpg): ONE critic values both proposals -- the fourth entry of the table IS the third (same packed
+    // weights, same LDS image), which datd3_forward_wg recognises and runs on the tables and the ring the third pass left behind
+    if (k == 3 && m.W1 == nets[2]->W1 && m.b1 == nets[2]->b1 && m.W2 == nets[2]->W2 && m.b2 == nets[2]->b2 && m.W3 == nets[2]->W3 &&
+        m.b3 == nets[2]->b3) {
+      A[3] = A[2];
+      H[3] = H[2];
+      continue;
+    }
     float *base = datd3_buf + k * per_net;
     float *W1P = base, *W2P = base + n1, *B2W3 = base + n1 + n2;
     _Float16 *W2H = reinterpret_cast<_Float16 *>(base + n1 + n2 + n3), *W2L = W2H + n2;
@@ -429,7 +437,8 @@ int armenv_step(ArmEnv *env, const float *action_dev, float *obs_dev, float *rew
     return fail(ARMENV_ESTATE, "armenv_step: ik_updates_dev needs a handle created with fence_counters >= 1 (the bookkeeping build of the kernels)");
   if (diag_dev && env->cfg.fence_counters != 2)
     return fail(ARMENV_ESTATE, "armenv_step: diag_dev needs a handle created with fence_counters = 2");
-  if (diag_dev && !action_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3 || env->eng->pol.kind == ARMENV_POLICY_DATD3))
+  if (diag_dev && !action_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3 || env->eng->pol.kind == ARMENV_POLICY_DATD3 ||
+      env->eng->pol.kind == ARMENV_POLICY_DADDPG))
     return fail(ARMENV_ESTATE, "armenv_step: diag_dev is not available with a fused actor");
   StepIO io{action_dev, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};
   if (!action_dev) {   // fused policy: a one-step rollout
@@ -476,6 +485,12 @@ int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len
                          void *stream) {
   ENV_ENTER(env);
   return env->eng->episode_stats(last_return_dev, last_len_dev, last_success_dev, static_cast<hipStream_t>(stream));
+}
+
+int armenv_episode_returns_f32(ArmEnv *env, float *last_return_dev, void *stream) {
+  ENV_ENTER(env);
+  if (!last_return_dev) return fail(ARMENV_EINVAL, "armenv_episode_returns_f32: last_return_dev is NULL");
+  return env->eng->episode_returns_f32(last_return_dev, static_cast<hipStream_t>(stream));
 }
 
 int armenv_counters(ArmEnv *env, uint64_t out[16], void *stream) {
@@ -540,6 +555,14 @@ int armenv_set_policy_datd3(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMl
   return ARMENV_OK;
 }
 
+int armenv_set_policy_daddpg(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMlp *actor2, const ArmEnvMlp *critic, int32_t hidden_dim,
+                             float action_bound, float noise_sigma, float noise_clip, void *stream) {
+  const int rc = armenv_set_policy_datd3(env, actor1, actor2, critic, critic, hidden_dim, action_bound, noise_sigma, noise_clip, stream);
+  if (rc != ARMENV_OK) return rc;
+  env->eng->pol.kind = ARMENV_POLICY_DADDPG;
+  return ARMENV_OK;
+}
+
 int armenv_datd3_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, float *q1_dev, float *q2_dev,
                          uint8_t *picked_dev, void *stream) {
   ENV_ENTER(env);
@@ -568,7 +591,8 @@ int armenv_rollout(ArmEnv *env, int32_t steps, const float *actions_dev, float *
     return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev needs a handle created with fence_counters >= 1 (the bookkeeping build of the kernels)");
   if (diag_dev && env->cfg.fence_counters != 2)
     return fail(ARMENV_ESTATE, "armenv_rollout: diag_dev needs a handle created with fence_counters = 2");
-  if ((ik_updates_dev || diag_dev) && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3 || env->eng->pol.kind == ARMENV_POLICY_DATD3))
+  if ((ik_updates_dev || diag_dev) && !actions_dev && (env->eng->pol.kind == ARMENV_POLICY_ACTOR || env->eng->pol.kind == ARMENV_POLICY_ACTOR_F16X3 || env->eng->pol.kind == ARMENV_POLICY_DATD3 ||
+      env->eng->pol.kind == ARMENV_POLICY_DADDPG))
     return fail(ARMENV_ESTATE, "armenv_rollout: ik_updates_dev / diag_dev are not available with a fused actor");
   StepIO io{nullptr, obs_dev, reward_dev, done_dev, success_dev, terminal_obs_dev, ik_updates_dev, diag_dev};
   return env->eng->rollout(steps, actions_dev, io, actions_out_dev, static_cast<hipStream_t>(stream));

@@ -652,7 +652,8 @@ AE_DEV void actor_forward_wg_f16x3(const ActorParams &A, const ActorParamsH &H, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109) for the 256 envs of a workgroup:
+// DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109; DARC_MLP's, algo/DARC/DARC_mlp.py:92-113, is the same; DADDPG_MLP's,
+// algo/DADDPG/DADDPG_mlp.py:77-97, is the same with critic2 = critic1) for the 256 envs of a workgroup:
 //     a1 = actor1(s), a2 = actor2(s), q1 = critic1(s, a1), q2 = critic2(s, a2), action = a1 if q1 >= q2 else a2
 // as four passes of the f16x3 workgroup actor above, one network after the other through the same LDS tables and the same W2 ring.
 // All four nets run as (OBS + 3)-input nets: the critics take cat(s, a) (net_mlp.py:55; reach 6 + 3, push / pick 9 + 3), the actors
@@ -672,17 +673,25 @@ AE_DEV void datd3_forward_wg(const ActorParams *nets, const ActorParamsH *nets_h
   static_for<0, OBS>([&](auto DI) { constexpr int d = DI; x[d] = s[d]; });
   x[OBS] = x[OBS + 1] = x[OBS + 2] = 0.f;
   const int live = nw * 64;
+  uint64_t staged = 0;      // the W2 fragments whose tables and ring are in LDS
 #pragma unroll 1
   for (int net = 0; net < 4; ++net) {
     const ActorParams A = nets[net];
     const ActorParamsH H = nets_h[net];
-    actor_ring_drain();
-    __syncthreads();
-    if (A.lds_image) actor_stage_image(A.lds_image, w1_lds, nw);
-    else { actor_stage_w1(A.W1P, w1_lds, A.B2W3, IN, live); actor_stage_w1h(A.W1P, w1_lds, IN, live); }
-    actor_ring_init(H, ring, nw);
-    actor_ring_drain();       // (the table image arrives by DMA like the ring: it must have landed before anyone reads a table)
-    __syncthreads();
+    // DADDPG (DADDPG_mlp.py:93-94: ONE critic values both proposals): the fourth entry of the table is the third.  Its tables are in LDS
+    // and the third pass's tail has refilled the ring for the pass that follows (as between two env steps of the single fused actor):
+    // nothing to drain, meet for or stage.
+    const uint64_t want = scalar_opaque((uint64_t)(uintptr_t)H.W2H);
+    if (want != staged) {
+      actor_ring_drain();
+      __syncthreads();
+      if (A.lds_image) actor_stage_image(A.lds_image, w1_lds, nw);
+      else { actor_stage_w1(A.W1P, w1_lds, A.B2W3, IN, live); actor_stage_w1h(A.W1P, w1_lds, IN, live); }
+      actor_ring_init(H, ring, nw);
+      actor_ring_drain();       // (the table image arrives by DMA like the ring: it must have landed before anyone reads a table)
+      __syncthreads();
+      staged = want;
+    }
     if (net >= 2) static_for<0, 3>([&](auto KI) { constexpr int k = KI; x[OBS + k] = net == 2 ? a1[k] : a2[k]; });      // cat(s, a_i), net_mlp.py:55
     float o[3];
     actor_forward_wg_f16x3<IN>(A, H, w1_lds, ring, nw, x, o);

@@ -97,6 +97,7 @@ struct EngineBase {
   virtual int set_state(const double *q, const float *goal, const int32_t *step, const uint32_t *episode,
                         const double *ep_return, const double *aux, const double *trig, hipStream_t s) = 0;
   virtual int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) = 0;
+  virtual int episode_returns_f32(float *last_return, hipStream_t s) = 0;
   virtual int counters(uint64_t out[16], hipStream_t s) = 0;
   virtual int summary(double *out_dev, hipStream_t s) = 0;
   virtual const char *name() const = 0;
@@ -340,7 +341,8 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
   }
   void launch_rollout_policy(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) {
     // lane-asynchronous form (ArmEnvConfig.rollout_ready_lanes > 0): external actions or the in-kernel random policy
-    const bool fused_actor = !actions && (pol.kind == ARMENV_POLICY_ACTOR || pol.kind == ARMENV_POLICY_ACTOR_F16X3 || pol.kind == ARMENV_POLICY_DATD3);
+    const bool fused_actor = !actions && (pol.kind == ARMENV_POLICY_ACTOR || pol.kind == ARMENV_POLICY_ACTOR_F16X3 || pol.kind == ARMENV_POLICY_DATD3 ||
+                                         pol.kind == ARMENV_POLICY_DADDPG);
     if (ready_lanes > 0 && steps > 1 && !fused_actor) {
       if (fence_on) {
         with_book_lane([&](auto *tag) {
@@ -365,7 +367,8 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
     if (actions) launch_rollout<ARMENV_POLICY_EXTERNAL>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR) launch_rollout<ARMENV_POLICY_ACTOR>(steps, actions, io0, actions_out, s);
     else if (pol.kind == ARMENV_POLICY_ACTOR_F16X3) launch_rollout<ARMENV_POLICY_ACTOR_F16X3>(steps, actions, io0, actions_out, s);
-    else if (pol.kind == ARMENV_POLICY_DATD3) launch_rollout<ARMENV_POLICY_DATD3>(steps, actions, io0, actions_out, s);
+    else if (pol.kind == ARMENV_POLICY_DATD3 || pol.kind == ARMENV_POLICY_DADDPG)   // DADDPG: the same kernel over a net table whose two critics are one
+      launch_rollout<ARMENV_POLICY_DATD3>(steps, actions, io0, actions_out, s);
     else launch_rollout<ARMENV_POLICY_RANDOM>(steps, actions, io0, actions_out, s);
   }
   int rollout(int32_t steps, const float *actions, const StepIO &io0, float *actions_out, hipStream_t s) override {
@@ -401,6 +404,11 @@ template <template <class, class, int> class LaneT, class C, typename T> struct 
   int episode_stats(double *last_return, int32_t *last_len, uint8_t *last_success, hipStream_t s) override {
     hipLaunchKernelGGL((episode_stats_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, last_return,
                        last_len, last_success);
+    HIP_TRY(hipGetLastError());
+    return ARMENV_OK;
+  }
+  int episode_returns_f32(float *last_return, hipStream_t s) override {
+    hipLaunchKernelGGL((episode_returns_f32_kernel<T>), dim3(grid_for(P.n, block)), dim3(block), 0, s, P, last_return);
     HIP_TRY(hipGetLastError());
     return ARMENV_OK;
   }

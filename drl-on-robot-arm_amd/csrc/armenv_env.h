@@ -1359,6 +1359,12 @@ __global__ __launch_bounds__(256) void set_state_kernel(EnvParams<T> P, const do
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void episode_returns_f32_kernel(EnvParams<T> P, float *last_return) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P.n) last_return[i] = (float)P.last_return[i];
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void episode_stats_kernel(EnvParams<T> P, double *last_return, int32_t *last_len,
                                                             uint8_t *last_success) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

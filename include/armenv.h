@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define ARMENV_NJ 7
-#define ARMENV_ABI_VERSION 5
+#define ARMENV_ABI_VERSION 6
 
 enum {
   ARMENV_OK = 0,
@@ -54,7 +54,8 @@ enum {
   ARMENV_POLICY_RANDOM = 1,
   ARMENV_POLICY_ACTOR = 2,        /* TD3 actor, exact f32 (layers 1 and 2 on the f32-input MFMA) */
   ARMENV_POLICY_ACTOR_F16X3 = 3,  /* same actor, layer 2 on the f16 MFMA with 3-pass hi/lo operand splitting (~1e-6) */
-  ARMENV_POLICY_DATD3 = 4         /* DATD3_MLP.take_action: two actors, two critics, the better-valued action (armenv_set_policy_datd3) */
+  ARMENV_POLICY_DATD3 = 4,        /* DATD3_MLP / DARC_MLP.take_action: two actors, two critics, the better-valued action (armenv_set_policy_datd3) */
+  ARMENV_POLICY_DADDPG = 5        /* DADDPG_MLP.take_action: two actors, ONE critic on both proposals (armenv_set_policy_daddpg) */
 };
 
 typedef struct ArmEnv ArmEnv;
@@ -315,6 +316,10 @@ int armenv_set_state(ArmEnv *env, const double *q_dev, const float *goal_dev, co
 int armenv_episode_stats(ArmEnv *env, double *last_return_dev, int32_t *last_len_dev, uint8_t *last_success_dev,
                          void *stream);
 
+/* The same returns as ONE f32 vector [N]: the send buffer of the logging all-gather (what main.py:130,150 plot from a single env; SURVEY.md
+ * section 8e: ncclAllGather(episode_return_local[N/R] f32)) written by one kernel on `stream`, no intermediate f64 vector. */
+int armenv_episode_returns_f32(ArmEnv *env, float *last_return_dev, void *stream);
+
 /* Totals since creation, copied to host (synchronises `stream`), out[16]: out[0] episodes finished, out[1] successes,
  * out[2] env-steps executed, out[3] non-finite joint states seen, out[4] IK (DLS) updates applied, out[5] env steps whose IK
  * result left the URDF joint limits, out[6] env steps that ended with the flange below fence_z, out[7] env steps whose IK
@@ -362,7 +367,17 @@ int armenv_set_policy_datd3(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMl
                             const ArmEnvMlp *critic2, int32_t hidden_dim, float action_bound, float noise_sigma, float noise_clip,
                             void *stream);
 
-/* The installed DATD3 policy alone (take_action without noise) for n states f32 [n][obs_dim]: actions f32 [n][3] and, nullable, the two
+/* Installs DADDPG_MLP.take_action (/root/reference/algo/DADDPG/DADDPG_mlp.py:77-97; opt.algo's default, /root/reference/config.py:33)
+ * as the fused policy of armenv_rollout / armenv_step(action_dev = NULL):
+ *     a1 = actor1(s), a2 = actor2(s), q1 = critic(cat(s, a1)), q2 = critic(cat(s, a2)), a = a1 if q1 >= q2 else a2
+ * -- the selection rule of armenv_set_policy_datd3 (`>=`: a tie takes actor 1) with ONE critic valuing both proposals: three networks
+ * are packed and staged, and the critic's second pass runs on the tables and the W2 ring its first pass left in LDS.
+ * DARC_MLP.take_action (/root/reference/algo/DARC/DARC_mlp.py:92-113) is DATD3's, two critics: install it with
+ * armenv_set_policy_datd3.  armenv_datd3_forward serves all three. */
+int armenv_set_policy_daddpg(ArmEnv *env, const ArmEnvMlp *actor1, const ArmEnvMlp *actor2, const ArmEnvMlp *critic,
+                             int32_t hidden_dim, float action_bound, float noise_sigma, float noise_clip, void *stream);
+
+/* The installed DATD3 / DARC / DADDPG policy alone (take_action without noise) for n states f32 [n][obs_dim]: actions f32 [n][3] and, nullable, the two
  * Q values f32 [n] and the index of the actor whose action was taken u8 [n] (0: actor1, 1: actor2). */
 int armenv_datd3_forward(ArmEnv *env, int64_t n, const float *states_dev, float *actions_dev, float *q1_dev, float *q2_dev,
                          uint8_t *picked_dev, void *stream);

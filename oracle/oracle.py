@@ -379,7 +379,8 @@ def qvalue_forward(sd, states, actions):
 
 def datd3_take_action(nets, states, action_bound):
     """DATD3_MLP.take_action (/root/reference/algo/DATD3/DATD3_mlp.py:88-109), batched: nets = (actor1, actor2, critic1, critic2)
-    state dicts.  Returns (action [n,3], q1 [n], q2 [n], picked [n] u8: 0 actor1, 1 actor2)."""
+    state dicts.  DARC_MLP.take_action (algo/DARC/DARC_mlp.py:92-113) is the same statement; DADDPG_MLP.take_action
+    (algo/DADDPG/DADDPG_mlp.py:77-97) is the same with its ONE critic in both critic places.  Returns (action [n,3], q1 [n], q2 [n], picked [n] u8: 0 actor1, 1 actor2)."""
     a1 = actor_forward(nets[0], states, action_bound)
     a2 = actor_forward(nets[1], states, action_bound)
     q1 = qvalue_forward(nets[2], states, a1)

@@ -514,7 +514,83 @@ def g14_datd3_take_action_nine_inputs():
     np.savez_compressed(os.path.join(OUT, "datd3_take_action9_seed0.npz"), **out)
 
 
+def g15_daddpg_darc_take_action():
+    """G15: take_action of the reference's DEFAULT agent -- opt.algo = 'DADDPG_MLP' (config.py:33): two actors and ONE critic evaluated
+    on both proposals, `action1 if q1 >= q2 else action2` (algo/DADDPG/DADDPG_mlp.py:77-97) -- and of DARC_MLP (two actors, two critics:
+    algo/DARC/DARC_mlp.py:92-113, the same selection as DATD3's), produced like G11 / G14 by importing the agents and calling their own
+    take_action one state at a time:
+      daddpg_take_action_seed0.npz    6-float observations (reach), action_bound 0.7
+      daddpg_take_action9_seed0.npz   9-float observations (push / pick), action_bound 0.4 (main.py:457)
+      darc_take_action_seed0.npz      6-float observations, action_bound 0.7"""
+    sys.path.insert(0, REF)
+    import torch
+    from algo.DADDPG.DADDPG_mlp import DADDPG_MLP
+    from algo.DARC.DARC_mlp import DARC_MLP
+    cpu = torch.device("cpu")
+    boxes = {6: (np.array([0.2, -0.3, 0.0, 0.2, -0.3, 0.0]), np.array([0.7, 0.3, 0.55, 0.7, 0.3, 0.55])),
+             9: (np.array([0.2, -0.3, 0.0, 0.2, -0.3, -0.006, 0.2, -0.3, 0.0]), np.array([0.7, 0.3, 0.1, 0.7, 0.3, 0.01, 0.7, 0.3, 0.011]))}
+    for obs, bound, fname, seed in ((6, 0.7, "daddpg_take_action_seed0.npz", 15), (9, 0.4, "daddpg_take_action9_seed0.npz", 16)):
+        rng = np.random.default_rng(seed)
+        lo, hi = boxes[obs]
+        states = (lo + (hi - lo) * rng.random((256, obs))).astype(np.float32)
+        torch.manual_seed(0)
+        agent = DADDPG_MLP(obs, 3, bound, device=cpu)
+        with torch.no_grad():
+            # Freshly initialised actors differ by a near-constant offset over this small observation box, and the ONE critic then prefers
+            # the same proposal on every state.  So that `action1 if q1 >= q2 else action2` takes both branches, some of them by a narrow
+            # margin: a wider critic output layer, an actor 1 whose proposal varies with the state (wider first and last layers), and
+            # actor 2 = actor 1 with its hidden layer perturbed (the situation late in training: two actors that nearly agree).
+            torch.nn.init.normal_(agent.critic.fc3.weight, std=0.5)
+            torch.nn.init.normal_(agent.actor1.fc1.weight, std=2.0)
+            torch.nn.init.normal_(agent.actor1.fc3.weight, std=0.2)
+            agent.actor2.load_state_dict(agent.actor1.state_dict())
+            agent.actor2.fc2.weight += 0.05 * torch.randn_like(agent.actor2.fc2.weight)
+        acts, q1s, q2s, pick = [], [], [], []
+        for s_ in states:
+            st = torch.tensor([s_], dtype=torch.float)
+            with torch.no_grad():
+                a1, a2 = agent.actor1(st), agent.actor2(st)
+                q1, q2 = float(agent.critic(st, a1)), float(agent.critic(st, a2))
+            a = agent.take_action(s_)
+            acts.append(a); q1s.append(q1); q2s.append(q2)
+            pick.append(0 if np.array_equal(a, a1.numpy().flatten()) else 1)
+        assert 10 < sum(pick) < 246, sum(pick)        # both branches taken
+        out = {"states": states, "actions": np.stack(acts).astype(np.float32), "q1": np.float32(q1s), "q2": np.float32(q2s),
+               "picked_actor": np.uint8(pick), "action_bound": np.float32(bound)}
+        for name in ("actor1", "actor2", "critic"):
+            out.update({name + "_" + k.replace(".", "_"): v.detach().numpy().copy() for k, v in getattr(agent, name).state_dict().items()})
+        np.savez_compressed(os.path.join(OUT, fname), **out)
+    rng = np.random.default_rng(17)
+    lo, hi = boxes[6]
+    states = (lo + (hi - lo) * rng.random((256, 6))).astype(np.float32)
+    torch.manual_seed(0)
+    agent = DARC_MLP(6, 3, 0.7, device=cpu)
+    with torch.no_grad():       # as in G11
+        for c in (agent.critic1, agent.critic2):
+            torch.nn.init.normal_(c.fc3.weight, std=0.5)
+            c.fc3.bias.zero_()
+        sb = torch.from_numpy(states)
+        gap = agent.critic1(sb, agent.actor1(sb)) - agent.critic2(sb, agent.actor2(sb))
+        agent.critic2.fc3.bias += gap.median()
+    acts, q1s, q2s, pick = [], [], [], []
+    for s_ in states:
+        st = torch.tensor([s_], dtype=torch.float)
+        with torch.no_grad():
+            a1, a2 = agent.actor1(st), agent.actor2(st)
+            q1, q2 = float(agent.critic1(st, a1)), float(agent.critic2(st, a2))
+        a = agent.take_action(s_)
+        acts.append(a); q1s.append(q1); q2s.append(q2)
+        pick.append(0 if np.array_equal(a, a1.numpy().flatten()) else 1)
+    assert 20 < sum(pick) < 236, sum(pick)
+    out = {"states": states, "actions": np.stack(acts).astype(np.float32), "q1": np.float32(q1s), "q2": np.float32(q2s),
+           "picked_actor": np.uint8(pick), "action_bound": np.float32(0.7)}
+    for name in ("actor1", "actor2", "critic1", "critic2"):
+        out.update({name + "_" + k.replace(".", "_"): v.detach().numpy().copy() for k, v in getattr(agent, name).state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, "darc_take_action_seed0.npz"), **out)
+
+
 if __name__ == "__main__":
+    g15_daddpg_darc_take_action()
     g14_datd3_take_action_nine_inputs()
     g13_visdata_push_td3()
     g12_visdata_reach_td3()

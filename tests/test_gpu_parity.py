@@ -1561,6 +1561,120 @@ def test_fused_datd3_rollout_vs_oracle(envs, O, kuka):
     a_env.close(); b_env.close()
 
 
+def _nets_of(g, names):
+    keys = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+    return [{k: g["%s_%s" % (n, k.replace(".", "_"))] for k in keys} for n in names]
+
+
+@pytest.mark.parametrize("agent,task", [("daddpg", "reach"), ("daddpg", "push"), ("darc", "reach")])
+def test_fused_daddpg_darc_take_action_match_reference_golden(envs, O, agent, task):
+    """The reference's DEFAULT agent, opt.algo = 'DADDPG_MLP' (/root/reference/config.py:33): take_action with two actors and ONE critic
+    valuing both proposals (/root/reference/algo/DADDPG/DADDPG_mlp.py:77-97) -- armenv_set_policy_daddpg: three packed nets, the
+    critic's second pass on the LDS tables and W2 ring its first pass left -- and DARC_MLP.take_action
+    (/root/reference/algo/DARC/DARC_mlp.py:92-113: DATD3's selection, through armenv_set_policy_datd3), against G15 (produced by calling
+    the reference's own take_action one state at a time): Q values within 1e-5, the same actor picked wherever |q1 - q2| > 1e-4 (both
+    branches occur; `>=`: a tie takes actor 1 in all three agents), actions within 1e-5; and against the oracle on 4 096 + 192 random
+    states (ragged last workgroup).  The DADDPG install equals a DATD3 install given the same critic twice, bit for bit."""
+    g = golden_npz({("daddpg", "reach"): "daddpg_take_action_seed0.npz", ("daddpg", "push"): "daddpg_take_action9_seed0.npz",
+                    ("darc", "reach"): "darc_take_action_seed0.npz"}[(agent, task)])
+    nets = _nets_of(g, ("actor1", "actor2", "critic", "critic") if agent == "daddpg" else ("actor1", "actor2", "critic1", "critic2"))
+    tn = [{k: torch.from_numpy(v) for k, v in sd.items()} for sd in nets]
+    bound = float(g["action_bound"])
+    Env = envs.BatchedReachEnv if task == "reach" else envs.BatchedPushEnv
+    e = Env(4096 + 192, device=DEV, seed=3)
+    if agent == "daddpg":
+        e.set_policy_daddpg(tn[0], tn[1], tn[2], action_bound=bound)
+    else:
+        e.set_policy_darc(*tn, action_bound=bound)
+    a, q1, q2, pk = (_np(x) for x in e.datd3_forward(torch.from_numpy(g["states"]).to(DEV), want_q=True))
+    assert np.abs(q1 - g["q1"]).max() < 1e-5 and np.abs(q2 - g["q2"]).max() < 1e-5
+    clear = np.abs(g["q1"] - g["q2"]) > 1e-4
+    assert clear.sum() >= 240 and np.array_equal(pk[clear], g["picked_actor"][clear].astype(np.uint8)) and 10 < pk[clear].sum() < 246
+    assert np.abs(a - g["actions"])[clear].max() < 1e-5
+    tie = g["q1"] == g["q2"]                      # `q1 >= q2` -> actor 1
+    assert not tie.any() or (g["picked_actor"][tie] == 0).all()
+    rng = np.random.default_rng(5)
+    D = g["states"].shape[1]
+    lo, hi = g["states"].min(0), g["states"].max(0)
+    st = (lo + (hi - lo) * rng.random((4096 + 192, D), dtype=np.float32)).astype(np.float32)
+    got = [_np(x) for x in e.datd3_forward(torch.from_numpy(st).to(DEV), want_q=True)]
+    a, q1, q2, pk = got
+    ar, q1r, q2r, pr = O.datd3_take_action(nets, st, bound)
+    assert np.abs(q1 - q1r).max() < 1e-5 and np.abs(q2 - q2r).max() < 1e-5
+    clear = np.abs(q1r - q2r) > 1e-4
+    assert clear.mean() > 0.9 and np.array_equal(pk[clear], pr[clear]) and np.abs(a - ar)[clear].max() < 1e-5
+    if agent == "daddpg":
+        assert e._lib.armenv_kernel_name(e._h) and e._policy == "daddpg"
+        e2 = Env(4096 + 192, device=DEV, seed=3)
+        e2.set_policy_datd3(tn[0], tn[1], tn[2], {k: v.clone() for k, v in tn[2].items()}, action_bound=bound)   # four staged nets
+        for x, y in zip(got, e2.datd3_forward(torch.from_numpy(st).to(DEV), want_q=True)):
+            assert np.array_equal(x, _np(y))
+        e2.close()
+    e.close()
+
+
+def test_fused_daddpg_rollout_vs_oracle(envs, O, kuka):
+    """DADDPG_MLP.take_action folded into the rollout kernel (ARMENV_POLICY_DADDPG) at 65 536 reach envs, 2 x armenv_rollout(50) with
+    run()'s exploration noise (main.py:116-117), on a strided sample of 2 048 envs: actions within 2e-5 of the oracle's take_action + noise
+    on the observations the fused policy saw (wherever the critic does not value the two proposals within 1e-4 of each other), observations
+    within 1e-5 and identical flags with the oracle teacher-forced on the engine's actions; rollout == step(None) launches bit for bit on a
+    ragged 256 + 64-env handle; a push handle (G15's nine-input nets) stays finite."""
+    g = golden_npz("daddpg_take_action_seed0.npz")
+    nets = _nets_of(g, ("actor1", "actor2", "critic", "critic"))
+    tn = [{k: torch.from_numpy(v) for k, v in sd.items()} for sd in nets]
+    n, T, stride = 65536, 50, 32
+    e = envs.BatchedReachEnv(n, device=DEV, seed=4)
+    e.set_policy_daddpg(tn[0], tn[1], tn[2], action_bound=0.7, noise_sigma=0.7 * 0.98, noise_clip=0.7)
+    obs0 = _np(e.reset()).copy()
+    ids = np.arange(0, n, stride)
+    cfg = O.default_config()
+    st = O.ReachState(ids.size)
+    st.q[:] = np.array(O.INIT_Q); st.goal[:] = obs0[ids, 3:]; st.episode[:] = 1
+    obs_prev = obs0[ids].copy()
+    worst_a = worst_o = 0.0
+    flags = unclear = 0
+    picks = 0
+    for launch in range(2):
+        out = e.rollout(T, None, want_actions=True, want_terminal_obs=True)
+        acts, obs, term, done, succ = (_np(out[k]) for k in ("actions", "obs", "terminal_obs", "done", "success"))
+        for t in range(T):
+            mu, q1, q2, pk = O.datd3_take_action(nets, obs_prev, 0.7)
+            picks += int(pk.sum())
+            nz = O.policy_noise_ids(4, ids, st.episode, st.step)
+            want = np.clip(mu + np.float32(0.7 * 0.98) * nz, -np.float32(0.7), np.float32(0.7))
+            a = acts[t][ids]
+            clear = np.abs(q1 - q2) > 1e-4
+            unclear += int((~clear).sum())
+            worst_a = max(worst_a, float(np.abs(a - want)[clear].max()))
+            o_r, r_r, d_r, s_r, iters = O.reach_step(kuka, cfg, st, a)
+            worst_o = max(worst_o, float(np.abs(term[t][ids] - o_r).max()))
+            flags += int((done[t][ids] != d_r.astype(bool)).sum() + (succ[t][ids] != s_r.astype(bool)).sum())
+            fin = d_r.astype(bool)
+            if fin.any():
+                st.q[fin] = np.array(O.INIT_Q); st.step[fin] = 0; st.episode[fin] += 1; st.ep_return[fin] = 0
+                st.goal[fin] = obs[t][ids][fin, 3:]
+            obs_prev = obs[t][ids].copy()
+    e.close()
+    assert worst_a < 2e-5 and worst_o < 1e-5 and flags == 0, (worst_a, worst_o, flags)
+    assert unclear < 0.02 * 2 * T * ids.size and 0.02 < picks / (2 * T * ids.size) < 0.98        # both actors act
+    a_env, b_env = (envs.BatchedReachEnv(256 + 64, device=DEV, seed=9, max_steps=12) for _ in range(2))
+    for x in (a_env, b_env):
+        x.set_policy_daddpg(tn[0], tn[1], tn[2], action_bound=0.7); x.reset()
+    out = a_env.rollout(30, None)
+    for t in range(30):
+        o, r, d, s = b_env.step(None)
+        _same_rollout_step(out, t, o, r, d)
+    a_env.close(); b_env.close()
+    g9 = golden_npz("daddpg_take_action9_seed0.npz")
+    t9 = [{k: torch.from_numpy(v) for k, v in sd.items()} for sd in _nets_of(g9, ("actor1", "actor2", "critic"))]
+    p = envs.BatchedPushEnv(2048 + 64, device=DEV, seed=2)
+    p.set_policy_daddpg(*t9, action_bound=0.4, noise_sigma=0.4 * 0.98, noise_clip=1e9)
+    p.reset()
+    o = p.rollout(20, None)
+    assert bool(torch.isfinite(o["obs"]).all()) and p.counters()["nonfinite"] == 0
+    p.close()
+
+
 def test_fused_actor_nine_inputs_push(envs, O):
     """obs_dim 9 (push / pick): both fused actor variants against the oracle's actor on the observations they saw."""
     rng = np.random.default_rng(82)

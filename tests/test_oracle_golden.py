@@ -632,6 +632,25 @@ def test_oracle_datd3_take_action_matches_reference_golden(O, fixture):
     assert np.array_equal(pick[clear], g["picked_actor"][clear].astype(np.uint8)) and np.abs(a - g["actions"])[clear].max() < 1e-6
 
 
+@pytest.mark.parametrize("fixture,names", [("daddpg_take_action_seed0.npz", ("actor1", "actor2", "critic", "critic")),
+                                           ("daddpg_take_action9_seed0.npz", ("actor1", "actor2", "critic", "critic")),
+                                           ("darc_take_action_seed0.npz", ("actor1", "actor2", "critic1", "critic2"))])
+def test_oracle_daddpg_darc_take_action_match_reference_golden(O, fixture, names):
+    """G15: the oracle's batched take_action given DADDPG's net table (two actors and the ONE critic in both critic places,
+    algo/DADDPG/DADDPG_mlp.py:77-97 -- the reference's default agent, config.py:33) and DARC's (algo/DARC/DARC_mlp.py:92-113, the same
+    selection as DATD3's) against vectors produced by calling the reference's own take_action one state at a time: Q values to 1e-5, the
+    same actor picked wherever the two Q values are not within rounding of each other (both branches occur), actions 5e-6 (G15's
+    DADDPG actors have a wide first layer -- activations of order 10, where f32 summation order shows at 1e-6; the bar is 1e-5)."""
+    g = golden_npz(fixture)
+    nets = [{k: g["%s_%s" % (n, k.replace(".", "_"))] for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")}
+            for n in names]
+    a, q1, q2, pick = O.datd3_take_action(nets, g["states"], float(g["action_bound"]))
+    assert np.abs(q1 - g["q1"]).max() < 1e-5 and np.abs(q2 - g["q2"]).max() < 1e-5
+    clear = np.abs(g["q1"] - g["q2"]) > 1e-4
+    assert clear.sum() >= 240 and 10 < g["picked_actor"][clear].sum() < 246
+    assert np.array_equal(pick[clear], g["picked_actor"][clear].astype(np.uint8)) and np.abs(a - g["actions"])[clear].max() < 5e-6
+
+
 def test_policy_noise_angle_kernel_against_libm(O):
     """The sin / cos pair of the in-kernel policy's Box-Muller (sincos_2pi, engine and oracle the same statements): within 1.2e-7 of
     sin / cos of 2 pi u in f64 over a million u in [0, 1), quadrant boundaries and the ends included; and the stream's normals have
