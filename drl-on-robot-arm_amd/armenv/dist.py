@@ -106,7 +106,7 @@ class ShmBarrier:
 
 
 class _NcclUniqueId(ctypes.Structure):
-    _fields_ = [("internal", ctypes.c_char * 128)]        # rccl.h: NCCL_UNIQUE_ID_BYTES
+    _fields_ = [("internal", ctypes.c_ubyte * 128)]       # rccl.h: NCCL_UNIQUE_ID_BYTES (c_ubyte: a c_char array reads back cut at its first NUL)
 
 
 class RcclComm:
@@ -143,7 +143,7 @@ class RcclComm:
         uid = _NcclUniqueId()
         if ok and rank == 0 and self.lib.ncclGetUniqueId(ctypes.byref(uid)) != 0:
             ok, why = 0, "ncclGetUniqueId failed"
-        box = [bytes(uid.internal) if rank == 0 else None]
+        box = [ctypes.string_at(ctypes.byref(uid), 128) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         if ok:
             ctypes.memmove(ctypes.byref(uid), box[0], 128)

@@ -551,13 +551,14 @@ def test_bench_one_rank_over_rccl_keeps_the_single_gpu_value():
     bracket lost 41 % here.  Both runs are medians-free single regions, so the bound is on the better of two tries."""
     from test_gpu_parity import _run_bench
     argv = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--secondary-legs", "0", "--fence-steps", "0",
-            "--large-batch", "0", "--ab-regions", "0"]
+            "--large-batch", "0", "--ab-regions", "0", "--repeat-regions", "2"]
     best = 0.0
     for _ in range(2):
         plain = _run_bench(argv)
         rccl = _run_bench_env(argv)
         assert rccl["config"]["rccl_backend"] == "nccl" and rccl["config"]["gathers_in_timed_region"] == 1
         assert rccl["config"]["collective_verified"] is True
+        assert rccl["config"]["collective_transport"] == "rccl-direct", rccl["config"]["collective_direct_error"]
         assert rccl["value_steps"] >= rccl["value"] >= rccl["value_bracketed"]
         best = max(best, rccl["value"] / plain["value"])
         if best >= 0.95:
