@@ -642,7 +642,7 @@ def main():
     ap.add_argument("--task", default="reach", choices=["reach", "push", "pick"],
                     help="reach = BASELINE configs[1] (headline); push = configs[3] (use --envs-per-gpu 32768); "
                          "pick = the next-row env (SURVEY.md section 8f.4)")
-    ap.add_argument("--policy", default="external", choices=["external", "random", "actor", "actor_f16x3"],
+    ap.add_argument("--policy", default="external", choices=["external", "random", "actor", "actor_f16x3", "datd3", "daddpg"],
                     help="external = pre-generated actions in HBM (configs[1], headline); random / actor = fused in-kernel "
                          "policy (actor = configs[2]: TD3 actor forward folded into the rollout kernel)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
@@ -694,9 +694,19 @@ def main():
             sd = golden_actor()
             if args.task != "reach":
                 raise SystemExit("--policy actor: the golden actor has 6 inputs (reach)")
-        env.set_policy(args.policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if args.task == "reach" else 1e9,
-                       actor_state_dict=sd)
+        if args.policy in ("datd3", "daddpg"):       # the fused two-actor policies (golden nets G11 / G15: 6-float observations)
+            if args.task != "reach":
+                raise SystemExit("--policy %s: the golden nets have 6 inputs (reach)" % args.policy)
+            if args.policy == "datd3":
+                env.set_policy_datd3(*golden_datd3(), action_bound=bound, noise_sigma=sig, noise_clip=bound)
+            else:
+                env.set_policy_daddpg(*golden_daddpg(), action_bound=bound, noise_sigma=sig, noise_clip=bound)
+        else:
+            env.set_policy(args.policy, action_bound=bound, noise_sigma=sig, noise_clip=bound if args.task == "reach" else 1e9,
+                           actor_state_dict=sd)
     gather = ReturnGatherer(n, dev, world, collective=multi)
+    if multi:
+        gather.warm_up()       # the communicator's first collectives set up channels: not inside a rollout loop, not inside the clock
     env.reset()
     R = max(1, min(args.rollout_steps, args.steps))
     R = min(R, S)
@@ -720,7 +730,7 @@ def main():
         """The all-gather that ends a region: armenv_episode_stats too goes to the side stream (behind the region's steps), so the
         launch stream carries the K steps and nothing else and its synchronise closes the clock on them; the collective is waited
         for -- and checked -- after the clock (logging only, never on the step critical path)."""
-        gather.launch_into(lambda stage: env.episode_returns_f32(out=stage))
+        gather.launch_into(lambda stage, stream=None: env.episode_returns_f32(out=stage, stream=stream), takes_stream=True)
 
     def plan(k):
         """The launches of exactly k env steps of every env of this rank, prepared up front (buffers, pointers, the
@@ -981,7 +991,10 @@ def main():
         pol_txt = {"external": "random policy %s pre-generated in HBM as an i.i.d. [steps, N, 3] pool, step() throughput only",
                    "random": "random policy %s generated in-kernel (Philox)",
                    "actor": "TD3 actor forward (exact f32 MFMA) + exploration noise %s fused into the step kernel",
-                   "actor_f16x3": "TD3 actor forward (f16 MFMA, 3-pass hi/lo split) + exploration noise %s fused into the step kernel"}
+                   "actor_f16x3": "TD3 actor forward (f16 MFMA, 3-pass hi/lo split) + exploration noise %s fused into the step kernel",
+                   "datd3": "DATD3_MLP.take_action (two actors, two critics, f16x3 MFMA passes) + exploration noise %s fused into the step kernel",
+                   "daddpg": "DADDPG_MLP.take_action (two actors, one critic on both proposals, f16x3 MFMA passes) + exploration noise %s fused "
+                             "into the step kernel"}
         noise = "clip(N(0,0.686),+-0.7)" if args.task == "reach" else "N(0,0.392)"
         workload = {"reach": "rl_reach_env %d parallel envs per GPU, %s, KUKA iiwa chain, auto-reset on",
                     "push": "rl_push_env %d parallel envs per GPU (arm FK/IK + cube contact/overlap test), %s, auto-reset on",

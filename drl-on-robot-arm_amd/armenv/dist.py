@@ -212,6 +212,8 @@ class ReturnGatherer:
         self.launches = 0
         self._last = None
         self.read_done = None        # (GPU) event on the side stream: the last launch's source has been copied into its slot
+        self._read_evs = [torch.cuda.Event(), torch.cuda.Event()] if self.side is not None else None    # re-used: one per slot
+        self._fork_ev = torch.cuda.Event() if self.side is not None else None
         self.rccl, self.direct_error = None, None
         if direct is None:
             direct = os.environ.get("ARMENV_DIST_DIRECT_RCCL", "1") != "0"
@@ -236,16 +238,28 @@ class ReturnGatherer:
         return t
 
     _fills = False      # launch_into: the producer writes the f32 vector straight into the slot's send buffer
+    _raw_stream_ok = False
 
-    def launch_into(self, fill):
+    def launch_into(self, fill, takes_stream=False):
         """As launch(callable), for a producer that WRITES the vector: `fill(stage)` is called with the slot's f32 send buffer
         [n_local] (on GPUs with the side stream current) -- BatchedArmEnv.episode_returns_f32(out=stage): one kernel, no
-        intermediate tensor, no conversion copy."""
-        self._fills = True
+        intermediate tensor, no conversion copy.  takes_stream: the producer is `fill(stage, stream)` and enqueues on the raw HIP
+        stream it is handed (the direct-RCCL path then enters no torch stream context at all)."""
+        self._fills, self._raw_stream_ok = True, bool(takes_stream)
         try:
-            self.launch(fill)
+            self.launch((lambda st, s=None: fill(st, s)) if takes_stream else fill)
         finally:
-            self._fills = False
+            self._fills = self._raw_stream_ok = False
+
+    def warm_up(self, rounds=3):
+        """A few gathers of zeros, waited for: the first collectives on a fresh communicator set up channels and load kernels
+        (the first ncclAllGather of a job cost the issuing host 214 us against 68 for the second, gpurun_out/r06/p3_rccl_world1_*.json);
+        a rollout loop that logs from its first step on does not want that inside it."""
+        for _ in range(int(rounds)):
+            self.launch_into(lambda st: st.zero_())
+            self.result()
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).synchronize()
 
     def launch(self, local_returns):
         """Enqueue the gather of `local_returns` ([n_local], any float dtype).  Non-blocking on GPUs: the side stream waits for
@@ -274,15 +288,20 @@ class ReturnGatherer:
         if self.rccl is not None:
             # RCCL's own call on the side stream: everything of this slot's earlier use is in that stream's order already
             cur = torch.cuda.current_stream(self.device)
-            self.side.wait_stream(cur)         # the producer of the vector; consumers of the result() of two launches ago
-            with torch.cuda.stream(self.side):
-                src = local_returns if producer is None else self._produce(producer, slot)
-                if src is not slot["stage"]:
-                    slot["stage"].copy_(src)
-                if producer is None:
-                    local_returns.record_stream(self.side)
-                self.read_done = self.side.record_event()
-                self.rccl.all_gather_f32(slot["stage"].data_ptr(), slot["out"].data_ptr(), self.n_local, self.side.cuda_stream)
+            self._fork_ev.record(cur)          # the producer of the vector; consumers of the result() of two launches ago
+            self.side.wait_event(self._fork_ev)
+            if producer is not None and self._fills and self._raw_stream_ok:
+                producer(slot["stage"], self.side.cuda_stream)     # one C call on the side stream, no stream context to enter
+            else:
+                with torch.cuda.stream(self.side):
+                    src = local_returns if producer is None else self._produce(producer, slot)
+                    if src is not slot["stage"]:
+                        slot["stage"].copy_(src)
+                    if producer is None:
+                        local_returns.record_stream(self.side)
+            self.read_done = self._read_evs[(self.launches - 1) & 1]
+            self.read_done.record(self.side)
+            self.rccl.all_gather_f32(slot["stage"].data_ptr(), slot["out"].data_ptr(), self.n_local, self.side.cuda_stream)
             return
         if self.side is not None:
             cur = torch.cuda.current_stream(self.device)

@@ -257,13 +257,18 @@ class BatchedArmEnv:
         torch.cuda.current_stream(self.device).synchronize()
         self._policy = "daddpg"
 
-    def episode_returns_f32(self, out=None):
+    def episode_returns_f32(self, out=None, stream=None):
         """Return of each env's most recently finished episode as ONE f32 vector [N] (armenv_episode_returns_f32: the send buffer
-        of the logging all-gather, written by one kernel on the launch stream; `out` to write into a caller's buffer)."""
+        of the logging all-gather, written by one kernel on the launch stream; `out` to write into a caller's buffer).
+        stream: a raw HIP stream (int) to enqueue on instead -- the caller then owns the ordering against the env's launches
+        (armenv.dist.ReturnGatherer.launch_into(..., takes_stream=True) does)."""
         if out is None:
             out = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
         elif out.dtype != torch.float32 or tuple(out.shape) != (self.num_envs,) or out.device != self.device or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous float32 tensor [{self.num_envs}] on {self.device}")
+        if stream is not None:
+            L.check(self._lib.armenv_episode_returns_f32(self._h, _ptr(out), C.c_void_p(stream)))
+            return out
         with self._ordered():
             L.check(self._lib.armenv_episode_returns_f32(self._h, _ptr(out), self._stream()))
         return out

@@ -26,7 +26,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def short(name):
@@ -91,16 +91,29 @@ def by_steps(trace_csv, bench_json, dst):
     R = int(round(spl))
     W = int(b["warmup"])
     cands = sorted({R, 100, (W % R) or R})          # the warm-up's last (short) launch, the timed launches, the 100-step legs
+    # The headline kernel's time per step comes from the bench line; every other rollout variant of the run (the scratch handle's
+    # in-kernel policy, the fused-actor / push / DATD3 legs, the fence handles) is launched 100 steps at a time by bench.py, so its
+    # own median launch is a 100-step one (round 6: these rows carried "?" before).
+    pol = {"external": 0, "random": 1, "actor": 2, "actor_f16x3": 3, "datd3": 4, "daddpg": 4}.get(b["config"].get("policy", "external"), 0)
+    lane = {"reach": "ReachLane", "push": "false, 0>", "pick": "true, 0>"}[("push" if "rl_push" in b["metric"] else ("pick" if "rl_pick" in b["metric"] else "reach"))]
+    prec = "double" if b.get("dtype", "f64") == "f64" else "float"
+
+    def is_headline(name):
+        return lane in name and (", %d, 1>" % pol) in name and ("%s, 0>" % prec in name or lane != "ReachLane") and "async" not in name
+    durs = collections.defaultdict(list)
+    for r in rows:
+        if "env_rollout" in r["Kernel_Name"]:
+            durs[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    per_step = {n_: (us_step if is_headline(n_) else statistics.median(v_) / 100.0) for n_, v_ in durs.items()}
     groups = collections.defaultdict(list)
     for r in rows:
         name = r["Kernel_Name"]
-        if not any(s_ in name for s_ in ("env_", "actor_", "her_", "index_episodes")):
+        if not any(s_ in name for s_ in ("env_", "actor_", "her_", "index_episodes", "datd3")):
             continue
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         T = ""
         if "env_rollout" in name:
-            # per-step time differs between kernel variants (fused actors, push): scale by the variant's own median launch
-            T = min(cands, key=lambda c: abs(math.log(max(d, 1e-3) / (c * us_step)))) if ("ReachLane" in name and ", 0, 1>" in name and "double, 0>" in name) else "?"
+            T = min(cands, key=lambda c: abs(math.log(max(d, 1e-3) / (c * per_step[name]))))
         groups[(name, T)].append(d)
     with open(dst, "w") as fh:
         fh.write("Kernel_Name,steps_per_launch,calls,avg_us,min_us,max_us,median_us\n")
@@ -151,7 +164,9 @@ def main():
     # the launch shapes of bench.py's config3 / config4 legs (one bench run per shape: its headline kernel is "rollout")
     for suf, key in (("_actor", "reach_rollout<f64,kuka>|policy=actor|T=100|N=65536"),
                      ("_actor_f16x3", "reach_rollout<f64,kuka>|policy=actor_f16x3|T=100|N=65536"),
-                     ("_push", "push_rollout<f64,kuka>|policy=external|T=100|N=32768")):
+                     ("_push", "push_rollout<f64,kuka>|policy=external|T=100|N=32768"),
+                     ("_datd3", "reach_rollout<f64,kuka>|policy=datd3|T=100|N=65536"),
+                     ("_daddpg", "reach_rollout<f64,kuka>|policy=daddpg|T=100|N=65536")):
         d = pmc(sorted(glob.glob(os.path.join(SRC, f"pmc[34]{suf}_counters.csv"))), short)
         add(d, "rollout", key, 0)
     traffic["_note"] = ("FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over bench.py (KiB per launch, mean over "

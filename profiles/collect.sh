@@ -2,7 +2,7 @@
 # Collects a round's rocprofv3 evidence on the MI355X box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash profiles/collect.sh'        (or `bash profiles/collect.sh pmc` for the counter passes only,
 #                                                               `bash profiles/collect.sh pick` to redo the pick row alone)
-# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r05_*).
+# Writes under gpurun_out/prof/; profiles/aggregate.py turns the outputs into the summaries kept in profiles/ (r06_*).
 # PMC passes are separate runs with --kernel-trace only (never combined with other trace domains).
 set -u
 REPO=$(pwd)
@@ -67,6 +67,13 @@ pmc pmc3_actor_f16x3 FETCH_SIZE -- $A16
 pmc pmc4_actor_f16x3 WRITE_SIZE -- $A16
 pmc pmc3_push FETCH_SIZE -- $PU
 pmc pmc4_push WRITE_SIZE -- $PU
+# the fused two-actor policies (bench.py's datd3_fused / daddpg_fused legs)
+D3="--policy datd3 --steps 300 --warmup 100 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"
+DD="--policy daddpg --steps 300 --warmup 100 --no-cpu-baseline --fence-steps 0 --large-batch 0 --secondary-legs 0"
+pmc pmc3_datd3 FETCH_SIZE -- $D3
+pmc pmc4_datd3 WRITE_SIZE -- $D3
+pmc pmc3_daddpg FETCH_SIZE -- $DD
+pmc pmc4_daddpg WRITE_SIZE -- $DD
 if [ "$MODE" = "all" ]; then
 pmc pmc_actor SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- --policy actor_f16x3 --steps 200 --no-cpu-baseline --fence-steps 0
 pmc pmc_actor3 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_WAVES -- --policy actor_f16x3 --steps 200 --no-cpu-baseline --fence-steps 0
