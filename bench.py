@@ -15,13 +15,19 @@ enqueued right in front of its opening synchronise (the region starts from the c
                  per-step outputs written to [R][N][...] buffers (the trajectory of R armenv_step calls);
   --mode step:   armenv_step, one launch per step (the gym-style call).  In rollout mode this path is also timed
                  beside the headline and reported under "step_api".
-Timing: W untimed steps, then barrier + synchronise, the clock, EXACTLY K steps, synchronise (incl. the logging all-gather of a
-multi-rank run) + barrier, the clock.  `value` = all ranks' env-steps / MAX over ranks of that wall time; `value_steps` = the same
-with each rank's clock stopped when its own launch stream is idle (no collective, no barrier); `value_kernel` = the same steps /
-MAX over ranks of the kernels' own time (HIP events on the launch stream).  Single-GPU runs repeat the identical region 15 more
+Timing -- ONE bracket for 1 and N ranks (round 6): W untimed steps, then device synchronise + barrier, the clock, EXACTLY K steps, the
+launch stream's synchronise + barrier, the clock; the barrier of the bracket is the single-node shared-memory one
+(armenv.dist.ShmBarrier, ~3 us; RCCL's dist.barrier() runs before and after, outside the clock).  A multi-rank run issues its logging
+all-gather INSIDE the region -- RCCL's own ncclAllGather on a side stream behind the steps (armenv.dist.RcclComm; ~40 us of host time
+under the running kernel) -- and waits for it and verifies it right after the clock (config.collective_us, collective_verified).
+`value` = all ranks' env-steps / MAX over ranks of that wall time; `value_steps` = the same with each rank's clock stopped when its
+own launch stream is idle (no barrier); `value_bracketed` = rounds 1-5's multi-rank clock (the collective's completion, a device
+synchronise and dist.barrier() inside it); `value_kernel` = the same steps / MAX over ranks of the kernels' own time (HIP events on
+the launch stream).  Single-GPU runs repeat the identical region 15 more
 times on fresh action rows and report the spread (value_median / value_min / value_max, launch_us_samples) beside the
 contract's first region.  Rank 0 prints ONE JSON line; besides the headline it carries
-short legs for the other single-GPU BASELINE configs (config3_actor_f32, config3_actor_f16x3, config4_push).
+short legs for the other single-GPU BASELINE configs (config3_actor_f32, config3_actor_f16x3, config4_push) and the fused two-actor
+policies (datd3_fused, daddpg_fused).
 The CPU oracle is timed beside it (rank 0, N=1 only) on a bounded sample -- one thread, then every core the process may
 use -- as a baseline, never as the thing measured.  A short extra leg on a second handle with the parity-fence counters on
 reports how often the workload crosses the URDF joint limits / drives the flange below z = 0.05 / runs an IK call to its
@@ -881,6 +887,7 @@ def main():
         env.set_state(**snap, sync=False)       # diagnostic: the contract region behind the same (idempotent) restore as its repeats
     wall, gpu_ms, launches, gathers, dc, wall_steps = timed(args.steps, tag="r0", ahead_ms=args.busy_ahead_ms)
     host_us_main = dict(host_us)
+    extra_main = dict(extra)
 
     # The headline is ONE sample of a short region (the driver's 20 steps are one ~120 us launch): the same region again, 15
     # times -- the env state restored ON THE DEVICE (one kernel on the launch stream, no host round trip) to what it was when the
@@ -912,7 +919,6 @@ def main():
             ab[mode] = res
     scratch.close()
 
-    extra_main = dict(extra)
     t = torch.tensor([wall, gpu_ms * 1e-3, wall_steps, extra_main["wall_bracketed"], 0.0 if extra_main.get("collective_verified", True) else 1.0],
                      dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     per_rank = None

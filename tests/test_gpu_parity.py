@@ -2307,6 +2307,15 @@ def test_bench_line_contract():
     assert "error" not in dd, dd
     assert dd["policy"] == "datd3" and dd["envs"] == 65536 and dd["value_kernel"] > 0.5e9 and 0.2 < dd["roofline_mfma"]["frac"] < 1.0
     assert cf["datd3_us_per_step"] == dd["us_per_step"]
+    da = d["daddpg_fused"]            # the reference's default agent (config.py:33): two actors, ONE critic valuing both proposals
+    assert "error" not in da, da
+    assert da["policy"] == "daddpg" and da["envs"] == 65536 and da["value_kernel"] > 0.5e9 and 0.2 < da["roofline_mfma"]["frac"] < 1.0
+    assert cf["daddpg_us_per_step"] == da["us_per_step"] <= 1.02 * dd["us_per_step"]      # three staged nets: never slower than DATD3's four
+    for leg_ in (dd, da):             # PMC traffic of the two-actor launch shapes
+        assert leg_["roofline"]["traffic"] is not None and 0.9 < leg_["roofline"]["traffic"] / leg_["roofline"]["algo_bytes_per_launch"] < 1.2
+    # the bracket's own numbers as flat keys (round 6)
+    assert cf["procedure_version"] == 3 and cf["barrier_us"] < 50.0 and cf["collective_us"] == 0.0 and cf["collective_verified"] is None
+    assert d["value_steps"] >= d["value"] >= 0.9 * d["value_steps"] and d["value_bracketed"] > 0
 
 
 def test_bench_two_ranks_on_one_gpu_shard_the_trajectory(envs):
