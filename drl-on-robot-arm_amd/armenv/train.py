@@ -1,9 +1,12 @@
 """On-device training loop: the reference's ``run()`` (/root/reference/main.py:77-162) with its four stages kept on the
-GPU -- fused-actor rollouts (armenv_rollout), trajectory store + HER batches (armenv_her_sample), TD3 updates (torch),
+GPU -- fused-policy rollouts (armenv_rollout), trajectory store + HER batches (armenv_her_sample), the agent's updates (torch),
 success accounting (armenv_counters).  One iteration = `rollout_steps` env steps of `num_envs` envs followed by
-`updates` TD3 steps; the reference does 40 updates of 256 samples after every (<= 501-step) episode of its single env.
+`updates` updates; the reference does 40 updates of 256 samples after every (<= 501-step) episode of its single env.
+The agent: `--algo td3` (train_reach_with_TD3's, main.py:165-231) or `--algo daddpg` -- opt.algo's default, what `run()` itself
+instantiates (config.py:33, main.py:93): two actors and one critic, take_action fused into the rollout kernel.
 
     python -m armenv.train --iterations 200
+    python -m armenv.train --iterations 200 --algo daddpg
 """
 import argparse
 import json
@@ -13,16 +16,17 @@ import torch
 
 from . import envs
 from .replay import TrajectoryStore
+from .daddpg import DADDPG
 from .td3 import TD3
 
 
 def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
                 device="cuda:0", actor_kind="actor_f16x3", expl_sigma=0.7 * 0.98, log_every=10, log=print,
-                window_steps=1536, minimal_episodes=5, max_steps=500, use_graphs=True):
+                window_steps=1536, minimal_episodes=5, max_steps=500, use_graphs=True, algo="td3"):
     torch.manual_seed(seed)
     action_bound = 0.7                                            # main.py:87
     env = envs.BatchedReachEnv(num_envs, device=device, seed=seed, max_steps=max_steps)
-    agent = TD3(6, 3, action_bound, device=device)
+    agent = (DADDPG if algo == "daddpg" else TD3)(6, 3, action_bound, device=device)      # getattr(algo, opt.algo)(...), main.py:93
     static = agent.capture(batch_size) if use_graphs else None     # TD3 update as hipGraphs: launch-bound otherwise
     store = TrajectoryStore(device=device, seed=seed, capacity_steps=window_steps)   # last `window_steps` steps of every env
     ready = False
@@ -33,8 +37,11 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
     bufs = {}
     for it in range(iterations):
         # take_action + exploration noise + step, fused (main.py:114-124)
-        env.set_policy(actor_kind, action_bound=action_bound, noise_sigma=expl_sigma, noise_clip=action_bound,
-                       actor_state_dict=agent.actor_state_dict())
+        if algo == "daddpg":
+            env.set_policy_daddpg(*agent.policy_state_dicts(), action_bound=action_bound, noise_sigma=expl_sigma, noise_clip=action_bound)
+        else:
+            env.set_policy(actor_kind, action_bound=action_bound, noise_sigma=expl_sigma, noise_clip=action_bound,
+                           actor_state_dict=agent.actor_state_dict())
         obs0 = obs.clone()
         out = env.rollout(rollout_steps, None, out=bufs, want_actions=True, want_terminal_obs=True)
         obs = out["obs"][-1]
@@ -118,13 +125,14 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--window-steps", type=int, default=1536)
     ap.add_argument("--max-steps", type=int, default=500, help="opt.max_steps_one_episode")
+    ap.add_argument("--algo", default="td3", choices=["td3", "daddpg"], help="reach only: the agent (config.py:33's default is DADDPG_MLP)")
     a = ap.parse_args()
     if a.task != "reach":
         train_push(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
                    window_steps=a.window_steps, max_steps=a.max_steps, task=a.task)
         return
     train_reach(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
-                expl_sigma=a.sigma, window_steps=a.window_steps, max_steps=a.max_steps)
+                expl_sigma=a.sigma, window_steps=a.window_steps, max_steps=a.max_steps, algo=a.algo)
 
 
 if __name__ == "__main__":

@@ -589,7 +589,36 @@ def g15_daddpg_darc_take_action():
     np.savez_compressed(os.path.join(OUT, "darc_take_action_seed0.npz"), **out)
 
 
+def g16_daddpg_train():
+    """G16: eight DADDPG_MLP.train() updates of the reference's default agent (algo/DADDPG/DADDPG_mlp.py:114-171) from
+    torch.manual_seed(0) initialisation on fixed batches (four updates of each actor, the critic's target soft-updated on the odd
+    ones): critic losses and the final parameters of all six nets."""
+    sys.path.insert(0, REF)
+    import torch
+    from algo.DADDPG.DADDPG_mlp import DADDPG_MLP
+    torch.manual_seed(0)
+    agent = DADDPG_MLP(6, 3, 0.7, device=torch.device("cpu"))
+    rng = np.random.default_rng(16)
+    B = 64
+    batches = []
+    for _ in range(8):
+        st = rng.uniform(0.2, 0.6, (B, 6)).astype(np.float32)
+        ns = st.copy(); ns[:, :3] += rng.normal(0, 0.01, (B, 3)).astype(np.float32)
+        batches.append(dict(states=st, actions=rng.uniform(-0.7, 0.7, (B, 3)).astype(np.float32), next_states=ns,
+                            rewards=rng.choice([-0.1, 1.0], B).astype(np.float32), dones=rng.integers(0, 2, B).astype(np.uint8)))
+    losses = [float(agent.update({k: v.tolist() if k in ("rewards", "dones") else v for k, v in b.items()}, B)) for b in batches]
+    out = {"losses": np.array(losses)}
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            out[f"b{i}_{k}"] = v
+    for name in ("actor1", "actor2", "critic", "target_actor1", "target_actor2", "target_critic"):
+        for k, v in getattr(agent, name).state_dict().items():
+            out[f"{name}__{k.replace('.', '_')}"] = v.detach().numpy().copy()
+    np.savez(os.path.join(OUT, "daddpg_train_seed0.npz"), **out)
+
+
 if __name__ == "__main__":
+    g16_daddpg_train()
     g15_daddpg_darc_take_action()
     g14_datd3_take_action_nine_inputs()
     g13_visdata_push_td3()

@@ -2077,6 +2077,39 @@ def test_td3_update_as_hipgraph_equals_eager(envs):
     assert static is b._graphs["buf"]
 
 
+def test_training_loop_daddpg_default_agent(envs):
+    """The reference's `run()` with its DEFAULT agent (main.py:77-162 with opt.algo = 'DADDPG_MLP', config.py:33) on the device:
+    DADDPG_MLP.take_action fused into the rollouts (armenv_set_policy_daddpg, re-installed from the learner every iteration), HER
+    batches from the device store, DADDPG's alternating updates replayed from hipGraphs -- and the graphed update follows the eager
+    one (as test_td3_update_as_hipgraph_equals_eager)."""
+    from armenv.daddpg import DADDPG
+    from armenv.train import train_reach
+    agent, hist = train_reach(num_envs=256, iterations=8, rollout_steps=16, updates=4, batch_size=256, window_steps=64,
+                              max_steps=20, log_every=4, log=lambda s: None, algo="daddpg")
+    assert isinstance(agent, DADDPG) and agent.total_it > 0
+    assert len(hist) == 2 and hist[-1]["env_steps"] == 256 * 16 * 8 and hist[-1]["episodes"] >= 256 * 5
+    assert all(torch.isfinite(p).all() for n_ in agent._nets() for p in n_.parameters())
+    torch.manual_seed(3)
+    a, b = DADDPG(6, 3, 0.7, device=DEV), DADDPG(6, 3, 0.7, device=DEV)
+    for nb, na in zip(b._nets(), a._nets()):
+        nb.load_state_dict(na.state_dict())
+    B = 512
+    b.capture(B)
+    gen = torch.Generator(device=DEV); gen.manual_seed(11)
+    mk = lambda: dict(states=torch.rand(B, 6, device=DEV, generator=gen), actions=torch.rand(B, 3, device=DEV, generator=gen) - 0.5,
+                      next_states=torch.rand(B, 6, device=DEV, generator=gen), rewards=torch.rand(B, device=DEV, generator=gen),
+                      dones=(torch.rand(B, device=DEV, generator=gen) < 0.1).to(torch.uint8))
+    for it in range(20):
+        batch = mk()
+        la, lb = float(a.train(batch)), float(b.train_graphed(batch))
+        assert abs(la - lb) < 2e-3 * max(1.0, abs(la)), (it, la, lb)
+    held = mk()
+    with torch.no_grad():
+        for x, y in ((a.actor1, b.actor1), (a.actor2, b.actor2), (a.target_actor1, b.target_actor1)):
+            assert float((x(held["states"]) - y(held["states"])).abs().max()) < 5e-3
+        assert float((a.critic(held["states"], held["actions"]) - b.critic(held["states"], held["actions"])).abs().max()) < 5e-3
+
+
 def test_training_loop_smoke_pick(envs):
     """train_pick_with_TD3 (main.py:518-585) on the device: the 9-input fused actor drives PickLane rollouts."""
     from armenv.train import train_push

@@ -263,6 +263,37 @@ def test_ddpg_and_datd3_take_action_match_reference_golden():
     assert np.array_equal((q1 < q2).numpy()[clear], g["picked_actor"][clear].astype(bool))
 
 
+def test_daddpg_learner_reproduces_the_reference_updates():
+    """G16: eight DADDPG_MLP.update() calls of the reference's default agent (/root/reference/algo/DADDPG/DADDPG_mlp.py:117-171;
+    config.py:33) reproduced by armenv.daddpg.DADDPG on the CPU: the same initial weights under torch.manual_seed(0) (creation order
+    actor1, actor2, critic), critic losses to 2e-6, every parameter of the six nets to 2e-6 -- including which target is soft-updated
+    on which update (actor 1's on even updates; actor 2's and the critic's on odd ones) -- and take_action's selection."""
+    import torch
+    from conftest import golden_npz
+    from armenv.daddpg import DADDPG
+    g = golden_npz("daddpg_train_seed0.npz")
+    torch.manual_seed(0)
+    agent = DADDPG(6, 3, 0.7, device="cpu")
+    for i, want in enumerate(g["losses"]):
+        b = {k: torch.from_numpy(g[f"b{i}_{k}"]) for k in ("states", "actions", "next_states", "rewards", "dones")}
+        loss = float(agent.train(b))
+        assert abs(loss - want) < 2e-6 * max(1.0, abs(want)), (i, loss, want)
+    assert agent.total_it == 8
+    for name in ("actor1", "actor2", "critic", "target_actor1", "target_actor2", "target_critic"):
+        for k, v in getattr(agent, name).state_dict().items():
+            d = np.abs(v.numpy() - g[f"{name}__{k.replace('.', '_')}"])
+            assert (d < 2e-6).mean() > 0.999 and d.max() < 2e-3, (name, k, (d < 2e-6).mean(), d.max())     # (Adam: see the TD3 test)
+    g15 = golden_npz("daddpg_take_action_seed0.npz")
+    pol = DADDPG(6, 3, float(g15["action_bound"]), device="cpu")
+    for name in ("actor1", "actor2", "critic"):
+        getattr(pol, name).load_state_dict(_sd(g15, name))
+    clear = np.abs(g15["q1"] - g15["q2"]) > 1e-4
+    for i in np.flatnonzero(clear)[:40]:
+        assert np.abs(pol.take_action(g15["states"][i]) - g15["actions"][i]).max() < 5e-6
+    a1, a2, c = pol.policy_state_dicts()
+    assert tuple(a1["fc1.weight"].shape) == (256, 6) and tuple(c["fc1.weight"].shape) == (256, 9) and tuple(c["fc3.weight"].shape) == (1, 256)
+
+
 def test_bench_launcher_relays_exit_code_and_refuses_contradictions():
     """`python bench.py --gpus 2` without WORLD_SIZE starts its own two ranks (torch.distributed.run on a free 127.0.0.1 port) and
     relays their exit code -- here, without a GPU, both ranks fail, and the launcher must come back non-zero without a JSON line
