@@ -87,7 +87,9 @@ def by_steps(trace_csv, bench_json, dst):
     except Exception:
         return
     spl = float(b["config"]["steps_per_launch"])
-    us_step = b["roofline"]["avg_launch_us"] / spl
+    # (the median of the run's repeated regions where the line has it: the contract region alone can carry a host hiccup between its
+    # opening event and its launch -- under the profiler it did, 331 us for a 120 us kernel, and every launch was mislabelled)
+    us_step = (b.get("launch_us_median") or b["roofline"]["avg_launch_us"]) / spl
     R = int(round(spl))
     W = int(b["warmup"])
     cands = sorted({R, 100, (W % R) or R})          # the warm-up's last (short) launch, the timed launches, the 100-step legs

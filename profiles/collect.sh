@@ -27,6 +27,12 @@ stats push32768 --task push --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
 stats pick32768 --task pick --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
 stats f32engine --precision 32 --steps 1000 --no-cpu-baseline --fence-steps 0 --secondary-legs 0
 fi
+if [ "$MODE" = "driver" ]; then
+stats driver --steps 20 --warmup 5
+stats driver2 --steps 20 --warmup 5
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+exit 0
+fi
 if [ "$MODE" = "pick" ]; then
 stats pick32768 --task pick --envs-per-gpu 32768 --steps 1000 --no-cpu-baseline
 fi
