@@ -175,7 +175,10 @@ typedef struct ArmEnvConfig {
    *     nominal one; push_contact_erp and push_friction are FITTED to the touched episodes (tests/tools/fit_bullet.py part C, DESIGN.md
    *     section 2): counts of steps on which the cube moves 149 / 192 / 90 / 43 against Bullet's 149 / 192 / 84 / 32, returns under the
    *     shipped reward within 12.4 (rounds 1-4: 25-195 off), final cube-target distances within 4.3 cm.  Effective values of this planar
-   *     stand-in, not Bullet's contact parameters.
+   *     stand-in, not Bullet's contact parameters, and PROVISIONAL: checked in-sample only.  (Round 6 tested the alternative the data
+   *     suggests -- a cube that can tip, Bullet's own ERP 0.2 and friction 2.5, nothing fitted: it explains the moving-step counts the
+   *     planar model needs an 80 x too slippery table for, and misses the returns by 38 or more, chaotically in the contact height:
+   *     profiles/r06_push_rocking_model.txt.  Not adopted.)
    *   0: rounds 1-4 -- tool sphere of push_eef_radius at the link-7 frame, the whole penetration removed in one step, the cube
    *     already at rest at push_rest_z after reset().
    * The pick task loads the SAME body into the same scene (rl_pick_env.py:210): with push_contact_model = 1 its cube falls the same way
