@@ -54,20 +54,12 @@ class DADDPG(GraphedLearner):
             tq = torch.min(self.target_critic(s2, self.target_actor1(s2)), self.target_critic(s2, self.target_actor2(s2)))
             target_q = r + (1 - d) * self.gamma * tq
         critic_loss = F.mse_loss(self.critic(s, a), target_q)
-        self.critic_opt.zero_grad()
-        critic_loss.backward()
-        self.critic_opt.step()
+        self._step(critic_loss, self.critic_opt)
         if update_a1:
-            loss = -self.critic(s, self.actor1(s)).mean()
-            self.actor1_opt.zero_grad()
-            loss.backward()
-            self.actor1_opt.step()
+            self._step(-self.critic(s, self.actor1(s)).mean(), self.actor1_opt)
             self._soft_update(self.actor1, self.target_actor1)
         else:
-            loss = -self.critic(s, self.actor2(s)).mean()
-            self.actor2_opt.zero_grad()
-            loss.backward()
-            self.actor2_opt.step()
+            self._step(-self.critic(s, self.actor2(s)).mean(), self.actor2_opt)
             self._soft_update(self.actor2, self.target_actor2)
             self._soft_update(self.critic, self.target_critic)
         return critic_loss.detach()

@@ -40,121 +40,7 @@ class TwinCritic(nn.Module):
         return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x))))), self.fc6(F.relu(self.fc5(F.relu(self.fc4(x)))))
 
 
-class GraphedLearner:
-    """What the learners of this package share: soft updates, `train(batch)` from a dict of device tensors, and the update replayed
-    from hipGraphs.  A subclass provides `_update(s, a, r, s2, d, flag)` (one update; `flag` selects which of its two variants runs),
-    `_flag()` (the variant of update number self.total_it), `_nets()` and `_opts()` (everything an update may write)."""
-
-    tau = 0.005
-    total_it = 0
-    _graphs = None
-
-    @torch.no_grad()
-    def _soft_update(self, net, target):
-        for pt, p in zip(target.parameters(), net.parameters()):
-            pt.mul_(1.0 - self.tau).add_(p, alpha=self.tau)
-
-    @staticmethod
-    def _step(loss, opt):
-        """loss.backward() + opt.step() of the reference's updates, written so that it means the same thing eagerly and replayed from
-        a hipGraph: the gradients of `loss` with respect to the parameters `opt` owns -- and nothing else -- go into PERSISTENT .grad
-        buffers (made once, written by a copy).  `loss.backward()` also leaves gradients on every other parameter the loss touches (the
-        actor loss on the critic's: the reference wipes them with the next zero_grad) and re-makes the .grad tensors it writes to; under
-        capture those tensors live in the capturing graph's private pool, and with two captured variants sharing one optimiser the
-        graphed TD3 never got past 20-60 % success on the reach task where the eager one reaches 100 % (round 6, gpurun_out/r06:
-        train_bisect; policy_freq = 1, one variant only, was fine)."""
-        params = [p for g in opt.param_groups for p in g["params"]]
-        grads = torch.autograd.grad(loss, params)
-        with torch.no_grad():
-            for p, g in zip(params, grads):
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-                p.grad.copy_(g)
-        opt.step()
-
-    def train(self, batch):
-        """One update from a dict of device tensors: states [B,D], actions [B,3], next_states [B,D], rewards [B], dones [B] (any
-        dtype).  Returns the critic loss as a 0-dim tensor (no host sync)."""
-        s = batch["states"].to(self.device, torch.float32)
-        a = batch["actions"].to(self.device, torch.float32)
-        r = batch["rewards"].to(self.device, torch.float32).view(-1, 1)
-        s2 = batch["next_states"].to(self.device, torch.float32)
-        d = batch["dones"].to(self.device, torch.float32).view(-1, 1)
-        self.total_it += 1
-        return self._update(s, a, r, s2, d, self._flag())
-
-    # ---- hipGraph path: one update is ~130 small kernels (1.7 ms of launch latency at any batch size up to 16 k);
-    # replayed from a captured graph it costs its kernel time only.
-    def capture(self, batch_size):
-        """Captures the two update variants as hipGraphs over static input buffers of `batch_size` rows; ``train_graphed`` then
-        replays them.  Parameters and optimiser state are left exactly as they were (the warm-up and capture passes run on a
-        snapshot that is restored)."""
-        dev, B = self.device, int(batch_size)
-        D, A = self.actor.fc1.in_features, self.actor.fc3.out_features
-        buf = dict(states=torch.zeros(B, D, device=dev), actions=torch.zeros(B, A, device=dev),
-                   next_states=torch.zeros(B, D, device=dev), rewards=torch.zeros(B, device=dev),
-                   dones=torch.zeros(B, dtype=torch.uint8, device=dev))
-        loss = torch.zeros((), device=dev)
-        nets, opts = self._nets(), self._opts()
-
-        def run(flag):
-            out = self._update(buf["states"], buf["actions"], buf["rewards"].view(-1, 1), buf["next_states"],
-                               buf["dones"].to(torch.float32).view(-1, 1), flag)
-            loss.copy_(out)
-
-        def snapshot():
-            return ([{k: v.clone() for k, v in n.state_dict().items()} for n in nets], [copy.deepcopy(o.state_dict()) for o in opts])
-
-        def restore(snap):
-            with torch.no_grad():
-                for n, sd in zip(nets, snap[0]):
-                    for k, v in n.state_dict().items():
-                        v.copy_(sd[k])
-                # in place (the graphs alias these tensors); state that did not exist before the warm-up goes back to a
-                # fresh Adam's: zero moments, step 0
-                for opt, saved in zip(opts, (x["state"] for x in snap[1])):
-                    for pid, p in enumerate(opt.param_groups[0]["params"]):
-                        for k, v in opt.state[p].items():
-                            if pid in saved:
-                                v.copy_(saved[pid][k])
-                            else:
-                                v.zero_()
-
-        first = snapshot()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                       # warm-up: allocates grads and optimiser state
-            for _ in range(2):
-                run(True)
-                run(False)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graphs = {}
-        for flag in (False, True):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                run(flag)
-            graphs[flag] = g
-        # optimiser state may not have existed before the warm-up: "restore" then means zero moments and step 0
-        restore(first)
-        torch.cuda.synchronize(dev)
-        self._graphs = dict(buf=buf, loss=loss, g=graphs, B=B)
-        return buf
-
-    def train_graphed(self, batch):
-        """``train`` through the captured graphs: `batch` is copied into the static buffers (or IS the dict returned by
-        ``capture`` / filled in place by ``TrajectoryStore.sample(out=...)``).  Returns the loss tensor of the replay."""
-        g = self._graphs
-        if g is None:
-            raise RuntimeError("%s.train_graphed: call capture(batch_size) first" % type(self).__name__)
-        if batch is not g["buf"]:
-            for k, v in g["buf"].items():
-                v.copy_(batch[k].view_as(v))
-        self.total_it += 1
-        g["g"][self._flag()].replay()
-        return g["loss"]
-
-
-class TD3(GraphedLearner):
+class TD3:
     """Hyper-parameters default to config.py:55-73 (hidden 256, lr 1e-3, tau 0.005, gamma 0.98, policy noise 0.2,
     clip 0.5, delayed actor update every 3 critic updates)."""
 
@@ -175,17 +61,23 @@ class TD3(GraphedLearner):
         self.total_it = 0
         self._graphs = None
 
-    def _flag(self):
-        return self.total_it % self.policy_freq == 0        # delayed actor + soft updates, TD3_mlp.py:144
+    @torch.no_grad()
+    def _soft_update(self, net, target):
+        for pt, p in zip(target.parameters(), net.parameters()):
+            pt.mul_(1.0 - self.tau).add_(p, alpha=self.tau)
 
-    def _nets(self):
-        return (self.actor, self.critic, self.target_actor, self.target_critic)
-
-    def _opts(self):
-        return (self.actor_opt, self.critic_opt)
+    def train(self, batch):
+        """One TD3 update from a dict of device tensors: states [B,D], actions [B,3], next_states [B,D], rewards [B],
+        dones [B] (any dtype).  Returns the critic loss as a 0-dim tensor (no host sync).  TD3_mlp.py:114-161."""
+        s = batch["states"].to(self.device, torch.float32)
+        a = batch["actions"].to(self.device, torch.float32)
+        r = batch["rewards"].to(self.device, torch.float32).view(-1, 1)
+        s2 = batch["next_states"].to(self.device, torch.float32)
+        d = batch["dones"].to(self.device, torch.float32).view(-1, 1)
+        self.total_it += 1
+        return self._update(s, a, r, s2, d, self.total_it % self.policy_freq == 0)
 
     def _update(self, s, a, r, s2, d, with_actor):
-        """TD3_mlp.py:114-161"""
         with torch.no_grad():
             noise = (torch.randn_like(a) * self.policy_noise).clamp(-self.noise_clip, self.noise_clip)
             a2 = (self.target_actor(s2) + noise).clamp(-self.action_bound, self.action_bound)
@@ -193,13 +85,87 @@ class TD3(GraphedLearner):
             target_q = r + (1 - d) * self.gamma * torch.min(tq1, tq2)
         q1, q2 = self.critic(s, a)
         critic_loss = F.mse_loss(q1, target_q) + F.mse_loss(q2, target_q)
-        self._step(critic_loss, self.critic_opt)
+        self.critic_opt.zero_grad()
+        critic_loss.backward()
+        self.critic_opt.step()
         if with_actor:
             actor_loss = -self.critic.q1(s, self.actor(s)).mean()
-            self._step(actor_loss, self.actor_opt)
+            self.actor_opt.zero_grad()
+            actor_loss.backward()
+            self.actor_opt.step()
             self._soft_update(self.actor, self.target_actor)
             self._soft_update(self.critic, self.target_critic)
         return critic_loss.detach()
+
+    # ---- hipGraph path: one update is ~130 small kernels (1.7 ms of launch latency at any batch size up to 16 k);
+    # replayed from a captured graph it costs its kernel time only.
+    def capture(self, batch_size):
+        """Captures the two update variants (critic only / critic + delayed actor + soft updates) as hipGraphs over
+        static input buffers of `batch_size` rows; ``train_graphed`` then replays them.  Parameters and optimiser state
+        are left exactly as they were (the warm-up and capture passes run on a snapshot that is restored)."""
+        dev, B = self.device, int(batch_size)
+        D, A = self.actor.fc1.in_features, self.actor.fc3.out_features
+        buf = dict(states=torch.zeros(B, D, device=dev), actions=torch.zeros(B, A, device=dev),
+                   next_states=torch.zeros(B, D, device=dev), rewards=torch.zeros(B, device=dev),
+                   dones=torch.zeros(B, dtype=torch.uint8, device=dev))
+        loss = torch.zeros((), device=dev)
+        nets = (self.actor, self.critic, self.target_actor, self.target_critic)
+
+        def run(with_actor):
+            out = self._update(buf["states"], buf["actions"], buf["rewards"].view(-1, 1), buf["next_states"],
+                               buf["dones"].to(torch.float32).view(-1, 1), with_actor)
+            loss.copy_(out)
+
+        def snapshot():
+            return ([{k: v.clone() for k, v in n.state_dict().items()} for n in nets],
+                    copy.deepcopy(self.actor_opt.state_dict()), copy.deepcopy(self.critic_opt.state_dict()))
+
+        def restore(snap):
+            with torch.no_grad():
+                for n, sd in zip(nets, snap[0]):
+                    for k, v in n.state_dict().items():
+                        v.copy_(sd[k])
+                # in place (the graphs alias these tensors); state that did not exist before the warm-up goes back to a
+                # fresh Adam's: zero moments, step 0
+                for opt, saved in ((self.actor_opt, snap[1]["state"]), (self.critic_opt, snap[2]["state"])):
+                    for pid, p in enumerate(opt.param_groups[0]["params"]):
+                        for k, v in opt.state[p].items():
+                            if pid in saved:
+                                v.copy_(saved[pid][k])
+                            else:
+                                v.zero_()
+
+        first = snapshot()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up: allocates grads and optimiser state
+            for _ in range(2):
+                run(True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graphs = {}
+        for with_actor in (False, True):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run(with_actor)
+            graphs[with_actor] = g
+        # optimiser state may not have existed before the warm-up: "restore" then means zero moments and step 0
+        restore(first)
+        torch.cuda.synchronize(dev)
+        self._graphs = dict(buf=buf, loss=loss, g=graphs, B=B)
+        return buf
+
+    def train_graphed(self, batch):
+        """``train`` through the captured graphs: `batch` is copied into the static buffers (or IS the dict returned by
+        ``capture`` / filled in place by ``TrajectoryStore.sample(out=...)``).  Returns the loss tensor of the replay."""
+        g = self._graphs
+        if g is None:
+            raise RuntimeError("TD3.train_graphed: call capture(batch_size) first")
+        if batch is not g["buf"]:
+            for k, v in g["buf"].items():
+                v.copy_(batch[k].view_as(v))
+        self.total_it += 1
+        g["g"][self.total_it % self.policy_freq == 0].replay()
+        return g["loss"]
 
     def take_action(self, state):
         """TD3_MLP.take_action (TD3_mlp.py:82-97): one state (sequence of floats) -> np.float32[action_dim], no exploration noise
