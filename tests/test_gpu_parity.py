@@ -2013,7 +2013,7 @@ def test_training_loop_smoke(envs):
     from armenv.train import train_reach
     logs = []
     agent, hist = train_reach(num_envs=256, iterations=12, rollout_steps=16, updates=4, batch_size=256, window_steps=64,
-                              max_steps=20, log_every=4, log=logs.append)
+                              max_steps=20, log_every=4, log=logs.append, use_graphs=True)      # (the opt-in hipGraph path still runs)
     assert len(hist) == 3 and hist[-1]["env_steps"] == 256 * 16 * 12 and hist[-1]["episodes"] >= 256 * 8
     assert agent.total_it > 0
     assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
@@ -2085,7 +2085,7 @@ def test_training_loop_daddpg_default_agent(envs):
     from armenv.daddpg import DADDPG
     from armenv.train import train_reach
     agent, hist = train_reach(num_envs=256, iterations=8, rollout_steps=16, updates=4, batch_size=256, window_steps=64,
-                              max_steps=20, log_every=4, log=lambda s: None, algo="daddpg")
+                              max_steps=20, log_every=4, log=lambda s: None, algo="daddpg", use_graphs=True)
     assert isinstance(agent, DADDPG) and agent.total_it > 0
     assert len(hist) == 2 and hist[-1]["env_steps"] == 256 * 16 * 8 and hist[-1]["episodes"] >= 256 * 5
     assert all(torch.isfinite(p).all() for n_ in agent._nets() for p in n_.parameters())
@@ -2102,12 +2102,25 @@ def test_training_loop_daddpg_default_agent(envs):
     for it in range(20):
         batch = mk()
         la, lb = float(a.train(batch)), float(b.train_graphed(batch))
-        assert abs(la - lb) < 2e-3 * max(1.0, abs(la)), (it, la, lb)
+        assert abs(la - lb) < 5e-3 * max(1.0, abs(la)), (it, la, lb)      # (Adam: lr-sized differences from the fifth update on, see TD3's test)
     held = mk()
     with torch.no_grad():
         for x, y in ((a.actor1, b.actor1), (a.actor2, b.actor2), (a.target_actor1, b.target_actor1)):
             assert float((x(held["states"]) - y(held["states"])).abs().max()) < 5e-3
         assert float((a.critic(held["states"], held["actions"]) - b.critic(held["states"], held["actions"])).abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize("algo", ["td3", "daddpg"])
+def test_training_loop_learns_the_reach_task(envs, algo):
+    """The on-device `run()` loop with its default settings LEARNS: >= 90 % of the episodes finished in the last 20 of 140 iterations end
+    in success (reach_dis 0.01), for train_reach_with_TD3's agent and for the reference's default agent DADDPG.  A regression test of
+    round 6: until then only smoke runs were tested, and the hipGraph update path -- green in its 30-update comparison with the eager
+    one -- had stopped learning (TD3: 20-60 %); it is opt-in now (profiles/r06_td3_hipgraph_learning.txt)."""
+    from armenv.train import train_reach
+    hist = []
+    import json
+    train_reach(iterations=140, log_every=20, log=lambda s_: hist.append(json.loads(s_)), algo=algo)
+    assert hist[-1]["success_rate"] >= 0.9 and hist[-1]["episodes"] > 5000, [round(h["success_rate"], 2) for h in hist]
 
 
 def test_training_loop_smoke_pick(envs):
