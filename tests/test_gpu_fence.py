@@ -231,7 +231,9 @@ def test_pick_32768_free_running_vs_oracle(envs, O, kuka, record_property):
     assert r["counters"]["nonfinite"] == 0
 
 
-@pytest.mark.parametrize("task,seed", [("push", 6), ("push", 16), ("push", 26), ("pick", 7), ("pick", 17), ("pick", 27)])
+# (two seeds per task since round 6 -- the third, 26 / 27, gave the same rates to the second decimal in round 5 and cost a minute of
+# the suite: profiles/r05_fence_free_running.txt)
+@pytest.mark.parametrize("task,seed", [("push", 6), ("push", 16), ("pick", 7), ("pick", 17)])
 def test_cube_tasks_strict_tier_with_resync(envs, O, kuka, record_property, task, seed):
     """The strict tier over (nearly) everything: the same workloads as the two free-running tests above (32 768 envs, exploration
     noise of main.py:484 / :552, 501-step episodes, 600 steps), one env step per launch, and after every launch the oracle twin of
