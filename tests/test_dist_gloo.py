@@ -89,6 +89,14 @@ BARRIER_WORKER = textwrap.dedent("""
     g.launch(lambda: torch.full((3,), float(rank)))
     assert torch.equal(g.result(), torch.arange(world, dtype=torch.float32).repeat_interleave(3))
     g.order_after_read()                        # no stream on CPU: nothing to order, must not fail
+    # the producer that WRITES the send buffer (bench.py: armenv_episode_returns_f32 into the slot), with and without a raw stream argument
+    g.warm_up(2)
+    g.launch_into(lambda stage: stage.fill_(10.0 + rank))
+    assert torch.equal(g.result(), (10.0 + torch.arange(world, dtype=torch.float32)).repeat_interleave(3))
+    g.launch_into(lambda stage, stream=None: stage.fill_(20.0 + rank) if stream is None else None, takes_stream=True)
+    assert torch.equal(g.result(), (20.0 + torch.arange(world, dtype=torch.float32)).repeat_interleave(3))
+    assert g.rccl is None and g.direct_error is None        # gloo: no direct RCCL communicator is attempted
+    g.close()
     b.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -546,6 +546,30 @@ def test_bench_one_rank_over_rccl(envs):
     e.close()
 
 
+def test_episode_returns_f32_is_the_logging_vector(envs):
+    """armenv_episode_returns_f32 (ABI 6): the per-env return of the last finished episode as ONE f32 vector -- the send buffer of the
+    logging all-gather -- equals armenv_episode_stats' f64 vector rounded once, into a fresh tensor, into a caller's buffer, and on a
+    raw side stream ordered by the caller (ReturnGatherer.launch_into(..., takes_stream=True)); a wrong buffer is refused."""
+    from armenv.dist import ReturnGatherer
+    n = 4096 + 64
+    e = envs.BatchedReachEnv(n, device=DEV, seed=5, max_steps=15)
+    e.reset()
+    gen = torch.Generator(device=DEV); gen.manual_seed(2)
+    e.rollout(40, (torch.randn((40, n, 3), device=DEV, generator=gen) * 0.686).clamp_(-0.7, 0.7))
+    want = e.episode_stats()[0].to(torch.float32)
+    assert float(want.min()) < 0.0 and torch.equal(e.episode_returns_f32(), want)
+    out = torch.empty(n, dtype=torch.float32, device=DEV)
+    assert e.episode_returns_f32(out=out) is out and torch.equal(out, want)
+    with pytest.raises(ValueError):
+        e.episode_returns_f32(out=torch.empty(n, dtype=torch.float64, device=DEV))
+    g = ReturnGatherer(n, DEV, 1)                      # one rank, no process group: the side-stream plumbing without a collective
+    g.launch_into(lambda stage, stream=None: e.episode_returns_f32(out=stage, stream=stream), takes_stream=True)
+    g.order_after_read()
+    e.rollout(3, torch.zeros((3, n, 3), device=DEV))  # the next launch waits until the returns have been read
+    assert torch.equal(g.result(), want)
+    e.close()
+
+
 def test_bench_one_rank_over_rccl_keeps_the_single_gpu_value():
     """the N-rank `value` measures the engine.  The driver's shape (`--steps 20 --warmup 5`, 65 536 envs) as ONE
     rank down the whole RCCL path (process group, dist.barrier() around the bracket, the logging all-gather issued inside the region)
