@@ -1137,7 +1137,7 @@ def main():
         if step_api:
             cfg["step_api_us"] = step_api["avg_launch_us"]
         if in_kernel:
-            cfg["in_kernel_policy_us_per_step"] = in_kernel["us_per_step"]
+            cfg["in_kernel_policy_us_per_step"] = cfg["in_kernel_us_per_step"] = in_kernel["us_per_step"]
         if isinstance(line.get("large_batch"), dict) and "us_per_step" in line["large_batch"]:
             cfg["large_batch_env_steps_per_s"] = line["large_batch"]["value"]
         if isinstance(line.get("cpu_baseline"), dict) and "value" in line["cpu_baseline"]:
