@@ -4,10 +4,9 @@ ONE critic, alternating actor updates.  Like armenv.td3 it consumes device-resid
 and hands its three nets to the env engine for fused rollouts (BatchedArmEnv.set_policy_daddpg: take_action inside the rollout
 kernel).  Stock torch ops: the learner is integration, not a kernel."""
 import torch
-import torch.nn.functional as F
 
 from .policies import QValueNet
-from .td3 import Actor, GraphedLearner
+from .td3 import Actor, GraphedLearner, mean_sq, neg_mean
 
 
 class DADDPG(GraphedLearner):
@@ -53,13 +52,13 @@ class DADDPG(GraphedLearner):
         with torch.no_grad():
             tq = torch.min(self.target_critic(s2, self.target_actor1(s2)), self.target_critic(s2, self.target_actor2(s2)))
             target_q = r + (1 - d) * self.gamma * tq
-        critic_loss = F.mse_loss(self.critic(s, a), target_q)
+        critic_loss = mean_sq(self.critic(s, a) - target_q)                      # F.mse_loss, DADDPG_mlp.py:142
         self._step(critic_loss, self.critic_opt)
         if update_a1:
-            self._step(-self.critic(s, self.actor1(s)).mean(), self.actor1_opt)
+            self._step(neg_mean(self.critic(s, self.actor1(s))), self.actor1_opt)
             self._soft_update(self.actor1, self.target_actor1)
         else:
-            self._step(-self.critic(s, self.actor2(s)).mean(), self.actor2_opt)
+            self._step(neg_mean(self.critic(s, self.actor2(s))), self.actor2_opt)
             self._soft_update(self.actor2, self.target_actor2)
             self._soft_update(self.critic, self.target_critic)
         return critic_loss.detach()

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .td3 import Actor
+from .td3 import Actor, linear
 
 
 class QValueNet(nn.Module):
@@ -31,7 +31,7 @@ class QValueNet(nn.Module):
         self.fc3 = nn.Linear(hidden_dim, 1)
 
     def forward(self, s, a):
-        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(torch.cat([s, a], dim=1))))))
+        return linear(self.fc3, F.relu(linear(self.fc2, F.relu(linear(self.fc1, torch.cat([s, a], dim=1))))))
 
 
 class DDPGPolicy:

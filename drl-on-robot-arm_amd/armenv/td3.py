@@ -9,6 +9,52 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _CaptureSafeLinear(torch.autograd.Function):
+    """y = x W^T + b whose backward contains no multi-block REDUCTION: the bias gradient is a GEMM with a row of ones.
+
+    Why: torch's reductions initialise their cross-block semaphores with cudaMemsetAsync (ATen/native/cuda/Reduce.cuh), and on this
+    ROCm 7.2 / PyTorch 2.10 build a hipMemsetAsync captured into a hipGraph does its work on the FIRST replay only -- later replays
+    write pointer-like garbage to the destination (tests/tools/exp/graph_memset_probe.py: 49 of 50 replays wrong for every size from
+    64 B to 64 KB; the eager call is right 50 of 50).  A captured `grad_output.sum(0)` therefore goes wrong from the second replay
+    on: in the captured TD3 / DADDPG updates every gradient was bit-identical to the eager one EXCEPT the bias gradients, off by 0.4-0.7
+    on 103 of 150 updates, and the replayed learners did not learn (profiles/r06_td3_hipgraph_learning.txt).  Used by `linear()` below
+    under stream capture only; the eager path stays `F.linear` (bit-identical to the reference's modules)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g.mm(w) if ctx.needs_input_grad[0] else None
+        gw = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        gb = torch.ones(1, g.shape[0], dtype=g.dtype, device=g.device).mm(g)[0] if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def linear(layer, x):
+    """`layer(x)` for an nn.Linear: F.linear eagerly, _CaptureSafeLinear while the current stream is being captured into a hipGraph"""
+    if x.is_cuda and torch.cuda.is_current_stream_capturing():
+        return _CaptureSafeLinear.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
+def mean_sq(d):
+    """mean(d^2) of a [B, 1] column -- F.mse_loss's value -- as a 1 x 1 GEMM under capture (no multi-block reduction, see above)"""
+    if d.is_cuda and torch.cuda.is_current_stream_capturing():
+        return (d.t().mm(d) / d.shape[0])[0, 0]
+    return (d * d).mean()
+
+
+def neg_mean(q):
+    """-mean(q) of a [B, 1] column (the actors' loss), as a GEMM with a row of ones under capture"""
+    if q.is_cuda and torch.cuda.is_current_stream_capturing():
+        return -(torch.ones(1, q.shape[0], dtype=q.dtype, device=q.device).mm(q) / q.shape[0])[0, 0]
+    return -q.mean()
+
+
 class Actor(nn.Module):
     """a = bound * tanh(fc3(relu(fc2(relu(fc1(s))))))   (net_mlp.py:29-40; parameter names fc1/fc2/fc3 so that a
     reference state_dict loads unchanged)"""
@@ -19,7 +65,7 @@ class Actor(nn.Module):
         self.action_bound = action_bound
 
     def forward(self, s):
-        return torch.tanh(self.fc3(F.relu(self.fc2(F.relu(self.fc1(s)))))) * self.action_bound
+        return torch.tanh(linear(self.fc3, F.relu(linear(self.fc2, F.relu(linear(self.fc1, s)))))) * self.action_bound
 
 
 class TwinCritic(nn.Module):
@@ -33,11 +79,12 @@ class TwinCritic(nn.Module):
 
     def q1(self, s, a):
         x = torch.cat([s, a], dim=1)
-        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x)))))
+        return linear(self.fc3, F.relu(linear(self.fc2, F.relu(linear(self.fc1, x)))))
 
     def forward(self, s, a):
         x = torch.cat([s, a], dim=1)
-        return self.fc3(F.relu(self.fc2(F.relu(self.fc1(x))))), self.fc6(F.relu(self.fc5(F.relu(self.fc4(x)))))
+        return (linear(self.fc3, F.relu(linear(self.fc2, F.relu(linear(self.fc1, x))))),
+                linear(self.fc6, F.relu(linear(self.fc5, F.relu(linear(self.fc4, x))))))
 
 
 class GraphedLearner:
@@ -192,10 +239,10 @@ class TD3(GraphedLearner):
             tq1, tq2 = self.target_critic(s2, a2)
             target_q = r + (1 - d) * self.gamma * torch.min(tq1, tq2)
         q1, q2 = self.critic(s, a)
-        critic_loss = F.mse_loss(q1, target_q) + F.mse_loss(q2, target_q)
+        critic_loss = mean_sq(q1 - target_q) + mean_sq(q2 - target_q)          # F.mse_loss + F.mse_loss, TD3_mlp.py:137
         self._step(critic_loss, self.critic_opt)
         if with_actor:
-            actor_loss = -self.critic.q1(s, self.actor(s)).mean()
+            actor_loss = neg_mean(self.critic.q1(s, self.actor(s)))               # -mean(Q1), TD3_mlp.py:147
             self._step(actor_loss, self.actor_opt)
             self._soft_update(self.actor, self.target_actor)
             self._soft_update(self.critic, self.target_critic)

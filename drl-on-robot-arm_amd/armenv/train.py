@@ -22,13 +22,12 @@ from .td3 import TD3
 
 def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
                 device="cuda:0", actor_kind="actor_f16x3", expl_sigma=0.7 * 0.98, log_every=10, log=print,
-                window_steps=1536, minimal_episodes=5, max_steps=500, use_graphs=None, algo="td3"):
-    # use_graphs: the agent's update replayed from hipGraphs (GraphedLearner.capture): 2-3 x faster iterations (the update is ~130 small
-    # kernels) and OFF by default since round 6 -- on this ROCm / PyTorch build the replayed TD3 update does not learn the reach task
-    # (20-60 % success where the eager update reaches 96-100 % on every seed tried), DADDPG's learns on two seeds of three, and two
-    # replays of one captured update from an identical state are not always the same numbers while eager updates are bit-reproducible
-    # (profiles/r06_td3_hipgraph_learning.txt; the 30-update graph-vs-eager comparison of the tests stays green).  Opt in with True.
-    use_graphs = bool(use_graphs)
+                window_steps=1536, minimal_episodes=5, max_steps=500, use_graphs=True, algo="td3"):
+    # use_graphs: the agent's update replayed from hipGraphs (GraphedLearner.capture): the update is ~130 small kernels, launch-bound
+    # when issued one by one (160 iterations: 7 s against 14 s).  Round 6 found the replayed updates no longer learning and why: a
+    # hipMemsetAsync captured into a hipGraph works on the first replay only on this ROCm build, torch's multi-block reductions
+    # initialise their semaphores with one, so every captured bias gradient went wrong from the second replay on.  The captured update
+    # now contains no such reduction (armenv.td3._CaptureSafeLinear; profiles/r06_td3_hipgraph_learning.txt) and learns like the eager one.
     torch.manual_seed(seed)
     action_bound = 0.7                                            # main.py:87
     env = envs.BatchedReachEnv(num_envs, device=device, seed=seed, max_steps=max_steps)
@@ -76,7 +75,7 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
 
 def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
                device="cuda:0", actor_kind="actor_f16x3", log_every=10, log=print, window_steps=1536, minimal_episodes=5,
-               max_steps=500, task="push", use_graphs=False):
+               max_steps=500, task="push", use_graphs=True):
     """``train_push_with_TD3`` (/root/reference/main.py:449-515) on the device: state_dim 9, action_bound 0.4 (:455-457),
     unclipped exploration noise N(0, 0.4 * 0.98) (:484), push HER relabel rule (utils/rl_utils.py:171-188).  The cube
     follows the build's simplified push-out model, so learning curves are not comparable with the reference's.
@@ -131,7 +130,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--window-steps", type=int, default=1536)
     ap.add_argument("--max-steps", type=int, default=500, help="opt.max_steps_one_episode")
-    ap.add_argument("--graphs", type=int, default=0, help="1: the agent's updates replayed from hipGraphs (faster, not reliable on this build: see train_reach)")
+    ap.add_argument("--graphs", type=int, default=1, help="1: the agent's updates replayed from hipGraphs (default); 0: issued eagerly")
     ap.add_argument("--algo", default="td3", choices=["td3", "daddpg"], help="reach only: the agent (config.py:33's default is DADDPG_MLP)")
     a = ap.parse_args()
     if a.task != "reach":

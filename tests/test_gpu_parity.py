@@ -2112,17 +2112,63 @@ def test_training_loop_daddpg_default_agent(envs):
         assert float((a.critic(held["states"], held["actions"]) - b.critic(held["states"], held["actions"])).abs().max()) < 3e-2
 
 
-@pytest.mark.parametrize("algo", ["td3", "daddpg"])
-def test_training_loop_learns_the_reach_task(envs, algo):
+@pytest.mark.parametrize("algo,graphs", [("td3", True), ("daddpg", True), ("td3", False)])
+def test_training_loop_learns_the_reach_task(envs, algo, graphs):
     """The on-device `run()` loop with its default settings LEARNS: >= 90 % of the episodes finished in the last 20 of 140 iterations end
-    in success (reach_dis 0.01), for train_reach_with_TD3's agent and for the reference's default agent DADDPG.  A regression test of
-    round 6: until then only smoke runs were tested, and the hipGraph update path -- green in its 30-update comparison with the eager
-    one -- had stopped learning (TD3: 20-60 %); it is opt-in now (profiles/r06_td3_hipgraph_learning.txt)."""
+    in success (reach_dis 0.01), for train_reach_with_TD3's agent and for the reference's default agent DADDPG, with the updates
+    replayed from hipGraphs (the default) and issued eagerly.  A regression test of round 6: until then only smoke runs were tested, and
+    the replayed updates had stopped learning (TD3: 20-60 %) -- every captured bias gradient was wrong from the second replay on, because
+    a hipMemsetAsync captured into a hipGraph works once on this build (profiles/r06_td3_hipgraph_learning.txt)."""
     from armenv.train import train_reach
     hist = []
     import json
-    train_reach(iterations=140, log_every=20, log=lambda s_: hist.append(json.loads(s_)), algo=algo)
+    train_reach(iterations=140, log_every=20, log=lambda s_: hist.append(json.loads(s_)), algo=algo, use_graphs=graphs)
     assert hist[-1]["success_rate"] >= 0.9 and hist[-1]["episodes"] > 5000, [round(h["success_rate"], 2) for h in hist]
+
+
+@pytest.mark.parametrize("agent", ["td3", "daddpg"])
+def test_captured_update_has_the_eager_updates_gradients(envs, agent):
+    """The root cause test of round 6: from an identical state (parameters, Adam moments and step counters, batch) the update replayed
+    from its hipGraph leaves the SAME gradients in the optimisers' .grad buffers as the eager update -- all of them, on every one of
+    40 consecutive updates (before the fix: the bias gradients were off by 0.4-0.7 on two updates of three from the seventh on, every
+    other gradient bit-identical) -- and reports the same loss."""
+    from armenv.daddpg import DADDPG
+    from armenv.td3 import TD3
+    torch.manual_seed(0)
+    G = TD3(6, 3, 0.7, policy_noise=0.0) if agent == "td3" else DADDPG(6, 3, 0.7)
+    B = 2048
+    buf = G.capture(B)
+    gen = torch.Generator(device=DEV); gen.manual_seed(1)
+
+    def snap():
+        return ([{k: v.clone() for k, v in n_.state_dict().items()} for n_ in G._nets()],
+                [[{k: v.clone() for k, v in st.items()} for st in o.state.values()] for o in G._opts()])
+
+    def restore(s_):
+        with torch.no_grad():
+            for n_, sd in zip(G._nets(), s_[0]):
+                for k, v in n_.state_dict().items():
+                    v.copy_(sd[k])
+            for o, sts in zip(G._opts(), s_[1]):
+                for st, saved in zip(o.state.values(), sts):
+                    for k, v in st.items():
+                        v.copy_(saved[k])
+    params = [p for o in G._opts() for p in o.param_groups[0]["params"]]
+    worst = 0.0
+    for it in range(40):
+        for k, v in buf.items():
+            v.copy_((torch.rand(v.shape, device=DEV, generator=gen) * (1.1 if v.dtype == torch.uint8 else 1)).to(v.dtype))
+        G.total_it += 1
+        flag = G._flag()
+        s0 = snap()
+        G._graphs["g"][flag].replay()
+        gg, lg = [p.grad.clone() for p in params], float(G._graphs["loss"])
+        restore(s0)
+        le = float(G._update(buf["states"], buf["actions"], buf["rewards"].view(-1, 1), buf["next_states"],
+                             buf["dones"].to(torch.float32).view(-1, 1), flag))
+        worst = max(worst, max(float((a_ - p.grad).abs().max()) for a_, p in zip(gg, params)))
+        assert abs(lg - le) < 1e-5 * max(1.0, abs(le)), (it, lg, le)
+    assert worst < 1e-5, worst
 
 
 def test_training_loop_smoke_pick(envs):
