@@ -294,6 +294,28 @@ def test_daddpg_learner_reproduces_the_reference_updates():
     assert tuple(a1["fc1.weight"].shape) == (256, 6) and tuple(c["fc1.weight"].shape) == (256, 9) and tuple(c["fc3.weight"].shape) == (1, 256)
 
 
+def test_capture_safe_linear_is_linear():
+    """armenv.td3._CaptureSafeLinear -- the form of y = x W^T + b the learners use under hipGraph capture, whose backward holds no
+    multi-block reduction (the bias gradient is a GEMM with a row of ones: round 6, profiles/r06_td3_hipgraph_learning.txt) -- has
+    F.linear's value and gradients (f64: to rounding), also when the input needs no gradient; mean_sq / neg_mean are the losses' values."""
+    import torch
+    import torch.nn.functional as F
+    from armenv.td3 import _CaptureSafeLinear, mean_sq, neg_mean
+    torch.manual_seed(4)
+    for needs_x in (True, False):
+        x = torch.randn(37, 9, dtype=torch.float64, requires_grad=needs_x)
+        w = torch.randn(5, 9, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(5, dtype=torch.float64, requires_grad=True)
+        up = torch.randn(37, 5, dtype=torch.float64)
+        ins = (x, w, b) if needs_x else (w, b)
+        ya, yb = _CaptureSafeLinear.apply(x, w, b), F.linear(x, w, b)
+        assert torch.allclose(ya, yb, rtol=0, atol=1e-13)
+        for ga, gb in zip(torch.autograd.grad((ya * up).sum(), ins), torch.autograd.grad((yb * up).sum(), ins)):
+            assert torch.allclose(ga, gb, rtol=0, atol=1e-12)
+    d = torch.randn(64, 1, dtype=torch.float64)
+    assert abs(float(mean_sq(d)) - float(F.mse_loss(d, torch.zeros_like(d)))) < 1e-15 and abs(float(neg_mean(d)) + float(d.mean())) < 1e-15
+
+
 def test_bench_launcher_relays_exit_code_and_refuses_contradictions():
     """`python bench.py --gpus 2` without WORLD_SIZE starts its own two ranks (torch.distributed.run on a free 127.0.0.1 port) and
     relays their exit code -- here, without a GPU, both ranks fail, and the launcher must come back non-zero without a JSON line
