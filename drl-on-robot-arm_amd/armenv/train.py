@@ -75,7 +75,7 @@ def train_reach(num_envs=1024, iterations=200, rollout_steps=32, updates=48, bat
 
 def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batch_size=2048, her_ratio=0.8, seed=0,
                device="cuda:0", actor_kind="actor_f16x3", log_every=10, log=print, window_steps=1536, minimal_episodes=5,
-               max_steps=500, task="push", use_graphs=True):
+               max_steps=500, task="push", use_graphs=True, algo="td3"):
     """``train_push_with_TD3`` (/root/reference/main.py:449-515) on the device: state_dim 9, action_bound 0.4 (:455-457),
     unclipped exploration noise N(0, 0.4 * 0.98) (:484), push HER relabel rule (utils/rl_utils.py:171-188).  The cube
     follows the build's simplified push-out model, so learning curves are not comparable with the reference's.
@@ -84,7 +84,7 @@ def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batc
     action_bound = 0.4
     Env = envs.BatchedPushEnv if task == "push" else envs.BatchedPickEnv
     env = Env(num_envs, device=device, seed=seed, max_steps=max_steps)
-    agent = TD3(9, 3, action_bound, device=device)
+    agent = (DADDPG if algo == "daddpg" else TD3)(9, 3, action_bound, device=device)
     static = agent.capture(batch_size) if use_graphs else None
     store = TrajectoryStore(device=device, seed=seed, capacity_steps=window_steps)
     obs = env.reset()
@@ -92,8 +92,11 @@ def train_push(num_envs=1024, iterations=300, rollout_steps=32, updates=48, batc
     c_prev = env.counters()
     t0 = time.perf_counter()
     for it in range(iterations):
-        env.set_policy(actor_kind, action_bound=action_bound, noise_sigma=action_bound * 0.98, noise_clip=1e9,
-                       actor_state_dict=agent.actor_state_dict())
+        if algo == "daddpg":
+            env.set_policy_daddpg(*agent.policy_state_dicts(), action_bound=action_bound, noise_sigma=action_bound * 0.98, noise_clip=1e9)
+        else:
+            env.set_policy(actor_kind, action_bound=action_bound, noise_sigma=action_bound * 0.98, noise_clip=1e9,
+                           actor_state_dict=agent.actor_state_dict())
         obs0 = obs.clone()
         out = env.rollout(rollout_steps, None, out=bufs, want_actions=True, want_terminal_obs=True)
         obs = out["obs"][-1]
@@ -131,11 +134,11 @@ def main():
     ap.add_argument("--window-steps", type=int, default=1536)
     ap.add_argument("--max-steps", type=int, default=500, help="opt.max_steps_one_episode")
     ap.add_argument("--graphs", type=int, default=1, help="1: the agent's updates replayed from hipGraphs (default); 0: issued eagerly")
-    ap.add_argument("--algo", default="td3", choices=["td3", "daddpg"], help="reach only: the agent (config.py:33's default is DADDPG_MLP)")
+    ap.add_argument("--algo", default="td3", choices=["td3", "daddpg"], help="the agent (config.py:33's default is DADDPG_MLP)")
     a = ap.parse_args()
     if a.task != "reach":
         train_push(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
-                   window_steps=a.window_steps, max_steps=a.max_steps, task=a.task, use_graphs=a.graphs == 1)
+                   window_steps=a.window_steps, max_steps=a.max_steps, task=a.task, use_graphs=a.graphs == 1, algo=a.algo)
         return
     train_reach(a.num_envs, a.iterations, a.rollout_steps, a.updates, a.batch_size, seed=a.seed, actor_kind=a.actor,
                 expl_sigma=a.sigma, window_steps=a.window_steps, max_steps=a.max_steps, algo=a.algo,

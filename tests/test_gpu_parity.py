@@ -2176,6 +2176,10 @@ def test_training_loop_smoke_pick(envs):
                              max_steps=20, log_every=4, log=lambda s: None, task="pick")
     assert len(hist) == 2 and hist[-1]["env_steps"] == 256 * 16 * 8 and hist[-1]["episodes"] >= 256 * 5
     assert all(torch.isfinite(p).all() for p in agent.actor.parameters())
+    # the default agent (two actors, one critic on 9-float observations) on the push task
+    agent, hist = train_push(num_envs=256, iterations=8, rollout_steps=16, updates=4, batch_size=256, window_steps=64,
+                             max_steps=20, log_every=4, log=lambda s: None, task="push", algo="daddpg")
+    assert hist[-1]["env_steps"] == 256 * 16 * 8 and all(torch.isfinite(p).all() for n_ in agent._nets() for p in n_.parameters())
 
 
 def test_device_summary_matches_host_reduction(envs, O, kuka):
