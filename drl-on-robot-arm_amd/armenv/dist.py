@@ -114,8 +114,8 @@ class RcclComm:
     torch.distributed's "nccl" backend runs on): ncclGetUniqueId on rank 0, the id handed round with the job's process group, then
     ncclCommInitRank on every rank.  Why, beside torch.distributed: the one collective of this path -- the logging all-gather -- is
     issued from inside the rollout loop, and its ISSUE is what the loop pays; `dist.all_gather_into_tensor(async_op=True)` costs the
-    host 150-250 us per call (measured: gpurun_out/r06/bench_rccl_world1_*.json host_us.gather_issue), more than a 20-step rollout
-    launch runs; ncclAllGather on a stream the caller names is one C call.  Creation happens in a helper thread with a time limit: a
+    host 100-250 us per call (profiles/r06_bench_rccl_world1_torchdist.json: host_us.gather_issue 125), as long as a 20-step rollout
+    launch runs; ncclAllGather on a stream the caller names is one C call (profiles/r06_bench_rccl_world1.json: 42 us for the whole issue).  Creation happens in a helper thread with a time limit: a
     rank that cannot make the communicator reports so, the ranks agree (all-reduce), and the caller falls back to torch.distributed."""
 
     FLOAT32 = 7           # rccl.h ncclDataType_t
@@ -253,7 +253,7 @@ class ReturnGatherer:
 
     def warm_up(self, rounds=3):
         """A few gathers of zeros, waited for: the first collectives on a fresh communicator set up channels and load kernels
-        (the first ncclAllGather of a job cost the issuing host 214 us against 68 for the second, gpurun_out/r06/p3_rccl_world1_*.json);
+        (the first ncclAllGather of a job cost the issuing host 214 us against 40-68 afterwards, DESIGN.md section 6);
         a rollout loop that logs from its first step on does not want that inside it."""
         for _ in range(int(rounds)):
             self.launch_into(lambda st: st.zero_())

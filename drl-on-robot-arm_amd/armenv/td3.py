@@ -103,13 +103,12 @@ class GraphedLearner:
 
     @staticmethod
     def _step(loss, opt):
-        """loss.backward() + opt.step() of the reference's updates, written so that it means the same thing eagerly and replayed from
-        a hipGraph: the gradients of `loss` with respect to the parameters `opt` owns -- and nothing else -- go into PERSISTENT .grad
-        buffers (made once, written by a copy).  `loss.backward()` also leaves gradients on every other parameter the loss touches (the
-        actor loss on the critic's: the reference wipes them with the next zero_grad) and re-makes the .grad tensors it writes to; under
-        capture those tensors live in the capturing graph's private pool, and with two captured variants sharing one optimiser the
-        graphed TD3 never got past 20-60 % success on the reach task where the eager one reaches 100 % (round 6, gpurun_out/r06:
-        train_bisect; policy_freq = 1, one variant only, was fine)."""
+        """loss.backward() + opt.step() of the reference's updates with the .grad bookkeeping made explicit: the gradients of `loss` with
+        respect to the parameters `opt` owns -- and nothing else -- go into PERSISTENT .grad buffers (made once, written by a copy), so
+        that the two captured variants of an update and the eager path share one set of gradient tensors in ordinary memory.
+        (`loss.backward()` also leaves gradients on every other parameter the loss touches -- the actor loss on the critic's, which the
+        reference wipes with the next zero_grad -- and under capture re-makes the .grad tensors inside the capturing graph's private
+        pool.)  Bit-identical to backward() + step() eagerly."""
         params = [p for g in opt.param_groups for p in g["params"]]
         grads = torch.autograd.grad(loss, params)
         with torch.no_grad():
