@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define ARMENV_NJ 7
-#define ARMENV_ABI_VERSION 6
+#define ARMENV_ABI_VERSION 6   /* 6: + armenv_set_policy_daddpg, armenv_episode_returns_f32, ARMENV_POLICY_DADDPG; ArmEnvConfig unchanged since 5 */
 
 enum {
   ARMENV_OK = 0,
