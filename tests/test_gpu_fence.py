@@ -574,12 +574,13 @@ def test_bench_one_rank_over_rccl_keeps_the_single_gpu_value():
     """the N-rank `value` measures the engine.  The driver's shape (`--steps 20 --warmup 5`, 65 536 envs) as ONE
     rank down the whole RCCL path (process group, dist.barrier() around the bracket, the logging all-gather issued inside the region)
     against the plain single-GPU run of the same session: the same bracket code, so the two `value`s are commensurable -- round 5's
-    bracket lost 41 % here.  Both runs are medians-free single regions, so the bound is on the better of two tries."""
+    bracket lost 41 % here.  Both runs are single regions of ~150 us on a shared host, so the bound is on the best of three tries
+    (measured pairs: 0.955-0.965, profiles/r06_bench_rccl_world1.json beside r06_bench_plain_beside_rccl.json)."""
     from test_gpu_parity import _run_bench
     argv = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--secondary-legs", "0", "--fence-steps", "0",
             "--large-batch", "0", "--ab-regions", "0", "--repeat-regions", "2"]
     best = 0.0
-    for _ in range(2):
+    for _ in range(3):
         plain = _run_bench(argv)
         rccl = _run_bench_env(argv)
         assert rccl["config"]["rccl_backend"] == "nccl" and rccl["config"]["gathers_in_timed_region"] == 1
